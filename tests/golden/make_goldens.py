@@ -1,0 +1,377 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); nothing of the reference travels:
+the fixtures hold inputs/outputs (data) only.  Re-run with
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+Fixture families:
+  graphs.npz   the small test graphs (scipy CSR arrays)
+  g1_norm.npz  normalised adjacency values (fp64) of LaplacianGraphOp / PprGraphOp._construct_adj
+  g2_prop.npz  GraphOp.propagate outputs (through the reference's ctypes -> libmatmul.so path)
+  g3_agg.npz   every MessageOp.aggregate output (+ parameter / input gradients for learnable ops)
+  g4_models.npz  SGC / GAMLP / NAFS / ... preprocess + model_forward outputs with saved params
+  g5_errors.json the exception contract of propagate / aggregate
+Dense inputs are regenerated from tests/golden/inputs.py (integer hash), not stored.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from inputs import hash_matrix, hash_positive  # noqa: E402
+
+from sgl.operators.graph_op import LaplacianGraphOp, PprGraphOp  # noqa: E402
+from sgl.operators.message_op import (  # noqa: E402
+    ConcatMessageOp, IterateLearnableWeightedMessageOp, LastMessageOp, LearnableWeightedMessageOp,
+    MaxMessageOp, MeanMessageOp, MinMessageOp, OverSmoothDistanceWeightedOp, ProjectedConcatMessageOp,
+    SimpleWeightedMessageOp, SumMessageOp)
+
+
+# ------------------------------------------------------------------------------------------
+# graphs
+# ------------------------------------------------------------------------------------------
+def g_sym_binary(n, p, seed):
+    rng = np.random.default_rng(seed)
+    m = rng.random((n, n)) < p
+    m = np.triu(m, 1)
+    m = m | m.T
+    return sp.csr_matrix(m.astype(np.float32))
+
+
+def g_dir_weighted(n, m, seed):
+    """directed, weighted, with duplicate (r,c) pairs (summed by csr_matrix, as data/base_data.py:29
+    does), a few self loops, and node n-1 isolated"""
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, n - 1, m)
+    c = rng.integers(0, n - 1, m)
+    w = rng.uniform(0.25, 3.0, m).astype(np.float32)
+    r[:4], c[:4] = [1, 5, 7, 7], [1, 5, 9, 9]          # self loops + an explicit duplicate pair
+    return sp.csr_matrix((w, (r, c)), shape=(n, n), dtype=np.float32)
+
+
+def g_power_law(n, avg_deg, max_deg, seed, weight=1.0):
+    rng = np.random.default_rng(seed)
+    w = np.clip(rng.lognormal(0.0, 1.2, n), 0.05, None)
+    w = np.minimum(w / w.sum() * n * avg_deg, max_deg)
+    p = w / w.sum()
+    m = int(n * avg_deg / 2)
+    a = rng.choice(n, m, p=p)
+    b = rng.choice(n, m, p=p)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    adj = sp.coo_matrix((np.ones(len(a), np.float32), (a, b)), shape=(n, n)).tocsr()
+    adj = adj + adj.T
+    adj.data[:] = weight
+    adj = adj.tocsr().astype(np.float32)
+    adj.sort_indices()
+    return adj
+
+
+GRAPHS = {
+    "sym64": g_sym_binary(64, 0.08, 1),
+    "dir40": g_dir_weighted(40, 160, 2),
+    "pl2000": g_power_law(2000, 7.0, 300, 3),
+    "pl256": g_power_law(256, 8.0, 80, 4),
+    "pl256w2": g_power_law(256, 8.0, 80, 4, weight=2.0),
+}
+
+
+def save_graphs():
+    out = {}
+    for name, g in GRAPHS.items():
+        assert g.has_canonical_format
+        out[name + "|indptr"] = g.indptr.astype(np.int32)
+        out[name + "|indices"] = g.indices.astype(np.int32)
+        out[name + "|data"] = g.data.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "graphs.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+# G1: normalisation
+# ------------------------------------------------------------------------------------------
+def gen_g1():
+    out = {}
+    for name in ("sym64", "dir40", "pl2000"):
+        g = GRAPHS[name]
+        variants = [("lap", r, None) for r in (0.0, 0.3, 0.5, 1.0)]
+        variants += [("ppr", 0.5, a) for a in (0.1, 0.15, 0.2, 0.3)] + [("ppr", 0.3, 0.15)]
+        struct = None
+        for kind, r, a in variants:
+            op = LaplacianGraphOp(1, r=r) if kind == "lap" else PprGraphOp(1, r=r, alpha=a)
+            adj = op._construct_adj(g)
+            assert sp.isspmatrix_csr(adj) and adj.dtype == np.float64
+            adj.sort_indices()   # .tocsr() from CSC already yields sorted rows; make it explicit
+            key = f"{name}|{kind}|{r}" + ("" if a is None else f"|{a}")
+            if struct is None:
+                struct = (adj.indptr.copy(), adj.indices.copy())
+                out[name + "|indptr"] = adj.indptr.astype(np.int32)
+                out[name + "|indices"] = adj.indices.astype(np.int32)
+            else:
+                assert np.array_equal(struct[0], adj.indptr) and np.array_equal(struct[1], adj.indices), key
+            out[key] = adj.data.astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, "g1_norm.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+# G2: propagate (reference ctypes -> libmatmul.so path, Linux branch base_op.py:31-32)
+# ------------------------------------------------------------------------------------------
+G2_CONFIGS = [
+    # key, graph, op kind, r, alpha, d, K, order, keep ("all" hops or "last")
+    ("d1_k10", "pl256", "lap", 0.5, None, 1, 10, "C", "all"),
+    ("d3_k5", "pl256", "lap", 0.5, None, 3, 5, "C", "all"),
+    ("d7_k3", "pl256", "lap", 0.3, None, 7, 3, "C", "all"),
+    ("d16_k10", "pl256", "lap", 0.5, None, 16, 10, "C", "all"),
+    ("d16_k3_F", "pl256", "lap", 0.5, None, 16, 3, "F", "all"),
+    ("d16_k3_w2", "pl256w2", "lap", 0.5, None, 16, 3, "C", "all"),
+    ("d16_k3_ppr", "pl256", "ppr", 0.5, 0.15, 16, 3, "C", "all"),
+    ("d47_k2_dir", "dir40", "ppr", 0.5, 0.3, 47, 2, "C", "all"),
+    ("d100_k3", "pl256", "lap", 0.5, None, 100, 3, "C", "last"),
+    ("d128_k3", "pl256", "lap", 0.5, None, 128, 3, "C", "last"),
+    ("d147_k5", "pl256", "lap", 0.5, None, 147, 5, "C", "last"),
+    ("d500_k3", "sym64", "lap", 0.5, None, 500, 3, "C", "last"),
+    ("d32_k3_pl2000", "pl2000", "lap", 0.5, None, 32, 3, "C", "last"),
+]
+
+
+def gen_g2():
+    out = {}
+    meta = {}
+    for key, gname, kind, r, a, d, K, order, keep in G2_CONFIGS:
+        g = GRAPHS[gname]
+        x = hash_matrix(g.shape[0], d, seed=len(key) + d, order=order)
+        op = LaplacianGraphOp(K, r=r) if kind == "lap" else PprGraphOp(K, r=r, alpha=a)
+        feats = op.propagate(g, x)
+        assert len(feats) == K + 1 and all(f.dtype == torch.float32 for f in feats)
+        if keep == "all":
+            for h in range(1, K + 1):
+                out[f"{key}|h{h}"] = feats[h].numpy().copy()
+        else:
+            out[f"{key}|h{K}"] = feats[K].numpy().copy()
+        # cheap pin for the hops that are not stored: fp64 sum of every hop
+        out[f"{key}|sums"] = np.array([f.numpy().astype(np.float64).sum() for f in feats])
+        meta[key] = dict(graph=gname, kind=kind, r=r, alpha=a, d=d, K=K, order=order, keep=keep,
+                         seed=len(key) + d)
+    np.savez_compressed(os.path.join(HERE, "g2_prop.npz"), **out)
+    with open(os.path.join(HERE, "g2_prop.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+# ------------------------------------------------------------------------------------------
+# G3: aggregators
+# ------------------------------------------------------------------------------------------
+AGG_N, AGG_D, AGG_K = 96, 12, 4
+
+
+def agg_feats(requires_grad=False):
+    feats = [torch.from_numpy(hash_matrix(AGG_N, AGG_D, seed=100 + h).copy()) for h in range(AGG_K + 1)]
+    # make hop h look a bit "smoother" than hop 0 so NAFS weights are not degenerate
+    feats = [(feats[0] * (1.0 - 0.15 * h) + feats[h] * (0.15 * h)).contiguous() for h in range(AGG_K + 1)]
+    if requires_grad:
+        feats = [f.clone().requires_grad_(True) for f in feats]
+    return feats
+
+
+def state_arrays(module):
+    return {k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def gen_g3():
+    out = {}
+    H = AGG_K + 1
+    feats = agg_feats()
+    for j, f in enumerate(feats):
+        out[f"feat{j}"] = f.numpy().copy()     # stored: they are derived (blend) values
+    out["last"] = LastMessageOp().aggregate(feats).numpy().copy()
+    for (s, e) in ((0, H), (1, H - 1)):
+        tag = f"{s}_{e}"
+        out[f"concat|{tag}"] = ConcatMessageOp(s, e).aggregate(feats).numpy().copy()
+        out[f"mean|{tag}"] = MeanMessageOp(s, e).aggregate(feats).numpy().copy()
+        out[f"sum|{tag}"] = SumMessageOp(s, e).aggregate(feats).numpy().copy()
+        out[f"max|{tag}"] = MaxMessageOp(s, e).aggregate(feats).numpy().copy()
+        out[f"min|{tag}"] = MinMessageOp(s, e).aggregate(feats).numpy().copy()
+    for (s, e) in ((0, H), (1, H)):
+        out[f"simple_weighted|alpha0.85|{s}_{e}"] = SimpleWeightedMessageOp(s, e, "alpha", 0.85).aggregate(feats).numpy().copy()
+    hc = [0.5, 0.2, 0.15, 0.1, 0.05]
+    out["simple_weighted|hand_crafted|0_5"] = SimpleWeightedMessageOp(0, H, "hand_crafted", hc).aggregate(feats).numpy().copy()
+    out["simple_weighted|hand_crafted|w"] = np.asarray(hc, dtype=np.float32)
+    out["over_smooth"] = OverSmoothDistanceWeightedOp().aggregate(feats).numpy().copy()
+
+    gout = torch.from_numpy(hash_matrix(AGG_N, AGG_D, seed=777).copy())
+    for kind, args in (("simple", (AGG_K,)), ("simple_allow_neg", (AGG_K,)), ("gate", (AGG_D,)),
+                       ("ori_ref", (AGG_D,)), ("jk", (AGG_K, AGG_D))):
+        for (s, e) in ((0, H), (1, H)):
+            torch.manual_seed(1234 + len(kind) + s)
+            op = LearnableWeightedMessageOp(s, e, kind, *args)
+            fg = agg_feats(requires_grad=True)
+            y = op.aggregate(fg)
+            (y * gout).sum().backward()
+            tag = f"learnable|{kind}|{s}_{e}"
+            out[tag + "|out"] = y.detach().numpy().copy()
+            for k, v in state_arrays(op).items():
+                out[tag + "|param|" + k] = v
+            for k, p in op.named_parameters():
+                out[tag + "|grad|" + k] = p.grad.numpy().copy()
+            for j, f in enumerate(fg):
+                out[tag + f"|dfeat{j}"] = (f.grad if f.grad is not None else torch.zeros_like(f)).numpy().copy()
+
+    torch.manual_seed(99)
+    op = IterateLearnableWeightedMessageOp(0, H, "recursive", AGG_D)
+    fg = agg_feats(requires_grad=True)
+    y = op.aggregate(fg)
+    (y * gout).sum().backward()
+    out["iterate|0_5|out"] = y.detach().numpy().copy()
+    for k, v in state_arrays(op).items():
+        out["iterate|0_5|param|" + k] = v
+    for k, p in op.named_parameters():
+        out["iterate|0_5|grad|" + k] = p.grad.numpy().copy()
+    for j, f in enumerate(fg):
+        out[f"iterate|0_5|dfeat{j}"] = f.grad.numpy().copy()
+
+    # proj_concat needs sgl.models.simple_models -> imported lazily below (after stubbing)
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# model import recipe
+# ------------------------------------------------------------------------------------------
+def import_models():
+    for m in ["torch_geometric", "torch_geometric.data", "torch_geometric.datasets", "torch_geometric.io",
+              "torch_geometric.utils", "torch_sparse", "ogb", "ogb.nodeproppred", "munkres", "gensim",
+              "gensim.models", "openbox"]:
+        sys.modules.setdefault(m, MagicMock())
+    import sgl.dataset  # noqa: F401  (must come first: circular import)
+    import sgl.models.base_model  # noqa: F401
+    pkg = types.ModuleType("sgl.models.homo")
+    pkg.__path__ = [REF + "/sgl/models/homo"]
+    sys.modules["sgl.models.homo"] = pkg
+
+    def load(n):
+        spec = importlib.util.spec_from_file_location("sgl.models.homo." + n, f"{REF}/sgl/models/homo/{n}.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    return {n: load(n) for n in ("sgc", "ssgc", "sign", "gbp", "gamlp", "gamlp_recursive", "nafs", "pasca_v3")}
+
+
+def gen_g3_proj(out):
+    torch.manual_seed(5)
+    H = AGG_K + 1
+    op = ProjectedConcatMessageOp(0, H, AGG_D, 8, 2)
+    op.eval()
+    feats = agg_feats()
+    with torch.no_grad():
+        y = op.aggregate(feats)
+    out["proj_concat|0_5|out"] = y.numpy().copy()
+    for k, v in state_arrays(op).items():
+        out["proj_concat|0_5|param|" + k] = v
+
+
+def gen_g4(mods):
+    out = {}
+    g = GRAPHS["pl2000"]
+    n, d, C, K = g.shape[0], 16, 5, 3
+    x = hash_matrix(n, d, seed=4242)
+    idx = np.arange(0, n, 10)
+    out["idx"] = idx
+    specs = {
+        "SGC": (mods["sgc"].SGC, (K, d, C)),
+        "SSGC": (mods["ssgc"].SSGC, (K, d, C)),
+        "SIGN": (mods["sign"].SIGN, (K, d, C, 32, 2)),
+        "GBP": (mods["gbp"].GBP, (K, d, C, 32, 2)),
+        "GAMLP": (mods["gamlp"].GAMLP, (K, d, C, 32, 2)),
+        "GAMLPRecursive": (mods["gamlp_recursive"].GAMLPRecursive, (K, d, C, 32, 2)),
+        "NAFS": (mods["nafs"].NAFS, (K, d, C)),
+        "PASCA_V3": (mods["pasca_v3"].PASCA_V3, (K, 2, d, C, 32, 3)),
+    }
+    for name, (cls, args) in specs.items():
+        torch.manual_seed(7)
+        model = cls(*args)
+        model.eval()
+        model.preprocess(g, x)
+        with torch.no_grad():
+            y = model.model_forward(idx, torch.device("cpu"))
+        out[f"{name}|out"] = y.numpy().copy()
+        for k, v in state_arrays(model).items():
+            out[f"{name}|param|{k}"] = v
+        if name == "PASCA_V3":
+            with torch.no_grad():
+                full = model.model_forward(range(n), torch.device("cpu"))
+                post = model.postprocess(g, full)
+            out[f"{name}|post"] = post.numpy().copy()[idx]
+    np.savez_compressed(os.path.join(HERE, "g4_models.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+# G5: error contract
+# ------------------------------------------------------------------------------------------
+def gen_g5():
+    g = GRAPHS["sym64"]
+    x = hash_matrix(64, 4, seed=1)
+    cases = {}
+
+    def record(name, fn):
+        try:
+            r = fn()
+            cases[name] = {"raised": None, "returned_type": type(r).__name__,
+                           "returned_msg": str(r) if isinstance(r, Exception) else None}
+        except Exception as e:  # noqa: BLE001
+            cases[name] = {"raised": type(e).__name__, "msg": str(e)}
+
+    record("propagate_tensor_feature", lambda: LaplacianGraphOp(2).propagate(g, torch.from_numpy(x)))
+    record("propagate_coo_adj", lambda: LaplacianGraphOp(2).propagate(g.tocoo(), x))
+    record("propagate_dense_adj", lambda: LaplacianGraphOp(2).propagate(g.toarray(), x))
+    record("propagate_shape_mismatch", lambda: LaplacianGraphOp(2).propagate(g, x[:10]))
+    record("ppr_dense_adj", lambda: PprGraphOp(2).propagate(np.zeros((3, 3)), x))
+    record("aggregate_not_list", lambda: MeanMessageOp(0, 2).aggregate(torch.zeros(2, 2)))
+    record("aggregate_not_tensor", lambda: MeanMessageOp(0, 2).aggregate([np.zeros((2, 2)), np.zeros((2, 2))]))
+    record("simple_weighted_bad_type", lambda: SimpleWeightedMessageOp(0, 2, "nope", 0.5))
+    record("simple_weighted_alpha_int", lambda: SimpleWeightedMessageOp(0, 2, "alpha", 1))
+    record("simple_weighted_alpha_range", lambda: SimpleWeightedMessageOp(0, 2, "alpha", 1.5))
+    record("simple_weighted_nargs", lambda: SimpleWeightedMessageOp(0, 2, "alpha"))
+    record("simple_weighted_hand_bad", lambda: SimpleWeightedMessageOp(0, 2, "hand_crafted", 3))
+    record("learnable_bad_type", lambda: LearnableWeightedMessageOp(0, 2, "nope", 1))
+    record("learnable_simple_nargs", lambda: LearnableWeightedMessageOp(0, 2, "simple"))
+    record("learnable_jk_nargs", lambda: LearnableWeightedMessageOp(0, 2, "jk", 3))
+    record("iterate_bad_type", lambda: IterateLearnableWeightedMessageOp(0, 2, "nope", 4))
+    record("iterate_nargs", lambda: IterateLearnableWeightedMessageOp(0, 2, "recursive"))
+    with open(os.path.join(HERE, "g5_errors.json"), "w") as f:
+        json.dump(cases, f, indent=1, sort_keys=True)
+
+
+def main():
+    save_graphs()
+    gen_g1()
+    gen_g2()
+    g3 = gen_g3()
+    mods = import_models()
+    gen_g3_proj(g3)
+    np.savez_compressed(os.path.join(HERE, "g3_agg.npz"), **g3)
+    gen_g4(mods)
+    gen_g5()
+    tot = 0
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith((".npz", ".json")):
+            sz = os.path.getsize(os.path.join(HERE, fn))
+            tot += sz
+            print(f"{fn:20s} {sz / 1024:9.1f} KiB")
+    print(f"total {tot / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""Pin the CPU oracle (oracle/) to the reference: every golden vector in tests/golden/ was
+produced by importing the reference itself (make_goldens.py).  CPU-only; runs everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from inputs import hash_matrix
+
+G1_VARIANTS = [("lap", r, None) for r in (0.0, 0.3, 0.5, 1.0)] + \
+              [("ppr", 0.5, a) for a in (0.1, 0.15, 0.2, 0.3)] + [("ppr", 0.3, 0.15)]
+
+
+@pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
+def test_g1_normalisation_matches_reference(goldens, gname):
+    g = goldens.graph(gname)
+    g1 = goldens.npz("g1_norm")
+    n = g.shape[0]
+    for kind, r, a in G1_VARIANTS:
+        key = f"{gname}|{kind}|{r}" + ("" if a is None else f"|{a}")
+        ptr, col, val = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, r, a)
+        # structure: integer work -> bit exact
+        assert np.array_equal(ptr, g1[gname + "|indptr"]), key
+        assert np.array_equal(col, g1[gname + "|indices"]), key
+        ref = g1[key]
+        # fp64 values: same operation order -> expect bit equality; allow 2 ulp(fp64) for libm pow
+        assert np.allclose(val, ref, rtol=5e-16, atol=0), key
+        # what the SpMM consumes (fp32-rounded, operators/utils.py:32) must be identical
+        assert np.array_equal(val.astype(np.float32), ref.astype(np.float32)), key
+
+
+def _g2_cases(goldens):
+    return goldens.json("g2_prop")
+
+
+def test_g2_propagate_bit_exact(goldens):
+    g2 = goldens.npz("g2_prop")
+    meta = goldens.json("g2_prop")
+    for key, m in meta.items():
+        g = goldens.graph(m["graph"])
+        n = g.shape[0]
+        x = hash_matrix(n, m["d"], seed=m["seed"], order=m["order"])
+        norm = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, m["r"], m["alpha"])
+        feats = oracle.propagate(norm, x, m["K"])
+        hops = range(1, m["K"] + 1) if m["keep"] == "all" else [m["K"]]
+        for h in hops:
+            assert np.array_equal(feats[h], g2[f"{key}|h{h}"]), f"{key} hop {h} not bit-equal to reference"
+        sums = np.array([f.astype(np.float64).sum() for f in feats])
+        assert np.array_equal(sums, g2[f"{key}|sums"]), key
+
+
+def test_spmm_oracle_equals_reference_binary(goldens):
+    """C restatement == the reference's own compiled matmul.c (oracle/_ref), bit for bit."""
+    if oracle.load_reference_lib() is None:
+        pytest.skip("oracle/_ref/libmatmul.so not present (built only where /root/reference exists)")
+    for gname, d in (("pl2000", 37), ("dir40", 5), ("pl256", 128)):
+        g = goldens.graph(gname)
+        n = g.shape[0]
+        ptr, col, val = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, 0.5)
+        x = hash_matrix(n, d, seed=9)
+        a = oracle.oracle_spmm(ptr, col, val, x)
+        b = oracle.reference_spmm(ptr, col, val, x)
+        c = oracle.oracle_spmm_scalar(ptr, col, val, x)
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)
+
+
+def _feats(goldens):
+    g3 = goldens.npz("g3_agg")
+    return [g3[f"feat{j}"] for j in range(5)], g3
+
+
+def test_g3_simple_aggregators(goldens):
+    feats, g3 = _feats(goldens)
+    H = 5
+    assert np.array_equal(oracle.agg_last(feats), g3["last"])
+    for (s, e) in ((0, H), (1, H - 1)):
+        tag = f"{s}_{e}"
+        assert np.array_equal(oracle.agg_concat(feats, s, e), g3[f"concat|{tag}"])
+        assert np.array_equal(oracle.agg_sum(feats, s, e), g3[f"sum|{tag}"])
+        assert np.array_equal(oracle.agg_mean(feats, s, e), g3[f"mean|{tag}"])
+        assert np.array_equal(oracle.agg_max(feats, s, e), g3[f"max|{tag}"])
+        assert np.array_equal(oracle.agg_min(feats, s, e), g3[f"min|{tag}"])
+
+
+def test_g3_weighted_aggregators(goldens):
+    feats, g3 = _feats(goldens)
+    H = 5
+    for (s, e) in ((0, H), (1, H)):
+        y = oracle.agg_simple_weighted(feats, s, e, "alpha", 0.85)
+        assert oracle.parity_ok(y, g3[f"simple_weighted|alpha0.85|{s}_{e}"], 1e-6)
+    y = oracle.agg_simple_weighted(feats, 0, H, "hand_crafted", g3["simple_weighted|hand_crafted|w"])
+    assert oracle.parity_ok(y, g3["simple_weighted|hand_crafted|0_5"], 1e-6)
+    y = oracle.agg_over_smooth_distance(feats)
+    assert oracle.parity_ok(y, g3["over_smooth"], 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["simple", "simple_allow_neg", "gate", "ori_ref", "jk"])
+def test_g3_learnable_forward(goldens, kind):
+    feats, g3 = _feats(goldens)
+    H = 5
+    for (s, e) in ((0, H), (1, H)):
+        tag = f"learnable|{kind}|{s}_{e}"
+        if kind in ("simple", "simple_allow_neg"):
+            p = g3[tag + "|param|_LearnableWeightedMessageOp__learnable_weight"]
+            y = oracle.agg_learnable_weighted(feats, s, e, kind, param=p)
+        else:
+            w = g3[tag + "|param|_LearnableWeightedMessageOp__learnable_weight.weight"]
+            b = g3[tag + "|param|_LearnableWeightedMessageOp__learnable_weight.bias"]
+            y = oracle.agg_learnable_weighted(feats, s, e, kind, weight=w, bias=b)
+        rep = oracle.parity_report(y, g3[tag + "|out"], 1e-5)
+        assert rep["ok"], (tag, rep)
+
+
+def test_g3_iterate(goldens):
+    feats, g3 = _feats(goldens)
+    w = g3["iterate|0_5|param|_IterateLearnableWeightedMessageOp__learnable_weight.weight"]
+    b = g3["iterate|0_5|param|_IterateLearnableWeightedMessageOp__learnable_weight.bias"]
+    y = oracle.agg_iterate_learnable(feats, 0, 5, w, b)
+    rep = oracle.parity_report(y, g3["iterate|0_5|out"], 1e-5)
+    assert rep["ok"], rep
+
+
+def test_parity_metric_rejects_wrong():
+    ref = hash_matrix(50, 8, seed=3)
+    bad = ref.copy()
+    bad[7, 3] += 1e-3
+    assert oracle.parity_ok(ref, ref)
+    assert not oracle.parity_ok(bad, ref)
+    assert not oracle.parity_ok(ref[:10], ref)
