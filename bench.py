@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- SGAP pre-propagation SpMM throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S1_products] [--no-cpu-baseline]
+
+One "step" = one full k-hop propagation (prop_steps SpMM launches, k=3 for the headline config
+"SGC prop_steps=3 on ogbn-products") over a synthetic ogbn-products-shaped graph (Chung-Lu, N=2 449 029,
+61.86 M undirected edges, d=100; sgl_amd/synthetic.py).  A_hat, X and all hop buffers are resident in HBM when
+the timed region starts.  value = nnz(A_hat) * d * k * steps / time  [edge*featdim/s], whole job.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): A_hat is row-sharded (nnz-balanced), every rank
+keeps a full replica of the current feature block and the per-hop all-gather runs as grouped point-to-point
+RCCL transfers overlapped with the SpMM of the next row piece (sgl_amd/dist.py).  Total work is fixed ->
+"scaling": "strong".
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus
+  roofline     : dominant kernel (spmm_kernel) algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
+  cpu_baseline : the reference's own CPU kernel (oracle/_ref, else the C restatement) timed on this node's host
+                 cores on a bounded row sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES = 8.0e12  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_hop(n, nnz, d):
+    """SURVEY.md section 8(d) no-reuse gather model: gathered X rows + (col,val) + rowptr + Y write"""
+    return nnz * d * 4 + nnz * 8 + (n + 1) * 4 + n * d * 4
+
+
+def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
+    """time the reference CPU kernel (csrc/matmul.c:23-40) on the first rows of the same A_hat / X"""
+    import oracle  # test infrastructure: allowed here as the reported baseline only
+    n = rowptr.numel() - 1
+    rows = min(n, 400_000)
+    rp = rowptr[:rows + 1].cpu().numpy()
+    nnz_s = int(rp[-1])
+    c = col[:nnz_s].cpu().numpy()
+    v = val[:nnz_s].cpu().numpy()
+    xh = x.cpu().numpy()
+    xh = np.ascontiguousarray(xh[:, :d])
+    kind = "reference" if oracle.load_reference_lib() is not None and xh.shape[0] * d < 2 ** 31 else "port"
+    fn = (lambda: oracle.reference_spmm(rp, c, v, xh, n_rows=rows)) if kind == "reference" else \
+         (lambda: oracle.oracle_spmm(rp, c, v, xh, n_rows=rows))
+    fn()  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    for _ in range(5):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    t = float(np.median(times))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    return {"value": nnz_s * d / t, "unit": "edge*featdim/s", "cores": threads, "kind": kind,
+            "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}, one hop, median of {len(times)} reps, "
+                      f"OpenMP static schedule, {threads} threads",
+            "ms_per_hop_sample": t * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("SGL_BENCH_WORKLOAD", "S1_products"))
+    ap.add_argument("--pieces", type=int, default=4, help="row pieces per rank for comm/compute overlap (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the sgl_amd hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from sgl_amd import device as dev
+    from sgl_amd import synthetic
+    from sgl_amd.dist import ShardedPropagator, balanced_bounds, piece_bounds
+
+    wl = synthetic.WORKLOADS[args.workload]
+    n, d, K = wl["n"], wl["d"], wl["k"]
+
+    # ---- build the workload (untimed): graph -> A_hat on device, features -------------------------------
+    t_setup = time.perf_counter()
+    if rank == 0:
+        a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=args.seed, device=device)
+        rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)  # LaplacianGraphOp(r=0.5)
+        del a_ptr, a_col, a_val
+        x0 = synthetic.features_torch(n, d, seed=args.seed, device=device,
+                                      kind="pubmed" if args.workload.startswith("S0") else "normal")
+        meta = torch.tensor([col.numel()], dtype=torch.int64, device=device)
+    else:
+        meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if world > 1:
+        dist.broadcast(meta, 0)
+        nnz = int(meta.item())
+        if rank != 0:
+            rowptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+            col = torch.empty(nnz, dtype=torch.int32, device=device)
+            val = torch.empty(nnz, dtype=torch.float32, device=device)
+            x0 = torch.empty((n, d), dtype=torch.float32, device=device)
+        for t in (rowptr, col, val, x0):
+            dist.broadcast(t, 0)
+    nnz = int(col.numel())
+    torch.cuda.synchronize()
+
+    cpu = None
+    if world == 1:
+        csr = dev.DeviceCSR(rowptr, col, val, (n, n), strict=args.strict)
+        info = csr.info()
+        bufs = [dev.alloc_rows(n, d, device) for _ in range(K)]
+        src0 = dev.upload_rows(x0, device) if (d % 4) else x0
+
+        def step():
+            cur = dev.padded_parent(src0)
+            for h in range(K):
+                out = dev.padded_parent(bufs[h])
+                csr.spmm(cur, out=out)
+                cur = out
+    else:
+        rp_host = rowptr.cpu().numpy()
+        bounds = balanced_bounds(rp_host, world)
+        pb = np.stack([piece_bounds(rp_host, int(bounds[g]), int(bounds[g + 1]), args.pieces) for g in range(world)])
+        pieces = []
+        for p in range(args.pieces):
+            r0, r1 = int(pb[rank, p]), int(pb[rank, p + 1])
+            nb, ne = int(rp_host[r0]), int(rp_host[r1])
+            rp_local = (rowptr[r0:r1 + 1] - rowptr[r0]).contiguous()
+            c_local, v_local = col[nb:ne].contiguous(), val[nb:ne].contiguous()
+            h = dev.DeviceCSR(rp_local, c_local, v_local, (r1 - r0, n), strict=args.strict)
+            pieces.append(lambda x, out, h=h: h.spmm(x, out=out))
+        prop = ShardedPropagator(pieces, pb, rank, world, n)
+        xbufs = [torch.empty_like(x0) for _ in range(min(2, max(K - 1, 0)))]
+        info = {"n_items": None, "n_pieces": None, "n_long_rows": None}
+        del rowptr  # keep col/val alive through the piece views
+
+        def step():
+            prop.propagate(x0, K, x_buffers=xbufs)
+    setup_s = time.perf_counter() - t_setup
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        try:
+            cpu = cpu_baseline(rowptr, col, val, x0, d)
+        except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
+            cpu = {"value": None, "unit": "edge*featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        value = nnz * d * K * args.steps / elapsed
+        hop_s = (gpu_ms * 1e-3) / (K * args.steps)           # average launch duration from HIP events
+        alg = algorithmic_bytes_per_hop(n, nnz, d)
+        if world > 1:
+            alg = alg / world                                 # per-GPU share of one hop
+        achieved = alg / hop_s
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if tj.get("workload") == args.workload and world == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "pre-prop SpMM throughput (edge*featdim/s), ogbn-products k=3",
+            "value": value, "unit": "edge*featdim/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: SGC prop_steps={K} pre-propagation on an ogbn-products-shaped "
+                                   f"Chung-Lu graph, LaplacianGraphOp r=0.5",
+                       "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
+                       "parallelism": "single GPU" if world == 1 else f"row-sharded x{world} + p2p all-gather, {args.pieces} pieces",
+                       "summation": "strict (bit-exact reference order)" if args.strict else "fast (2 slots/wave for d=100)",
+                       "plan": info, "setup_s": round(setup_s, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_BYTES, "traffic": traffic,
+                         "kernel": "spmm_kernel", "algorithmic_bytes_per_launch": alg,
+                         "avg_launch_ms": hop_s * 1e3},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/*
+ * sgl_hip.h -- C ABI of libsgl_hip.so, the MI355X (gfx950) implementation of SGL's SGAP
+ * pre-propagation hot path.  Plain C: pointers and sizes only, no torch / C++ types.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   FloatCSRMulDenseOMP        sgl/operators/csrc/matmul.h:5, matmul.c:23-40 -- the ONE native symbol the
+ *                              reference resolves at run time (sgl/operators/utils.py:14,27,38).  Same name,
+ *                              same argument list, same accumulate-into-`answer` semantics, host pointers.
+ *   FloatCSRMulDense           sgl/operators/csrc/cudamatmul.c:28-146 (cudamatmul.h:4) -- the reference's dead
+ *                              cuSPARSE twin bound by utils.py:43-73.  Same name/arguments, overwrite (beta=0)
+ *                              semantics, returns 0/1 like the original.
+ *   sgl_csr_create/_destroy,   device-resident successor of the two above: the CSR lives on the GPU across the
+ *   sgl_spmm_f32               K hops of GraphOp.propagate (sgl/operators/base_op.py:29-35) instead of being
+ *                              re-uploaded per call (cudamatmul.c:57-74,129).
+ *   sgl_norm_*                 adj_to_symmetric_norm (sgl/operators/utils.py:76-88) + the Laplacian / PPR
+ *                              _construct_adj wrappers (graph_op/laplacian_graph_op.py:12-19,
+ *                              graph_op/ppr_graph_op.py:13-21), on device.
+ *   sgl_hop_reduce_f32         Sum/Mean/Max/Min MessageOp._combine (message_op/{sum,mean,max,min}_message_op.py)
+ *                              and one_dim_weighted_add (sgl/operators/utils.py:91-102).
+ *   sgl_hop_wsum2d_f32(+_bwd)  two_dim_weighted_add (sgl/operators/utils.py:105-116, torch.bmm) and its autograd.
+ *   sgl_hop_wsum1d_bwd_f32     autograd of one_dim_weighted_add w.r.t. the weight vector.
+ *   sgl_hop_concat_f32         ConcatMessageOp._combine (message_op/concat_message_op.py:11-12, torch.hstack).
+ *   sgl_nafs_f32               OverSmoothDistanceWeightedOp._combine (message_op/over_smooth_distance_op.py:11-33).
+ *   sgl_gather_rows_f32        the `feat[idx]` row gather of BaseSGAPModel.forward (sgl/models/base_model.py:58,60).
+ *
+ * Conventions
+ *   - every function returns int: 0 = success, non-zero = failure (hipError_t value or SGL_ERR_*); the message is
+ *     available from sgl_last_error() (thread-local).  Nothing is printed.  (The reference's CPU symbol returns
+ *     void and its GPU twin prints + returns EXIT_FAILURE, cudamatmul.c:7-25; Python never checks either.)
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensor data_ptr()); pointers named
+ *     h_* are HOST pointers.  The library owns only what it allocates inside handles.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are stream-ordered and do not
+ *     synchronise the device unless documented.
+ *   - matrices are row-major float32 with an explicit leading dimension (elements).  Column indices are int32,
+ *     row pointers int64, all element offsets are computed in 64 bits (the reference overflows `int` at
+ *     N*d >= 2^31, matmul.c:29,33).
+ */
+#ifndef SGL_HIP_H
+#define SGL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGL_OK 0
+#define SGL_ERR_INVALID 1001  /* bad argument                                  */
+#define SGL_ERR_NO_DEVICE 1002 /* no usable HIP device                          */
+#define SGL_ERR_UNSUPPORTED 1003
+#define SGL_ERR_ALLOC 1004
+
+#define SGL_MAX_HOPS 64 /* upper bound on the number of hop matrices one aggregator call accepts */
+
+/* ---- library ----------------------------------------------------------------------------------------------- */
+int sgl_version(void);                /* 10000*major + 100*minor + patch */
+const char *sgl_last_error(void);     /* thread-local, never NULL */
+int sgl_device_count(int *count);     /* 0 and *count = 0 when there is no GPU: never aborts */
+/* integer tuning knobs for experiments ("spmm_unroll", "spmm_nt", "spmm_group", ...); unknown key -> SGL_ERR_INVALID */
+int sgl_set_tuning(const char *key, int64_t value);
+int sgl_get_tuning(const char *key, int64_t *value);
+
+/* ---- execution plan (host-only, no GPU needed; exported so it can be unit-tested on CPU) ------------------- */
+/* Partition of the rows of a CSR matrix into work items for the SpMM kernel:
+ *   - "items": runs of <= 63 consecutive rows holding about `item_nnz` non-zeros, processed by one wavefront each;
+ *   - rows longer than `long_row_nnz` are cut into "pieces" of <= long_row_nnz non-zeros whose partial sums are
+ *     combined in storage order by a fix-up pass (never with atomics: results are deterministic).
+ * long_row_nnz <= 0 disables splitting (every row is summed by one sequential fmaf chain, bit-compatible with
+ * the reference's matmul.c:23-40 order). */
+typedef struct sgl_plan sgl_plan_t;
+int sgl_plan_build(sgl_plan_t **out, const int64_t *h_rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz);
+/* counts[0]=n_items, [1]=n_pieces, [2]=n_long_rows, [3]=max rows in an item, [4]=max nnz in an item, [5]=n_rows */
+int sgl_plan_counts(const sgl_plan_t *plan, int64_t counts[8]);
+/* copy-out (any pointer may be NULL): items as (row_begin,row_end) pairs [2*n_items];
+ * pieces as (nnz_begin [n_pieces] int64, nnz_len [n_pieces] int32, row [n_pieces] int32);
+ * long rows as (row [n_long] int32, first_piece [n_long+1] int32) */
+int sgl_plan_export(const sgl_plan_t *plan, int32_t *h_items, int64_t *h_piece_begin, int32_t *h_piece_len,
+                    int32_t *h_piece_row, int32_t *h_long_row, int32_t *h_long_first);
+void sgl_plan_destroy(sgl_plan_t *plan);
+
+/* ---- device CSR handle ------------------------------------------------------------------------------------- */
+typedef struct sgl_csr sgl_csr_t;
+
+#define SGL_CSR_STRICT_ORDER 0x1u /* no row splitting, one non-zero per step: bit-exact reference order */
+#define SGL_CSR_NO_XCD_REMAP 0x2u /* keep the hardware's round-robin block->XCD order                  */
+
+/* Wraps caller-owned device arrays (NOT copied; they must outlive the handle) and builds the execution plan
+ * (copies the row pointers to the host once: this call synchronises `stream`).
+ * item_nnz / long_row_nnz: 0 = library default. */
+int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
+                   const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
+                   int32_t long_row_nnz, void *stream);
+int sgl_csr_destroy(sgl_csr_t *csr);
+/* info[0]=n_rows [1]=n_cols [2]=nnz [3]=n_items [4]=n_pieces [5]=n_long_rows [6]=flags [7]=workspace bytes */
+int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
+
+/* Y[0:n_rows, 0:d] = A . X[0:n_cols, 0:d]  (+ Y if accumulate != 0), fp32, fmaf accumulation in CSR order.
+ * accumulate = 0 is the cuSPARSE-twin semantics (beta = 0, cudamatmul.c:46); accumulate = 1 is the CPU kernel's
+ * (matmul.c:37).  X and Y must not overlap.  ldx, ldy >= d. */
+int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
+                 int accumulate, void *stream);
+
+/* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */
+/* matmul.h:5 -- accumulates into `answer` (caller pre-zeroes it, utils.py:31).  Errors are recorded in
+ * sgl_last_error() (the reference symbol is void). */
+void FloatCSRMulDenseOMP(float answer[], float data[], int indices[], int indptr[], float mat[], int mat_row,
+                         int mat_col);
+/* cudamatmul.c:28 -- overwrites `answer`; returns 0 on success, 1 on failure (EXIT_SUCCESS / EXIT_FAILURE). */
+int FloatCSRMulDense(float answer[], int data_nnz, float data[], int indices[], int indptr[], float mat[],
+                     int mat_row, int mat_col);
+
+/* ---- normalisation on device (adj_to_symmetric_norm, operators/utils.py:76-88) ----------------------------- */
+/* Input: canonical CSR of A (sorted columns, no duplicates), n x n, values fp32, on device.
+ * Output: canonical CSR of  A_hat = D^{r-1} (A+I)^T D^{-r}   [then (1-alpha) A_hat + alpha I when use_alpha != 0]
+ * with nnz_out = nnz(A  U  diag).  Arithmetic in fp64 exactly in the reference's order, rounded to fp32 at the
+ * end (where utils.py:32 rounds).  Two-step protocol so the caller owns the output buffers:
+ *   1. sgl_norm_prepare(...)  -> *nnz_out   (counts missing diagonal entries; synchronises `stream`)
+ *   2. sgl_norm_execute(...)  fills d_out_rowptr [n+1], d_out_col [nnz_out], d_out_val [nnz_out]
+ *      (and d_out_val64 [nnz_out] when not NULL: the fp64 values before rounding, for parity tests). */
+int sgl_norm_prepare(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, int64_t *nnz_out,
+                     void *stream);
+int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                     double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
+                     int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream);
+
+/* ---- per-hop aggregators (MessageOp._combine) -------------------------------------------------------------- */
+#define SGL_REDUCE_SUM 0  /* ((X0 + X1) + X2) + ...            sum_message_op.py:10   */
+#define SGL_REDUCE_MEAN 1 /* sum, then one true division by H  mean_message_op.py:10  */
+#define SGL_REDUCE_MAX 2  /* NaN-propagating                   max_message_op.py:12   */
+#define SGL_REDUCE_MIN 3  /*                                   min_message_op.py:12   */
+#define SGL_REDUCE_WSUM 4 /* sum_h w[h] * X_h, d_w = H floats  operators/utils.py:91-102 */
+
+/* h_x: HOST array of n_hops DEVICE pointers; h_ldx: host array of leading dimensions (NULL = all d). */
+int sgl_hop_reduce_f32(int op, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w,
+                       float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream);
+/* out[n, k] = sum_h W[n, h] * X_h[n, k]   (W row-major [n, n_hops], leading dimension ldw) */
+int sgl_hop_wsum2d_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw,
+                       float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream);
+/* backward of the above: dW[n,h] = <dOut[n,:], X_h[n,:]> (d_dw may be NULL);
+ * dX_h[n,k] = W[n,h] * dOut[n,k] for every non-NULL h_dx[h] (h_dx may be NULL) */
+int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw,
+                           const float *d_dout, int64_t lddo, float *d_dw, int64_t lddw, float *const *h_dx,
+                           const int64_t *h_lddx, int64_t n, int64_t d, void *stream);
+/* backward of SGL_REDUCE_WSUM w.r.t. the weights: d_dw[h] = sum_{n,k} dOut[n,k] * X_h[n,k]   (d_dw: H floats,
+ * overwritten; deterministic two-level reduction; d_scratch: >= sgl_hop_wsum1d_bwd_scratch(n_hops) floats) */
+int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops);
+int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,
+                           int64_t lddo, float *d_dw, float *d_scratch, int64_t n, int64_t d, void *stream);
+/* out[:, h*d:(h+1)*d] = X_h */
+int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                       int64_t n, int64_t d, void *stream);
+/* NAFS: W[n,h] = softmax_h( <X_0[n],X_h[n]> / (|X_h[n]|+1e-10) / (|X_0[n]|+1e-10) ), out = sum_h W[n,h] X_h[n]
+ * d_w_out (optional, [n, n_hops] leading dimension ldw) receives W. */
+int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                 float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
+/* out[i, :] = X[idx[i], :]   (idx: int64 on device; negative indices are NOT wrapped) */
+int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
+                        float *d_out, int64_t ldo, int64_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGL_HIP_H */

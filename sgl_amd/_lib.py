@@ -1,0 +1,126 @@
+"""ctypes binding of libsgl_hip.so (C ABI declared in include/sgl_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or a device function is
+called without a GPU, this module raises.  torch is imported first so that the HIP runtime
+the library binds to (SONAME libamdhip64.so.7) is the one torch already loaded -- device
+pointers from torch tensors are then valid inside the library."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL: shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgl_hip.so")
+
+SGL_CSR_STRICT_ORDER = 0x1
+SGL_CSR_NO_XCD_REMAP = 0x2
+SGL_REDUCE_SUM, SGL_REDUCE_MEAN, SGL_REDUCE_MAX, SGL_REDUCE_MIN, SGL_REDUCE_WSUM = 0, 1, 2, 3, 4
+SGL_MAX_HOPS = 64
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol of include/sgl_hip.h
+PROTOTYPES = {
+    "sgl_version": (c_int, []),
+    "sgl_last_error": (c_char_p, []),
+    "sgl_device_count": (c_int, [POINTER(c_int)]),
+    "sgl_set_tuning": (c_int, [c_char_p, c_int64]),
+    "sgl_get_tuning": (c_int, [c_char_p, POINTER(c_int64)]),
+    "sgl_plan_build": (c_int, [POINTER(c_void_p), c_void_p, c_int64, c_int32, c_int32]),
+    "sgl_plan_counts": (c_int, [c_void_p, POINTER(c_int64)]),
+    "sgl_plan_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_plan_destroy": (None, [c_void_p]),
+    "sgl_csr_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_uint32,
+                               c_int32, c_int32, c_void_p]),
+    "sgl_csr_destroy": (c_int, [c_void_p]),
+    "sgl_csr_info": (c_int, [c_void_p, POINTER(c_int64)]),
+    "sgl_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "FloatCSRMulDenseOMP": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "FloatCSRMulDense": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "sgl_norm_prepare": (c_int, [c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
+    "sgl_norm_execute": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_hop_reduce_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                   c_void_p]),
+    "sgl_hop_wsum2d_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                   c_void_p]),
+    "sgl_hop_wsum2d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                       c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "sgl_hop_wsum1d_bwd_scratch": (c_int64, [c_int]),
+    "sgl_hop_wsum1d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                       c_int64, c_void_p]),
+    "sgl_hop_concat_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_nafs_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                             c_void_p]),
+    "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                    c_void_p]),
+}
+
+
+class SglHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SglHipError(
+                f"{LIB_PATH} is missing: build it with `python -m sgl_amd.csrc.build` (needs hipcc). "
+                "sgl_amd has no CPU fallback for the propagation hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().sgl_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SglHipError(f"{what or 'libsgl_hip'} failed (code {rc}): {last_error()}")
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().sgl_device_count(ctypes.byref(n)), "sgl_device_count")
+    return n.value
+
+
+def require_gpu():
+    if not torch.cuda.is_available() or device_count() < 1:
+        raise SglHipError("no MI355X/HIP device visible: the sgl_amd propagation path is GPU-only (no CPU fallback)")
+
+
+def set_tuning(key, value):
+    check(lib().sgl_set_tuning(key.encode(), int(value)), f"sgl_set_tuning({key})")
+
+
+def get_tuning(key):
+    v = c_int64(0)
+    check(lib().sgl_get_tuning(key.encode(), ctypes.byref(v)), f"sgl_get_tuning({key})")
+    return v.value
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def hop_arrays(tensors):
+    """(host array of device pointers, host array of leading dimensions) for a list of 2-D row-major
+    float32 CUDA tensors (column stride 1)."""
+    n = len(tensors)
+    ptrs = (c_void_p * n)(*[t.data_ptr() for t in tensors])
+    lds = (c_int64 * n)(*[t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)) for t in tensors])
+    return ptrs, lds

@@ -1,0 +1,27 @@
+"""Process-wide defaults of the MI355X propagation path (overridable per operator through ctor kwargs).
+
+device        where propagation runs and where the hop matrices stay ("cuda" = current device)
+host_output   True  -> GraphOp.propagate returns CPU FloatTensors exactly like the reference
+              False -> the K+1 hop matrices stay resident in HBM (`.to(device)` is then a no-op and the
+                       row gathers of BaseSGAPModel.forward run on the GPU)
+strict_types  True  -> reject torch.Tensor features / non-float32 input with the reference's exceptions
+              False -> superset: torch tensors and any float dtype are accepted
+strict_order  True  -> SpMM walks every row as ONE sequential fmaf chain (bit-exact with the reference's
+                       matmul.c:23-40 order); False -> fastest lane layout (same result within 1e-5)
+cache_adj     reuse the normalised device adjacency across propagate() calls on the same scipy matrix
+"""
+import os
+
+
+def _env_bool(name, default):
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    return v.strip().lower() in ("1", "true", "yes", "on")
+
+
+device = os.environ.get("SGL_AMD_DEVICE", "cuda")
+host_output = _env_bool("SGL_AMD_HOST_OUTPUT", False)
+strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
+strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
+cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)

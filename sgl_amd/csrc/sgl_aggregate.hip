@@ -1,0 +1,576 @@
+// Per-hop aggregators (MessageOp._combine) for gfx950: row-wise, single pass over the H hop matrices.
+// Reference semantics: sgl/operators/message_op/*.py and sgl/operators/utils.py:91-116 (table in SURVEY.md App. A).
+// All kernels are HBM-streaming: 16-byte loads per lane, consecutive lanes on consecutive addresses of a row.
+// Arithmetic order mirrors the reference's torch-CPU order where that is defined (sum/mean/max/min are bit-exact).
+#include "sgl_common.h"
+
+namespace {
+
+struct Hops {
+    const float *p[SGL_MAX_HOPS];
+    int64_t ld[SGL_MAX_HOPS];
+};
+struct HopsOut {
+    float *p[SGL_MAX_HOPS];
+    int64_t ld[SGL_MAX_HOPS];
+};
+
+using f4 = float __attribute__((ext_vector_type(4)));
+
+template <int VEC>
+struct Vt;
+template <>
+struct Vt<1> {
+    using type = float;
+};
+template <>
+struct Vt<4> {
+    using type = f4;
+};
+
+template <int VEC, typename F>
+__device__ __forceinline__ typename Vt<VEC>::type vmap2(const typename Vt<VEC>::type &a, const typename Vt<VEC>::type &b, F f) {
+    typename Vt<VEC>::type r;
+    if constexpr (VEC == 1) {
+        r = f(a, b);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r[e] = f(a[e], b[e]);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float nan_max(float r, float x) { return (x > r || x != x) ? x : r; }
+__device__ __forceinline__ float nan_min(float r, float x) { return (x < r || x != x) ? x : r; }
+
+// ---- elementwise reductions over hops --------------------------------------------------------------------
+template <int OP, int VEC>
+__global__ __launch_bounds__(256) void hop_reduce_kernel(const Hops hx, const int n_hops, const float *__restrict__ w,
+                                                         float *__restrict__ out, const int64_t ldo, const int64_t n,
+                                                         const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * VEC;
+        V acc;
+        {
+            const V x0 = *reinterpret_cast<const V *>(hx.p[0] + row * hx.ld[0] + col);
+            if constexpr (OP == SGL_REDUCE_SUM || OP == SGL_REDUCE_MEAN) {
+                // Python sum() starts from int 0: 0 + X_s  (sum_message_op.py:10)
+                V z;
+                if constexpr (VEC == 1) z = 0.f; else z = (V){0.f, 0.f, 0.f, 0.f};
+                acc = vmap2<VEC>(z, x0, [](float a, float b) { return __fadd_rn(a, b); });
+            } else if constexpr (OP == SGL_REDUCE_WSUM) {
+                const float w0 = w[0];
+                acc = vmap2<VEC>(x0, x0, [w0](float a, float) { return __fmul_rn(a, w0); });
+            } else {
+                acc = x0;
+            }
+        }
+        for (int h = 1; h < n_hops; ++h) {
+            const V x = *reinterpret_cast<const V *>(hx.p[h] + row * hx.ld[h] + col);
+            if constexpr (OP == SGL_REDUCE_SUM || OP == SGL_REDUCE_MEAN) {
+                acc = vmap2<VEC>(acc, x, [](float a, float b) { return __fadd_rn(a, b); });
+            } else if constexpr (OP == SGL_REDUCE_MAX) {
+                acc = vmap2<VEC>(acc, x, [](float a, float b) { return nan_max(a, b); });
+            } else if constexpr (OP == SGL_REDUCE_MIN) {
+                acc = vmap2<VEC>(acc, x, [](float a, float b) { return nan_min(a, b); });
+            } else {  // WSUM: rounded product, then add (operators/utils.py:100-101: mul, then sum)
+                const float wh = w[h];
+                acc = vmap2<VEC>(acc, x, [wh](float a, float b) { return __fadd_rn(a, __fmul_rn(b, wh)); });
+            }
+        }
+        if constexpr (OP == SGL_REDUCE_MEAN) {
+            const float hf = (float)n_hops;
+            acc = vmap2<VEC>(acc, acc, [hf](float a, float) { return __fdiv_rn(a, hf); });  // true division
+        }
+        *reinterpret_cast<V *>(out + row * ldo + col) = acc;
+    }
+}
+
+// out[n,k] = sum_h W[n,h] X_h[n,k]; FMA: fma chain from 0 (bmm-like); !FMA: rounded product then add (NAFS loop)
+template <int VEC, bool FMA>
+__global__ __launch_bounds__(256) void hop_wsum2d_kernel(const Hops hx, const int n_hops, const float *__restrict__ w,
+                                                         const int64_t ldw, float *__restrict__ out, const int64_t ldo,
+                                                         const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * VEC;
+        V acc;
+        if constexpr (VEC == 1) acc = 0.f; else acc = (V){0.f, 0.f, 0.f, 0.f};
+        const float *wr = w + row * ldw;
+        for (int h = 0; h < n_hops; ++h) {
+            const V x = *reinterpret_cast<const V *>(hx.p[h] + row * hx.ld[h] + col);
+            const float wh = wr[h];
+            if constexpr (FMA)
+                acc = vmap2<VEC>(acc, x, [wh](float a, float b) { return __builtin_fmaf(wh, b, a); });
+            else
+                acc = vmap2<VEC>(acc, x, [wh](float a, float b) { return __fadd_rn(a, __fmul_rn(wh, b)); });
+        }
+        *reinterpret_cast<V *>(out + row * ldo + col) = acc;
+    }
+}
+
+// dX_h[n,k] = W[n,h] * dOut[n,k]
+template <int VEC>
+__global__ __launch_bounds__(256) void hop_wsum2d_dx_kernel(const HopsOut dx, const int n_hops, const float *__restrict__ w,
+                                                            const int64_t ldw, const float *__restrict__ dout,
+                                                            const int64_t lddo, const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * VEC;
+        const V g = *reinterpret_cast<const V *>(dout + row * lddo + col);
+        const float *wr = w + row * ldw;
+        for (int h = 0; h < n_hops; ++h) {
+            if (dx.p[h] == nullptr) continue;
+            const float wh = wr[h];
+            const V r = vmap2<VEC>(g, g, [wh](float a, float) { return a * wh; });
+            *reinterpret_cast<V *>(dx.p[h] + row * dx.ld[h] + col) = r;
+        }
+    }
+}
+
+// ---- row-wise reductions: LPR lanes cooperate on one row, 64/LPR rows per wavefront ------------------------
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// dW[n,h] = <dOut[n,:], X_h[n,:]>
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void hop_rowdot_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
+                                                         const int64_t ldg, float *__restrict__ dw, const int64_t lddw,
+                                                         const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    constexpr int RPB = 256 / LPR;  // rows per block
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    for (int h = 0; h < n_hops; ++h) {
+        float acc = 0.f;
+        if (live) {
+            for (int c = l * VEC; c < d; c += LPR * VEC) {
+                const V gv = *reinterpret_cast<const V *>(g + r * ldg + c);
+                const V xv = *reinterpret_cast<const V *>(hx.p[h] + r * hx.ld[h] + c);
+                if constexpr (VEC == 1) {
+                    acc = __builtin_fmaf(gv, xv, acc);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc = __builtin_fmaf(gv[e], xv[e], acc);
+                }
+            }
+        }
+        acc = group_sum<LPR>(acc);
+        if (live && l == 0) dw[r * lddw + h] = acc;
+    }
+}
+
+// NAFS weights: W[n,h] = softmax_h( <X0,Xh> / (|Xh|+1e-10) / (|X0|+1e-10) )   (over_smooth_distance_op.py:12-22)
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const int n_hops, float *__restrict__ wout,
+                                                          const int64_t ldw, const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    float n0 = 0.f;
+    float run_max = -INFINITY;
+    // pass A: c_h for every hop (kept in the W row), running max
+    for (int h = 0; h < n_hops; ++h) {
+        float dot = 0.f, sq = 0.f;
+        if (live) {
+            for (int c = l * VEC; c < d; c += LPR * VEC) {
+                const V a = *reinterpret_cast<const V *>(hx.p[0] + r * hx.ld[0] + c);
+                const V b = *reinterpret_cast<const V *>(hx.p[h] + r * hx.ld[h] + c);
+                if constexpr (VEC == 1) {
+                    dot = __builtin_fmaf(a, b, dot);
+                    sq = __builtin_fmaf(b, b, sq);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        dot = __builtin_fmaf(a[e], b[e], dot);
+                        sq = __builtin_fmaf(b[e], b[e], sq);
+                    }
+                }
+            }
+        }
+        dot = group_sum<LPR>(dot);
+        sq = group_sum<LPR>(sq);
+        const float nh = __fadd_rn(__fsqrt_rn(sq), 1e-10f);
+        if (h == 0) n0 = nh;
+        const float ch = __fdiv_rn(__fdiv_rn(dot, nh), n0);
+        run_max = fmaxf(run_max, ch);
+        if (live && l == 0) wout[r * ldw + h] = ch;
+    }
+    // pass B: softmax over the H scores of this row (lane 0 of the group; H is small)
+    if (live && l == 0) {
+        float *wr = wout + r * ldw;
+        float sum = 0.f;
+        for (int h = 0; h < n_hops; ++h) {
+            const float e = expf(wr[h] - run_max);
+            wr[h] = e;
+            sum += e;
+        }
+        for (int h = 0; h < n_hops; ++h) wr[h] = __fdiv_rn(wr[h], sum);
+    }
+}
+
+// out[i,:] = X[idx[i],:]
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int64_t ldx,
+                                                          const int64_t *__restrict__ idx, const int64_t n_idx,
+                                                          float *__restrict__ out, const int64_t ldo, const int d) {
+    using V = typename Vt<VEC>::type;
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    if (i >= n_idx) return;
+    const int64_t src = idx[i];
+    for (int c = l * VEC; c < d; c += LPR * VEC)
+        *reinterpret_cast<V *>(out + i * ldo + c) = *reinterpret_cast<const V *>(x + src * ldx + c);
+}
+
+// out[:, h*d + k] = X_h[:, k]
+template <int VEC>
+__global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+                                                         const int64_t ldo, const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t per_hop = n * (int64_t)dv;
+    const int64_t total = per_hop * n_hops;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / ((int64_t)dv * n_hops);
+        const int rem = (int)(i - row * (int64_t)dv * n_hops);
+        const int h = rem / dv;
+        const int col = (rem - h * dv) * VEC;
+        *reinterpret_cast<V *>(out + row * ldo + (int64_t)h * d + col) =
+            *reinterpret_cast<const V *>(hx.p[h] + row * hx.ld[h] + col);
+    }
+}
+
+// dw[h] = sum_{n,k} dOut[n,k] X_h[n,k]: per-block partials, then a sequential (deterministic) second level
+constexpr int kW1dBlocks = 1024;
+
+__global__ __launch_bounds__(256) void hop_dot_partial_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
+                                                              const int64_t ldg, float *__restrict__ scratch,
+                                                              const int64_t n, const int d) {
+    __shared__ float red[4];
+    const int64_t total = n * (int64_t)d;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int h = 0; h < n_hops; ++h) {
+        float acc = 0.f;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t row = i / d;
+            const int col = (int)(i - row * d);
+            acc = __builtin_fmaf(g[row * ldg + col], hx.p[h][row * hx.ld[h] + col], acc);
+        }
+        acc = group_sum<64>(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) scratch[(int64_t)blockIdx.x * n_hops + h] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+__global__ void hop_dot_final_kernel(const float *__restrict__ scratch, const int n_blocks, const int n_hops,
+                                     float *__restrict__ dw) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hops) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += scratch[(int64_t)b * n_hops + h];
+    dw[h] = acc;
+}
+
+bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+int fill_hops(Hops &hx, int n_hops, const float *const *h_x, const int64_t *h_ldx, int64_t d, bool &vec4) {
+    if (n_hops < 1 || n_hops > SGL_MAX_HOPS) return sgl::fail(SGL_ERR_INVALID, "n_hops=%d outside [1,%d]", n_hops, SGL_MAX_HOPS);
+    if (!h_x) return sgl::fail(SGL_ERR_INVALID, "NULL hop pointer array");
+    for (int h = 0; h < n_hops; ++h) {
+        hx.p[h] = h_x[h];
+        hx.ld[h] = h_ldx ? h_ldx[h] : d;
+        if (!hx.p[h]) return sgl::fail(SGL_ERR_INVALID, "hop %d: NULL pointer", h);
+        if (hx.ld[h] < d) return sgl::fail(SGL_ERR_INVALID, "hop %d: leading dimension %lld < d", h, (long long)hx.ld[h]);
+        if (!aligned_to(hx.p[h], 4)) return sgl::fail(SGL_ERR_INVALID, "hop %d: pointer not 4-byte aligned", h);
+        if (hx.ld[h] % 4 != 0 || !aligned_to(hx.p[h], 16)) vec4 = false;
+    }
+    for (int h = n_hops; h < SGL_MAX_HOPS; ++h) {
+        hx.p[h] = nullptr;
+        hx.ld[h] = 0;
+    }
+    return SGL_OK;
+}
+
+int stream_grid(int64_t total_threads) {
+    // memory-bound elementwise: cap at 256 CUs x 8 blocks and grid-stride the rest
+    int64_t blocks = (total_threads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int pick_lpr(int64_t d, int vec) {
+    const int64_t lanes = (d + vec - 1) / vec;
+    int lpr = 8;
+    while (lpr < lanes && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+#define SGL_LAUNCH_CHECK(what)                                                                                  \
+    do {                                                                                                        \
+        hipError_t _e = hipGetLastError();                                                                      \
+        if (_e != hipSuccess) return sgl::fail((int)_e, what ": kernel launch failed: %s", hipGetErrorString(_e)); \
+    } while (0)
+
+}  // namespace
+
+SGL_EXPORT int sgl_hop_reduce_f32(int op, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w,
+                                  float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(op >= SGL_REDUCE_SUM && op <= SGL_REDUCE_WSUM, "sgl_hop_reduce_f32: unknown op %d", op);
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_reduce_f32: bad sizes");
+    SGL_REQUIRE(op != SGL_REDUCE_WSUM || d_w, "sgl_hop_reduce_f32: WSUM needs device weights");
+    Hops hx;
+    bool vec4 = (d % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_out, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_out && ldo >= d, "sgl_hop_reduce_f32: bad output");
+    hipStream_t st = sgl::as_stream(stream);
+    const int vec = vec4 ? 4 : 1;
+    const int grid = stream_grid(n * (d / vec));
+#define SGL_RED(OP)                                                                                               \
+    if (vec4)                                                                                                     \
+        hipLaunchKernelGGL((hop_reduce_kernel<OP, 4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, d_out, ldo, n, (int)d); \
+    else                                                                                                          \
+        hipLaunchKernelGGL((hop_reduce_kernel<OP, 1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, d_out, ldo, n, (int)d);
+    switch (op) {
+        case SGL_REDUCE_SUM: SGL_RED(SGL_REDUCE_SUM) break;
+        case SGL_REDUCE_MEAN: SGL_RED(SGL_REDUCE_MEAN) break;
+        case SGL_REDUCE_MAX: SGL_RED(SGL_REDUCE_MAX) break;
+        case SGL_REDUCE_MIN: SGL_RED(SGL_REDUCE_MIN) break;
+        default: SGL_RED(SGL_REDUCE_WSUM) break;
+    }
+#undef SGL_RED
+    SGL_LAUNCH_CHECK("sgl_hop_reduce_f32");
+    return SGL_OK;
+}
+
+static int wsum2d_impl(bool fma, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw,
+                       float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_wsum2d_f32: bad sizes");
+    Hops hx;
+    bool vec4 = (d % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_out, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_w && ldw >= n_hops, "sgl_hop_wsum2d_f32: bad weights");
+    SGL_REQUIRE(d_out && ldo >= d, "sgl_hop_wsum2d_f32: bad output");
+    hipStream_t st = sgl::as_stream(stream);
+    const int grid = stream_grid(n * (d / (vec4 ? 4 : 1)));
+    if (vec4 && fma)
+        hipLaunchKernelGGL((hop_wsum2d_kernel<4, true>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, ldw, d_out, ldo, n, (int)d);
+    else if (vec4)
+        hipLaunchKernelGGL((hop_wsum2d_kernel<4, false>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, ldw, d_out, ldo, n, (int)d);
+    else if (fma)
+        hipLaunchKernelGGL((hop_wsum2d_kernel<1, true>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, ldw, d_out, ldo, n, (int)d);
+    else
+        hipLaunchKernelGGL((hop_wsum2d_kernel<1, false>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_w, ldw, d_out, ldo, n, (int)d);
+    SGL_LAUNCH_CHECK("sgl_hop_wsum2d_f32");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_wsum2d_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w,
+                                  int64_t ldw, float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream) {
+    return wsum2d_impl(true, n_hops, h_x, h_ldx, d_w, ldw, d_out, ldo, n, d, stream);
+}
+
+template <int VEC>
+static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t st, const Hops &hx, int n_hops,
+                          const float *g, int64_t ldg, float *dw, int64_t lddw, int64_t n, int d) {
+    (void)grid_rows_per_block_unused;
+#define SGL_RD(L)                                                                                              \
+    hipLaunchKernelGGL((hop_rowdot_kernel<L, VEC>), dim3((unsigned)((n + (256 / L) - 1) / (256 / L))), dim3(256), 0, st, \
+                       hx, n_hops, g, ldg, dw, lddw, n, d)
+    switch (lpr) {
+        case 8: SGL_RD(8); break;
+        case 16: SGL_RD(16); break;
+        case 32: SGL_RD(32); break;
+        default: SGL_RD(64); break;
+    }
+#undef SGL_RD
+}
+
+SGL_EXPORT int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w,
+                                      int64_t ldw, const float *d_dout, int64_t lddo, float *d_dw, int64_t lddw,
+                                      float *const *h_dx, const int64_t *h_lddx, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: bad sizes");
+    Hops hx;
+    bool vec4 = (d % 4 == 0) && (lddo % 4 == 0) && aligned_to(d_dout, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum2d_bwd_f32: bad dOut");
+    hipStream_t st = sgl::as_stream(stream);
+    if (d_dw) {
+        SGL_REQUIRE(lddw >= n_hops, "sgl_hop_wsum2d_bwd_f32: lddw < n_hops");
+        const int lpr = pick_lpr(d, vec4 ? 4 : 1);
+        SGL_REQUIRE((n + (256 / lpr) - 1) / (256 / lpr) < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: too many rows");
+        if (vec4)
+            launch_rowdot<4>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
+        else
+            launch_rowdot<1>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
+        SGL_LAUNCH_CHECK("sgl_hop_wsum2d_bwd_f32(dW)");
+    }
+    if (h_dx) {
+        SGL_REQUIRE(d_w && ldw >= n_hops, "sgl_hop_wsum2d_bwd_f32: dX needs W");
+        HopsOut dx;
+        bool any = false, v4 = vec4;
+        for (int h = 0; h < SGL_MAX_HOPS; ++h) {
+            dx.p[h] = (h < n_hops) ? h_dx[h] : nullptr;
+            dx.ld[h] = (h < n_hops) ? (h_lddx ? h_lddx[h] : d) : 0;
+            if (dx.p[h]) {
+                any = true;
+                if (dx.ld[h] < d) return sgl::fail(SGL_ERR_INVALID, "sgl_hop_wsum2d_bwd_f32: dX ld < d");
+                if (dx.ld[h] % 4 != 0 || !aligned_to(dx.p[h], 16)) v4 = false;
+            }
+        }
+        if (any) {
+            const int grid = stream_grid(n * (d / (v4 ? 4 : 1)));
+            if (v4)
+                hipLaunchKernelGGL((hop_wsum2d_dx_kernel<4>), dim3(grid), dim3(256), 0, st, dx, n_hops, d_w, ldw, d_dout, lddo, n, (int)d);
+            else
+                hipLaunchKernelGGL((hop_wsum2d_dx_kernel<1>), dim3(grid), dim3(256), 0, st, dx, n_hops, d_w, ldw, d_dout, lddo, n, (int)d);
+            SGL_LAUNCH_CHECK("sgl_hop_wsum2d_bwd_f32(dX)");
+        }
+    }
+    return SGL_OK;
+}
+
+SGL_EXPORT int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops) { return (int64_t)kW1dBlocks * (n_hops > 0 ? n_hops : 1); }
+
+SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,
+                                      int64_t lddo, float *d_dw, float *d_scratch, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_wsum1d_bwd_f32: bad sizes");
+    Hops hx;
+    bool vec4 = false;
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    SGL_REQUIRE(d_dw && d_scratch, "sgl_hop_wsum1d_bwd_f32: NULL output/scratch");
+    hipStream_t st = sgl::as_stream(stream);
+    if (n == 0 || d == 0) {
+        SGL_HIP_CHECK(hipMemsetAsync(d_dw, 0, sizeof(float) * n_hops, st));
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum1d_bwd_f32: bad dOut");
+    int blocks = (int)std::min<int64_t>(kW1dBlocks, (n * d + 255) / 256);
+    hipLaunchKernelGGL(hop_dot_partial_kernel, dim3(blocks), dim3(256), 0, st, hx, n_hops, d_dout, lddo, d_scratch, n, (int)d);
+    SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(partial)");
+    hipLaunchKernelGGL(hop_dot_final_kernel, dim3(1), dim3(64), 0, st, d_scratch, blocks, n_hops, d_dw);
+    SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(final)");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                                  int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_concat_f32: bad sizes");
+    Hops hx;
+    bool vec4 = (d % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_out, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_out && ldo >= d * n_hops, "sgl_hop_concat_f32: bad output");
+    hipStream_t st = sgl::as_stream(stream);
+    const int grid = stream_grid(n * (d / (vec4 ? 4 : 1)) * n_hops);
+    if (vec4)
+        hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    else
+        hipLaunchKernelGGL((hop_concat_kernel<1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    SGL_LAUNCH_CHECK("sgl_hop_concat_f32");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                            float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_nafs_f32: bad sizes");
+    SGL_REQUIRE(d_w_out && ldw >= n_hops, "sgl_nafs_f32: the [n, n_hops] weight buffer is required");
+    Hops hx;
+    bool vec4 = (d % 4 == 0);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    hipStream_t st = sgl::as_stream(stream);
+    const int lpr = pick_lpr(d, vec4 ? 4 : 1);
+    const int64_t blocks = (n + (256 / lpr) - 1) / (256 / lpr);
+    SGL_REQUIRE(blocks < INT32_MAX, "sgl_nafs_f32: too many rows");
+#define SGL_NW(L, V) \
+    hipLaunchKernelGGL((nafs_weight_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_w_out, ldw, n, (int)d)
+    if (vec4) {
+        switch (lpr) {
+            case 8: SGL_NW(8, 4); break;
+            case 16: SGL_NW(16, 4); break;
+            case 32: SGL_NW(32, 4); break;
+            default: SGL_NW(64, 4); break;
+        }
+    } else {
+        switch (lpr) {
+            case 8: SGL_NW(8, 1); break;
+            case 16: SGL_NW(16, 1); break;
+            case 32: SGL_NW(32, 1); break;
+            default: SGL_NW(64, 1); break;
+        }
+    }
+#undef SGL_NW
+    SGL_LAUNCH_CHECK("sgl_nafs_f32(weights)");
+    if (!d_out) return SGL_OK;  // weights only
+    // out = sum_h W[:,h] * X_h accumulated in hop order from 0 with rounded products (over_smooth_distance_op.py:27-31)
+    return wsum2d_impl(false, n_hops, h_x, h_ldx, d_w_out, ldw, d_out, ldo, n, d, stream);
+}
+
+SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
+                                   float *d_out, int64_t ldo, int64_t d, void *stream) {
+    SGL_REQUIRE(n_idx >= 0 && d >= 0 && d < INT32_MAX && n_rows >= 0, "sgl_gather_rows_f32: bad sizes");
+    if (n_idx == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_x && d_idx && d_out && ldx >= d && ldo >= d, "sgl_gather_rows_f32: bad arguments");
+    const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_x, 16) && aligned_to(d_out, 16);
+    hipStream_t st = sgl::as_stream(stream);
+    const int lpr = pick_lpr(d, vec4 ? 4 : 1);
+    const int64_t blocks = (n_idx + (256 / lpr) - 1) / (256 / lpr);
+    SGL_REQUIRE(blocks < INT32_MAX, "sgl_gather_rows_f32: too many rows");
+#define SGL_GR(L, V) \
+    hipLaunchKernelGGL((gather_rows_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, d_idx, n_idx, d_out, ldo, (int)d)
+    if (vec4) {
+        switch (lpr) {
+            case 8: SGL_GR(8, 4); break;
+            case 16: SGL_GR(16, 4); break;
+            case 32: SGL_GR(32, 4); break;
+            default: SGL_GR(64, 4); break;
+        }
+    } else {
+        switch (lpr) {
+            case 8: SGL_GR(8, 1); break;
+            case 16: SGL_GR(16, 1); break;
+            case 32: SGL_GR(32, 1); break;
+            default: SGL_GR(64, 1); break;
+        }
+    }
+#undef SGL_GR
+    SGL_LAUNCH_CHECK("sgl_gather_rows_f32");
+    return SGL_OK;
+}

@@ -1,0 +1,174 @@
+// Host-only part of libsgl_hip.so: error text, tuning knobs, and the SpMM execution-plan builder.
+// No device code here, so these entry points work (and are unit-tested) on a machine without a GPU.
+#include <map>
+#include <mutex>
+
+#include "sgl_common.h"
+
+namespace sgl {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char *get_error() { return g_err.c_str(); }
+
+static std::mutex g_tune_mu;
+static std::map<std::string, int64_t> &tune_map() {
+    static std::map<std::string, int64_t> m = {
+        {"spmm_unroll", 0},      // 0 = default (8); 2/4/8: gathers in flight per lane
+        {"spmm_nt", 0},          // 1 = non-temporal loads for the CSR stream / stores of Y
+        {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
+        {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)
+        {"spmm_xcd_remap", 1},   // contiguous row ranges per XCD
+        {"agg_block", 0},
+    };
+    return m;
+}
+
+int64_t tuning(const char *key, int64_t dflt) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto &m = tune_map();
+    auto it = m.find(key);
+    if (it == m.end()) return dflt;
+    return it->second;
+}
+
+// Greedy partition of the rows into work items (see include/sgl_hip.h, "execution plan").
+int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz) {
+    if (n_rows < 0 || (n_rows > 0 && rowptr == nullptr)) return fail(SGL_ERR_INVALID, "build_plan: bad arguments");
+    if (n_rows >= (int64_t)INT32_MAX) return fail(SGL_ERR_UNSUPPORTED, "build_plan: n_rows >= 2^31 (shard the matrix)");
+    if (item_nnz <= 0) item_nnz = kDefaultItemNnz;
+    const bool split = long_row_nnz > 0;
+    plan = Plan();
+    plan.n_rows = n_rows;
+    plan.long_first.push_back(0);
+    int64_t cur_begin = 0, cur_nnz = 0;
+    auto close_item = [&](int64_t end) {
+        if (end > cur_begin) {
+            plan.items.push_back((int32_t)cur_begin);
+            plan.items.push_back((int32_t)end);
+            plan.max_item_rows = std::max<int64_t>(plan.max_item_rows, end - cur_begin);
+            plan.max_item_nnz = std::max<int64_t>(plan.max_item_nnz, cur_nnz);
+        }
+        cur_begin = end;
+        cur_nnz = 0;
+    };
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t b = rowptr[r], e = rowptr[r + 1];
+        if (e < b) return fail(SGL_ERR_INVALID, "build_plan: row pointers decrease at row %lld", (long long)r);
+        const int64_t deg = e - b;
+        if (!split && deg >= (int64_t)INT32_MAX)
+            return fail(SGL_ERR_UNSUPPORTED, "build_plan: a row with >= 2^31 non-zeros needs long_row_nnz > 0");
+        if (split && deg > long_row_nnz) {
+            close_item(r);  // rows before the long one
+            plan.long_row.push_back((int32_t)r);
+            for (int64_t p = b; p < e; p += long_row_nnz) {
+                Piece pc;
+                pc.begin = p;
+                pc.len = (int32_t)std::min<int64_t>(long_row_nnz, e - p);
+                pc.row = (int32_t)r;
+                plan.pieces.push_back(pc);
+            }
+            plan.long_first.push_back((int32_t)plan.pieces.size());
+            cur_begin = r + 1;
+            cur_nnz = 0;
+            continue;
+        }
+        // a row that would push the item past 2^31-1 relative offsets cannot happen when split is on
+        // (deg <= long_row_nnz); without splitting close the item first so offsets stay 32-bit.
+        if (cur_nnz > 0 && cur_nnz + deg >= (int64_t)INT32_MAX) close_item(r);
+        cur_nnz += deg;
+        if (cur_nnz >= item_nnz || (r + 1 - cur_begin) >= kMaxItemRows) close_item(r + 1);
+    }
+    close_item(n_rows);
+    return SGL_OK;
+}
+
+}  // namespace sgl
+
+SGL_EXPORT int sgl_version(void) { return 100; }
+
+SGL_EXPORT const char *sgl_last_error(void) { return sgl::get_error(); }
+
+SGL_EXPORT int sgl_device_count(int *count) {
+    if (!count) return sgl::fail(SGL_ERR_INVALID, "sgl_device_count: NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_set_tuning(const char *key, int64_t value) {
+    if (!key) return sgl::fail(SGL_ERR_INVALID, "sgl_set_tuning: NULL key");
+    std::lock_guard<std::mutex> lk(sgl::g_tune_mu);
+    auto &m = sgl::tune_map();
+    auto it = m.find(key);
+    if (it == m.end()) return sgl::fail(SGL_ERR_INVALID, "sgl_set_tuning: unknown key '%s'", key);
+    it->second = value;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_get_tuning(const char *key, int64_t *value) {
+    if (!key || !value) return sgl::fail(SGL_ERR_INVALID, "sgl_get_tuning: NULL");
+    std::lock_guard<std::mutex> lk(sgl::g_tune_mu);
+    auto &m = sgl::tune_map();
+    auto it = m.find(key);
+    if (it == m.end()) return sgl::fail(SGL_ERR_INVALID, "sgl_get_tuning: unknown key '%s'", key);
+    *value = it->second;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_plan_build(sgl_plan_t **out, const int64_t *h_rowptr, int64_t n_rows, int32_t item_nnz,
+                              int32_t long_row_nnz) {
+    if (!out) return sgl::fail(SGL_ERR_INVALID, "sgl_plan_build: NULL out");
+    *out = nullptr;
+    sgl_plan_t *p = new (std::nothrow) sgl_plan_t();
+    if (!p) return sgl::fail(SGL_ERR_ALLOC, "sgl_plan_build: out of memory");
+    int rc = sgl::build_plan(p->p, h_rowptr, n_rows, item_nnz, long_row_nnz);
+    if (rc != SGL_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_plan_counts(const sgl_plan_t *plan, int64_t counts[8]) {
+    if (!plan || !counts) return sgl::fail(SGL_ERR_INVALID, "sgl_plan_counts: NULL");
+    memset(counts, 0, 8 * sizeof(int64_t));
+    counts[0] = (int64_t)plan->p.items.size() / 2;
+    counts[1] = (int64_t)plan->p.pieces.size();
+    counts[2] = (int64_t)plan->p.long_row.size();
+    counts[3] = plan->p.max_item_rows;
+    counts[4] = plan->p.max_item_nnz;
+    counts[5] = plan->p.n_rows;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_plan_export(const sgl_plan_t *plan, int32_t *h_items, int64_t *h_piece_begin, int32_t *h_piece_len,
+                               int32_t *h_piece_row, int32_t *h_long_row, int32_t *h_long_first) {
+    if (!plan) return sgl::fail(SGL_ERR_INVALID, "sgl_plan_export: NULL plan");
+    const sgl::Plan &p = plan->p;
+    if (h_items && !p.items.empty()) memcpy(h_items, p.items.data(), p.items.size() * sizeof(int32_t));
+    for (size_t i = 0; i < p.pieces.size(); ++i) {
+        if (h_piece_begin) h_piece_begin[i] = p.pieces[i].begin;
+        if (h_piece_len) h_piece_len[i] = p.pieces[i].len;
+        if (h_piece_row) h_piece_row[i] = p.pieces[i].row;
+    }
+    if (h_long_row && !p.long_row.empty()) memcpy(h_long_row, p.long_row.data(), p.long_row.size() * sizeof(int32_t));
+    if (h_long_first) memcpy(h_long_first, p.long_first.data(), p.long_first.size() * sizeof(int32_t));
+    return SGL_OK;
+}
+
+SGL_EXPORT void sgl_plan_destroy(sgl_plan_t *plan) { delete plan; }

@@ -1,0 +1,253 @@
+// adj_to_symmetric_norm on device (reference: sgl/operators/utils.py:76-88 and the Laplacian / PPR wrappers
+// graph_op/laplacian_graph_op.py:12-19, graph_op/ppr_graph_op.py:13-21).
+//
+//   A' = A + I ; deg = rowsum(A') ; L = deg^(r-1), R = deg^(-r) (inf -> 0)
+//   A_hat = (A' diag(L))^T diag(R)          =>  A_hat[j,i] = (A'[i,j] * L[j]) * R[i]      (fp64, this order)
+//   PPR:  (1-alpha) * A_hat + alpha * I
+//   result as canonical CSR (rows sorted by column), values rounded to fp32 at the very end -- the place the
+//   reference rounds (utils.py:32).
+//
+// Integer work (structure) is exact; the fp64 values follow the reference's operation order.  The transpose is a
+// stable LSD radix sort by output row (rocPRIM), so each output row keeps ascending column order without atomics.
+// This is a once-per-graph setup step (HBM-streaming + one sort), not the per-hop hot loop.
+#include "sgl_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+__global__ __launch_bounds__(256) void diag_missing_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           int64_t n, int64_t *__restrict__ miss, unsigned long long *total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int m = 0;
+    if (i < n) {
+        int64_t lo = rowptr[i], hi = rowptr[i + 1];
+        while (lo < hi) {  // lower_bound(col[row], i)
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < (int32_t)i) lo = mid + 1; else hi = mid;
+        }
+        m = !(lo < rowptr[i + 1] && col[lo] == (int32_t)i);
+        miss[i] = m;
+    } else if (i == n) {
+        miss[i] = 0;
+    }
+    if (total) {
+        // wave-level count, one atomic per wave
+        const unsigned long long b = __ballot(m != 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(total, (unsigned long long)__popcll(b));
+    }
+}
+
+// rows of A' = A + I in row-major order: key = column (the OUTPUT row after transposition), row = i, value fp64
+__global__ __launch_bounds__(256) void build_aprime_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const float *__restrict__ val, const int64_t *__restrict__ shift,
+                                                           int64_t n, uint32_t *__restrict__ t_key, int32_t *__restrict__ t_row,
+                                                           double *__restrict__ a64, double *__restrict__ deg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = rowptr[i], e = rowptr[i + 1];
+    int64_t o = b + shift[i];
+    double s = 0.0;
+    bool placed = false;
+    for (int64_t p = b; p < e; ++p) {
+        const int32_t c = col[p];
+        double v = (double)val[p];
+        if (!placed && c >= (int32_t)i) {
+            placed = true;
+            if (c == (int32_t)i) {
+                v += 1.0;  // a_ii + 1
+            } else {       // insert the missing diagonal before the first larger column
+                t_key[o] = (uint32_t)i;
+                t_row[o] = (int32_t)i;
+                a64[o] = 1.0;
+                s += 1.0;
+                ++o;
+            }
+        }
+        t_key[o] = (uint32_t)c;
+        t_row[o] = (int32_t)i;
+        a64[o] = v;
+        s += v;
+        ++o;
+    }
+    if (!placed) {
+        t_key[o] = (uint32_t)i;
+        t_row[o] = (int32_t)i;
+        a64[o] = 1.0;
+        s += 1.0;
+    }
+    deg[i] = s;
+}
+
+__global__ __launch_bounds__(256) void degree_scale_kernel(const double *__restrict__ deg, int64_t n, double r,
+                                                           double *__restrict__ left, double *__restrict__ right) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dg = deg[i];
+    double l = pow(dg, r - 1.0);   // utils.py:79
+    if (isinf(l)) l = 0.0;         // utils.py:80
+    double rr = pow(dg, -r);       // utils.py:83
+    if (isinf(rr)) rr = 0.0;       // utils.py:84
+    left[i] = l;
+    right[i] = rr;
+}
+
+__global__ __launch_bounds__(256) void scale_values_kernel(const uint32_t *__restrict__ t_key, const int32_t *__restrict__ t_row,
+                                                           const double *__restrict__ left, const double *__restrict__ right,
+                                                           int64_t m, double *__restrict__ a64, uint32_t *__restrict__ iota) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    a64[p] = __dmul_rn(__dmul_rn(a64[p], left[t_key[p]]), right[t_row[p]]);  // (A'[i,j] * L[j]) * R[i]
+    iota[p] = (uint32_t)p;
+}
+
+__global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(const uint32_t *__restrict__ keys, int64_t m, int64_t n,
+                                                                 int64_t *__restrict__ out_rowptr) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {  // first q with keys[q] >= j
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    out_rowptr[j] = lo;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ t_row, const double *__restrict__ a64,
+                                                       int64_t m, int use_alpha, double one_minus_alpha, double alpha,
+                                                       int32_t *__restrict__ out_col, float *__restrict__ out_val,
+                                                       double *__restrict__ out_val64) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const uint32_t p = perm[q];
+    const int32_t i = t_row[p];
+    double v = a64[p];
+    if (use_alpha) {                       // ppr_graph_op.py:20
+        v = __dmul_rn(one_minus_alpha, v);
+        if ((uint32_t)i == keys[q]) v = __dadd_rn(v, alpha);
+    }
+    out_col[q] = i;
+    out_val[q] = (float)v;                 // operators/utils.py:32
+    if (out_val64) out_val64[q] = v;
+}
+
+struct Tmp {
+    std::vector<void *> ptrs;
+    ~Tmp() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return sgl::fail((int)e, "sgl_norm: hipMalloc failed: %s", hipGetErrorString(e));
+        ptrs.push_back(p);
+        *out = reinterpret_cast<T *>(p);
+        return SGL_OK;
+    }
+};
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+SGL_EXPORT int sgl_norm_prepare(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, int64_t *nnz_out,
+                                void *stream) {
+    SGL_REQUIRE(nnz_out != nullptr, "sgl_norm_prepare: NULL nnz_out");
+    SGL_REQUIRE(n >= 0 && nnz >= 0 && n < INT32_MAX, "sgl_norm_prepare: bad sizes");
+    if (n == 0) {
+        *nnz_out = 0;
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_rowptr && (nnz == 0 || d_col), "sgl_norm_prepare: NULL arrays");
+    hipStream_t st = sgl::as_stream(stream);
+    Tmp tmp;
+    int64_t *miss = nullptr;
+    unsigned long long *total = nullptr;
+    int rc;
+    if ((rc = tmp.alloc(&miss, (size_t)n + 1)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&total, 1)) != SGL_OK) return rc;
+    SGL_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(diag_missing_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, n, miss, total);
+    SGL_HIP_CHECK(hipGetLastError());
+    unsigned long long h_total = 0;
+    SGL_HIP_CHECK(hipMemcpyAsync(&h_total, total, sizeof(h_total), hipMemcpyDeviceToHost, st));
+    SGL_HIP_CHECK(hipStreamSynchronize(st));
+    *nnz_out = nnz + (int64_t)h_total;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                                double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
+                                int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream) {
+    SGL_REQUIRE(n >= 0 && nnz >= 0 && n < INT32_MAX, "sgl_norm_execute: bad sizes");
+    SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_execute: nnz_out inconsistent (call sgl_norm_prepare)");
+    SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX, "sgl_norm_execute: nnz_out >= 2^32 not supported on one device");
+    SGL_REQUIRE(d_out_rowptr != nullptr, "sgl_norm_execute: NULL output row pointers");
+    hipStream_t st = sgl::as_stream(stream);
+    if (n == 0) {
+        SGL_HIP_CHECK(hipMemsetAsync(d_out_rowptr, 0, sizeof(int64_t), st));
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_rowptr && (nnz == 0 || (d_col && d_val)) && d_out_col && d_out_val, "sgl_norm_execute: NULL arrays");
+    const int64_t m = nnz_out;
+    Tmp tmp;
+    int rc;
+    int64_t *miss = nullptr, *shift = nullptr;
+    uint32_t *t_key = nullptr, *keys_sorted = nullptr, *iota = nullptr, *perm = nullptr;
+    int32_t *t_row = nullptr;
+    double *a64 = nullptr, *deg = nullptr, *left = nullptr, *right = nullptr;
+    if ((rc = tmp.alloc(&miss, (size_t)n + 1)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&shift, (size_t)n + 1)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&t_key, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&keys_sorted, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&iota, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&perm, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&t_row, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&a64, (size_t)m)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&deg, (size_t)n)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&left, (size_t)n)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&right, (size_t)n)) != SGL_OK) return rc;
+
+    // 1. which rows lack a diagonal entry; exclusive scan -> how far each row of A' is shifted
+    hipLaunchKernelGGL(diag_missing_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, n, miss,
+                       (unsigned long long *)nullptr);
+    SGL_HIP_CHECK(hipGetLastError());
+    {
+        size_t bytes = 0;
+        SGL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, miss, shift, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+        char *scratch = nullptr;
+        if ((rc = tmp.alloc(&scratch, bytes)) != SGL_OK) return rc;
+        SGL_HIP_CHECK(rocprim::exclusive_scan(scratch, bytes, miss, shift, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+    }
+    // 2. A' = A + I as (key = column, row, fp64 value) triplets in row-major order; weighted degrees
+    hipLaunchKernelGGL(build_aprime_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d_rowptr, d_col, d_val, shift, n, t_key,
+                       t_row, a64, deg);
+    SGL_HIP_CHECK(hipGetLastError());
+    // 3. deg^(r-1), deg^(-r)
+    hipLaunchKernelGGL(degree_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, st, deg, n, r, left, right);
+    SGL_HIP_CHECK(hipGetLastError());
+    // 4. values of the transposed, scaled matrix (still in A' order) + identity permutation
+    hipLaunchKernelGGL(scale_values_kernel, dim3(blocks_for(m)), dim3(256), 0, st, t_key, t_row, left, right, m, a64, iota);
+    SGL_HIP_CHECK(hipGetLastError());
+    // 5. transpose = stable sort by output row
+    {
+        int end_bit = 1;
+        while (end_bit < 32 && ((uint64_t)1 << end_bit) < (uint64_t)n) ++end_bit;
+        size_t bytes = 0;
+        SGL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, t_key, keys_sorted, iota, perm, (size_t)m, 0, end_bit, st));
+        char *scratch = nullptr;
+        if ((rc = tmp.alloc(&scratch, bytes)) != SGL_OK) return rc;
+        SGL_HIP_CHECK(rocprim::radix_sort_pairs(scratch, bytes, t_key, keys_sorted, iota, perm, (size_t)m, 0, end_bit, st));
+    }
+    // 6. output row pointers, 7. gather + PPR + fp32 rounding
+    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, keys_sorted, m, n, d_out_rowptr);
+    SGL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks_for(m)), dim3(256), 0, st, keys_sorted, perm, t_row, a64, m, use_alpha,
+                       1.0 - alpha, alpha, d_out_col, d_out_val, d_out_val64);
+    SGL_HIP_CHECK(hipGetLastError());
+    SGL_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are freed on return
+    return SGL_OK;
+}

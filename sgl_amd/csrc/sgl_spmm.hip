@@ -1,0 +1,522 @@
+// CSR x dense fp32 SpMM for gfx950 (MI355X) -- the k-step A_hat . X kernel of GraphOp.propagate
+// (reference: sgl/operators/base_op.py:29-35 -> csrc/matmul.c:23-40; successor of the dead cuSPARSE twin
+// csrc/cudamatmul.c:104-119).
+//
+// Design (see DESIGN.md "Kernel 1"):
+//   * the path is sparse x dense, ~0.5 flop/byte: HBM/cache bound, no MFMA;
+//   * one 64-lane wavefront owns one work item = a run of <= 63 whole rows holding ~item_nnz non-zeros
+//     (host-built plan, sgl_core.cpp); very long rows are cut into pieces whose partial sums are combined by a
+//     deterministic fix-up pass (no float atomics);
+//   * inside a wavefront, lanes are laid out as R "non-zero slots" x GROUP "feature lanes" (R*GROUP = 64):
+//     every step gathers R rows of X, each read as one contiguous, 16-byte-per-lane segment (coalesced), and
+//     FMAs them into per-lane fp32 accumulators; the R slot accumulators are folded with a butterfly of
+//     cross-lane shuffles when the row ends (wavefront-level reduction).  R = 1 walks the row in storage order
+//     with one fmaf per non-zero = the reference's exact chain (bit-exact mode);
+//   * the item's (col, val) stream is read as coalesced 64-element slices that stay in registers and are
+//     broadcast to the slots through the LDS crossbar (ds_bpermute / v_readlane): the next slice is prefetched
+//     while the current one is consumed, so the CSR stream never stalls the gathers;
+//   * U independent gathers are kept in flight per lane (memory-level parallelism), x up to 8 waves per SIMD;
+//   * block -> item mapping is XCD-aware: each of the 8 XCDs walks its own contiguous range of rows, so rows that
+//     share neighbours (and the CSR stream) stay in one XCD's L2.
+#include "sgl_common.h"
+
+namespace {
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> {
+    using type = float;
+};
+template <>
+struct VecT<2> {
+    using type = float __attribute__((ext_vector_type(2)));
+};
+template <>
+struct VecT<4> {
+    using type = float __attribute__((ext_vector_type(4)));
+};
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vzero() {
+    typename VecT<VEC>::type z;
+    if constexpr (VEC == 1) {
+        z = 0.f;
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) z[e] = 0.f;
+    }
+    return z;
+}
+
+template <int VEC>
+__device__ __forceinline__ void vfma(typename VecT<VEC>::type &acc, float v, const typename VecT<VEC>::type &x) {
+    if constexpr (VEC == 1) {
+        acc = __builtin_fmaf(v, x, acc);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = __builtin_fmaf(v, x[e], acc[e]);
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void vadd_xor(typename VecT<VEC>::type &acc, int off) {
+    if constexpr (VEC == 1) {
+        acc += __shfl_xor(acc, off, 64);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += __shfl_xor(acc[e], off, 64);
+    }
+}
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+template <bool NT, typename T>
+__device__ __forceinline__ void st_stream(T *p, const T &v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+// broadcast element `idx` (0..63) of a wave-distributed register to this lane
+template <int R>
+__device__ __forceinline__ int bcast_i(int v, int idx) {
+    if constexpr (R == 1)
+        return __builtin_amdgcn_readlane(v, idx);  // idx is wave-uniform -> SGPR result
+    else
+        return __builtin_amdgcn_ds_bpermute(idx << 2, v);
+}
+template <int R>
+__device__ __forceinline__ float bcast_f(float v, int idx) {
+    return __int_as_float(bcast_i<R>(__float_as_int(v), idx));
+}
+
+struct SpmmArgs {
+    const int32_t *items;       // (row_begin,row_end) pairs
+    const sgl::Piece *pieces;   // long-row pieces
+    const int64_t *rowptr;
+    const int32_t *col;
+    const float *val;
+    const float *x;
+    float *y;
+    float *partial;
+    int64_t ldx, ldy, ldp;
+    int32_t n_items, n_pieces, d, accumulate;
+    int32_t piece_blocks, item_blocks_per_xcd, xcd_remap, waves;
+};
+
+// One wavefront walks `nrows` consecutive rows whose non-zeros are colb/valb[0 .. tot) ; lane i of `my_rel`
+// holds the offset of row i's first non-zero (lane nrows holds tot).
+template <int VEC, int GROUP, int NCH, int U, bool NT>
+__device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const float *__restrict__ valb,
+                                         const int my_rel, const int nrows, const int tot,
+                                         const float *__restrict__ x, const int64_t ldx, float *__restrict__ out,
+                                         const int64_t ldo, const int d, const bool accumulate, const int lane) {
+    using V = typename VecT<VEC>::type;
+    constexpr int R = 64 / GROUP;
+    const int s = (R == 1) ? 0 : (lane / GROUP);
+    const int l = lane % GROUP;
+    int colofs[NCH];
+    bool on[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        colofs[ch] = (ch * GROUP + l) * VEC;
+        on[ch] = colofs[ch] < d;
+    }
+
+    // current / next 64-element slice of the (col,val) stream, one element per lane
+    int cbr = 0;
+    int my_c = 0, nx_c = 0;
+    float my_v = 0.f, nx_v = 0.f;
+    if (lane < tot) {
+        my_c = ld_stream<NT>(colb + lane);
+        my_v = ld_stream<NT>(valb + lane);
+    }
+    if (64 + lane < tot) {
+        nx_c = ld_stream<NT>(colb + 64 + lane);
+        nx_v = ld_stream<NT>(valb + 64 + lane);
+    }
+
+    for (int ri = 0; ri < nrows; ++ri) {
+        const int jb = __builtin_amdgcn_readlane(my_rel, ri);
+        const int je = __builtin_amdgcn_readlane(my_rel, ri + 1);
+        float *orow = out + (int64_t)ri * ldo;
+        V acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) acc[ch] = vzero<VEC>();
+        if (accumulate && s == 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (on[ch]) acc[ch] = *reinterpret_cast<const V *>(orow + colofs[ch]);
+        }
+        int j = jb;
+        while (j < je) {
+            const int lim = min(je, cbr + 64);
+            const int o = j - cbr;
+            const int cnt = lim - j;
+            int t = 0;
+            for (; t + R * U <= cnt; t += R * U) {
+                int c[U];
+                float v[U];
+                V xv[U][NCH];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = o + t + u * R + s;
+                    c[u] = bcast_i<R>(my_c, idx);
+                    v[u] = bcast_f<R>(my_v, idx);
+                }
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (on[ch]) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            xv[u][ch] = *reinterpret_cast<const V *>(x + (int64_t)c[u] * ldx + colofs[ch]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) xv[u][ch] = vzero<VEC>();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) vfma<VEC>(acc[ch], v[u], xv[u][ch]);
+            }
+            for (; t < cnt; t += R) {
+                const int idx = (o + t + s) & 63;
+                const bool valid = (t + s) < cnt;
+                const int c = bcast_i<R>(my_c, idx);
+                const float v = bcast_f<R>(my_v, idx);
+                if (valid) {
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch)
+                        if (on[ch]) {
+                            const V xv = *reinterpret_cast<const V *>(x + (int64_t)c * ldx + colofs[ch]);
+                            vfma<VEC>(acc[ch], v, xv);
+                        }
+                }
+            }
+            j = lim;
+            if (lim == cbr + 64) {  // slice exhausted: rotate, prefetch the one after next
+                cbr += 64;
+                my_c = nx_c;
+                my_v = nx_v;
+                if (cbr + 64 + lane < tot) {
+                    nx_c = ld_stream<NT>(colb + cbr + 64 + lane);
+                    nx_v = ld_stream<NT>(valb + cbr + 64 + lane);
+                }
+            }
+        }
+        if constexpr (R > 1) {
+#pragma unroll
+            for (int off = GROUP; off < 64; off <<= 1)
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) vadd_xor<VEC>(acc[ch], off);
+        }
+        if (s == 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (on[ch]) st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), acc[ch]);
+        }
+    }
+}
+
+template <int VEC, int GROUP, int NCH, int U, bool NT>
+__global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    if (b < a.piece_blocks) {
+        const int p = b * a.waves + wave;
+        if (p >= a.n_pieces) return;
+        const sgl::Piece pc = a.pieces[p];
+        const int my_rel = (lane == 0) ? 0 : pc.len;
+        run_rows<VEC, GROUP, NCH, U, NT>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
+                                         a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane);
+    } else {
+        int ib = b - a.piece_blocks;
+        if (a.xcd_remap) ib = (ib & 7) * a.item_blocks_per_xcd + (ib >> 3);
+        const int item = ib * a.waves + wave;
+        if (item >= a.n_items) return;
+        const int row_begin = a.items[2 * item], row_end = a.items[2 * item + 1];
+        const int nrows = row_end - row_begin;
+        const int64_t rp = a.rowptr[(int64_t)row_begin + min(lane, nrows)];
+        const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
+        const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)rp >> 32));
+        const int64_t base = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+        const int my_rel = (int)(rp - base);
+        const int tot = __builtin_amdgcn_readlane(my_rel, nrows);
+        run_rows<VEC, GROUP, NCH, U, NT>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
+                                         a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane);
+    }
+}
+
+// Y[row, :] = (accumulate ? Y[row, :] : 0) + sum of the row's piece partials, in storage order.
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ long_row,
+                                                         const int32_t *__restrict__ long_first,
+                                                         const float *__restrict__ partial, int64_t ldp,
+                                                         float *__restrict__ y, int64_t ldy, int d, int accumulate) {
+    const int kblocks = (d + 255) / 256;
+    const int lr = blockIdx.x / kblocks;
+    const int k = (blockIdx.x % kblocks) * 256 + threadIdx.x;
+    if (k >= d) return;
+    const int row = long_row[lr];
+    const int p0 = long_first[lr], p1 = long_first[lr + 1];
+    float *yp = y + (int64_t)row * ldy + k;
+    float acc = accumulate ? *yp : 0.f;
+    for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
+    *yp = acc;
+}
+
+template <int VEC, int GROUP, int NCH, int U, bool NT>
+hipError_t launch_variant(const SpmmArgs &a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((spmm_kernel<VEC, GROUP, NCH, U, NT>), dim3(grid), dim3(64 * a.waves), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int VEC, int GROUP, int NCH, int U>
+hipError_t launch_nt(const SpmmArgs &a, int grid, hipStream_t st, bool nt) {
+    return nt ? launch_variant<VEC, GROUP, NCH, U, true>(a, grid, st)
+              : launch_variant<VEC, GROUP, NCH, U, false>(a, grid, st);
+}
+
+template <int VEC, int GROUP, int NCH>
+hipError_t launch_u(const SpmmArgs &a, int grid, hipStream_t st, bool nt, int ulevel) {
+    // gathers in flight per lane, scaled down with the number of column chunks to bound registers
+    constexpr int UH = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
+    constexpr int UL = UH / 2;
+    if (ulevel == 2) return launch_nt<VEC, GROUP, NCH, UH * 2 / (NCH == 1 ? 1 : 2)>(a, grid, st, nt);
+    return ulevel == 0 ? launch_nt<VEC, GROUP, NCH, UL>(a, grid, st, nt) : launch_nt<VEC, GROUP, NCH, UH>(a, grid, st, nt);
+}
+
+template <int VEC>
+hipError_t launch_group(const SpmmArgs &a, int grid, hipStream_t st, bool nt, int ulevel, int group, int nch) {
+    if (nch == 1) {
+        switch (group) {
+            case 8:
+                return launch_u<VEC, 8, 1>(a, grid, st, nt, ulevel);
+            case 16:
+                return launch_u<VEC, 16, 1>(a, grid, st, nt, ulevel);
+            case 32:
+                return launch_u<VEC, 32, 1>(a, grid, st, nt, ulevel);
+            default:
+                return launch_u<VEC, 64, 1>(a, grid, st, nt, ulevel);
+        }
+    }
+    if (nch == 2) return launch_u<VEC, 64, 2>(a, grid, st, nt, ulevel);
+    return launch_u<VEC, 64, 4>(a, grid, st, nt, ulevel);
+}
+
+}  // namespace
+
+struct sgl_csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    const int64_t *d_rowptr = nullptr;
+    const int32_t *d_col = nullptr;
+    const float *d_val = nullptr;
+    uint32_t flags = 0;
+    int64_t n_items = 0, n_pieces = 0, n_long = 0;
+    int32_t *d_items = nullptr;
+    sgl::Piece *d_pieces = nullptr;
+    int32_t *d_long_row = nullptr;
+    int32_t *d_long_first = nullptr;
+    float *d_partial = nullptr;
+    size_t partial_cap = 0;  // floats
+    int device = 0;
+};
+
+SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
+                              const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
+                              int32_t long_row_nnz, void *stream) {
+    if (!out) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_create: NULL out");
+    *out = nullptr;
+    SGL_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "sgl_csr_create: negative size");
+    SGL_REQUIRE(n_rows < INT32_MAX && n_cols < INT32_MAX, "sgl_csr_create: n_rows/n_cols must be < 2^31 (int32 ids)");
+    SGL_REQUIRE(d_rowptr != nullptr, "sgl_csr_create: NULL row pointers");
+    SGL_REQUIRE(nnz == 0 || (d_col && d_val), "sgl_csr_create: NULL col/val with nnz > 0");
+    hipStream_t st = sgl::as_stream(stream);
+    std::vector<int64_t> h_rowptr((size_t)n_rows + 1);
+    SGL_HIP_CHECK(hipMemcpyAsync(h_rowptr.data(), d_rowptr, h_rowptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SGL_HIP_CHECK(hipStreamSynchronize(st));
+    SGL_REQUIRE(h_rowptr[0] == 0 && h_rowptr[n_rows] == nnz, "sgl_csr_create: rowptr[0]=%lld rowptr[n]=%lld but nnz=%lld",
+                (long long)h_rowptr[0], (long long)h_rowptr[n_rows], (long long)nnz);
+    if (item_nnz <= 0) item_nnz = sgl::kDefaultItemNnz;
+    if (long_row_nnz == 0) long_row_nnz = sgl::kDefaultLongRowNnz;
+    if (flags & SGL_CSR_STRICT_ORDER) long_row_nnz = -1;
+    sgl::Plan plan;
+    int rc = sgl::build_plan(plan, h_rowptr.data(), n_rows, item_nnz, long_row_nnz);
+    if (rc != SGL_OK) return rc;
+
+    sgl_csr_t *h = new (std::nothrow) sgl_csr_t();
+    if (!h) return sgl::fail(SGL_ERR_ALLOC, "sgl_csr_create: out of memory");
+    h->n_rows = n_rows;
+    h->n_cols = n_cols;
+    h->nnz = nnz;
+    h->d_rowptr = d_rowptr;
+    h->d_col = d_col;
+    h->d_val = d_val;
+    h->flags = flags;
+    h->n_items = (int64_t)plan.items.size() / 2;
+    h->n_pieces = (int64_t)plan.pieces.size();
+    h->n_long = (int64_t)plan.long_row.size();
+    (void)hipGetDevice(&h->device);
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
+        if (bytes == 0) return SGL_OK;
+        SGL_HIP_CHECK(hipMalloc(dst, bytes));
+        SGL_HIP_CHECK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+        return SGL_OK;
+    };
+    rc = upload((void **)&h->d_items, plan.items.data(), plan.items.size() * sizeof(int32_t));
+    if (rc == SGL_OK) rc = upload((void **)&h->d_pieces, plan.pieces.data(), plan.pieces.size() * sizeof(sgl::Piece));
+    if (rc == SGL_OK) rc = upload((void **)&h->d_long_row, plan.long_row.data(), plan.long_row.size() * sizeof(int32_t));
+    if (rc == SGL_OK && h->n_long > 0)
+        rc = upload((void **)&h->d_long_first, plan.long_first.data(), plan.long_first.size() * sizeof(int32_t));
+    if (rc == SGL_OK) {
+        hipError_t e = hipStreamSynchronize(st);  // host vectors die at return
+        if (e != hipSuccess) rc = sgl::fail((int)e, "sgl_csr_create: sync failed: %s", hipGetErrorString(e));
+    }
+    if (rc != SGL_OK) {
+        sgl_csr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
+    if (!h) return SGL_OK;
+    (void)hipFree(h->d_items);
+    (void)hipFree(h->d_pieces);
+    (void)hipFree(h->d_long_row);
+    (void)hipFree(h->d_long_first);
+    (void)hipFree(h->d_partial);
+    delete h;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_csr_info(const sgl_csr_t *h, int64_t info[8]) {
+    if (!h || !info) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_info: NULL");
+    info[0] = h->n_rows;
+    info[1] = h->n_cols;
+    info[2] = h->nnz;
+    info[3] = h->n_items;
+    info[4] = h->n_pieces;
+    info[5] = h->n_long;
+    info[6] = h->flags;
+    info[7] = (int64_t)(h->partial_cap * sizeof(float));
+    return SGL_OK;
+}
+
+static bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+static int pick_vec(const float *d_x, int64_t ldx, const float *d_y, int64_t ldy, int64_t d) {
+    // vector width from alignment: every lane reads/writes VEC consecutive floats of a row
+    if (d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned_to(d_x, 16) && aligned_to(d_y, 16)) return 4;
+    if (d % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && aligned_to(d_x, 8) && aligned_to(d_y, 8)) return 2;
+    return 1;
+}
+
+static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int d, int vec,
+                      int accumulate, hipStream_t st) {
+    const int lanes = d / vec;
+    const bool strict = (h->flags & SGL_CSR_STRICT_ORDER) != 0;
+    int group = 64, nch = 1;
+    if (lanes > 64) {
+        const int need = (lanes + 63) / 64;
+        nch = need <= 2 ? need : 4;
+    } else if (!strict) {
+        group = 8;
+        while (group < lanes) group <<= 1;
+    }
+    const int64_t forced = sgl::tuning("spmm_group", 0);
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) {
+        if (nch == 1 && forced >= lanes) group = (int)forced;
+    }
+    int ulevel = 1;
+    const int64_t un = sgl::tuning("spmm_unroll", 0);
+    if (un == 1) ulevel = 0;   // half the default number of gathers in flight
+    if (un == 2) ulevel = 2;   // double
+    const bool nt = sgl::tuning("spmm_nt", 0) != 0;
+    int waves = (int)sgl::tuning("spmm_waves", 0);
+    if (waves != 1 && waves != 2 && waves != 4) waves = 4;
+
+    SpmmArgs a;
+    a.items = h->d_items;
+    a.pieces = h->d_pieces;
+    a.rowptr = h->d_rowptr;
+    a.col = h->d_col;
+    a.val = h->d_val;
+    a.x = d_x;
+    a.y = d_y;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.ldp = (d + 3) / 4 * 4;
+    a.n_items = (int32_t)h->n_items;
+    a.n_pieces = (int32_t)h->n_pieces;
+    a.d = d;
+    a.accumulate = accumulate;
+    a.waves = waves;
+    a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
+    const int64_t item_blocks = (h->n_items + waves - 1) / waves;
+    a.xcd_remap = (!(h->flags & SGL_CSR_NO_XCD_REMAP) && sgl::tuning("spmm_xcd_remap", 1) != 0) ? 1 : 0;
+    a.item_blocks_per_xcd = (int32_t)((item_blocks + 7) / 8);
+    const int64_t grid64 = a.piece_blocks + (a.xcd_remap ? (int64_t)a.item_blocks_per_xcd * 8 : item_blocks);
+    if (grid64 >= INT32_MAX) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_spmm_f32: grid too large");
+
+    if (h->n_pieces > 0) {
+        const size_t need = (size_t)h->n_pieces * (size_t)a.ldp;
+        if (need > h->partial_cap) {
+            SGL_HIP_CHECK(hipStreamSynchronize(st));
+            (void)hipFree(h->d_partial);
+            h->d_partial = nullptr;
+            h->partial_cap = 0;
+            SGL_HIP_CHECK(hipMalloc((void **)&h->d_partial, need * sizeof(float)));
+            h->partial_cap = need;
+        }
+    }
+    a.partial = h->d_partial;
+    if (grid64 == 0) return SGL_OK;
+    hipError_t e;
+    if (vec == 4)
+        e = launch_group<4>(a, (int)grid64, st, nt, ulevel, group, nch);
+    else if (vec == 2)
+        e = launch_group<2>(a, (int)grid64, st, nt, ulevel, group, nch);
+    else
+        e = launch_group<1>(a, (int)grid64, st, nt, ulevel, group, nch);
+    if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: kernel launch failed: %s", hipGetErrorString(e));
+    if (h->n_long > 0) {
+        const int64_t fg = (int64_t)((d + 255) / 256) * h->n_long;
+        if (fg >= INT32_MAX) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_spmm_f32: fix-up grid too large");
+        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_long_row, h->d_long_first, h->d_partial, a.ldp,
+                           d_y, ldy, d, accumulate);
+        e = hipGetLastError();
+        if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: fix-up launch failed: %s", hipGetErrorString(e));
+    }
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
+                            int accumulate, void *stream) {
+    if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_spmm_f32: NULL handle");
+    SGL_REQUIRE(d >= 0 && d < INT32_MAX, "sgl_spmm_f32: bad d");
+    if (d == 0 || h->n_rows == 0) return SGL_OK;
+    SGL_REQUIRE(d_x && d_y, "sgl_spmm_f32: NULL X or Y");
+    SGL_REQUIRE(ldx >= d && ldy >= d, "sgl_spmm_f32: leading dimension smaller than d");
+    SGL_REQUIRE(aligned_to(d_x, 4) && aligned_to(d_y, 4), "sgl_spmm_f32: X/Y not 4-byte aligned");
+    hipStream_t st = sgl::as_stream(stream);
+    // one launch covers up to 64 lanes x 4 chunks x VEC columns; wider matrices go in column slices
+    const int vec = pick_vec(d_x, ldx, d_y, ldy, d);
+    const int64_t max_cols = 64 * 4 * vec;
+    for (int64_t c0 = 0; c0 < d; c0 += max_cols) {
+        const int dc = (int)std::min<int64_t>(max_cols, d - c0);
+        int rc = spmm_slice(h, d_x + c0, ldx, d_y + c0, ldy, dc, vec, accumulate, st);
+        if (rc != SGL_OK) return rc;
+    }
+    return SGL_OK;
+}

@@ -1,0 +1,312 @@
+"""Thin Python layer over the C ABI (include/sgl_hip.h): device CSR handle, SpMM, aggregators.
+
+torch is used for device memory, streams and autograd bookkeeping only; every computation
+below is a hand-written HIP kernel in libsgl_hip.so.  There is no CPU fallback."""
+import ctypes
+from ctypes import c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream_ptr, lib, ptr
+
+__all__ = [
+    "DeviceCSR", "round_up", "alloc_rows", "upload_rows", "normalize_adj",
+    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "nafs_aggregate", "gather_rows",
+]
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def alloc_rows(n, d, device, zero_pad=True):
+    """[n, d] float32 view of a row-padded buffer whose leading dimension is a multiple of 4 floats, so
+    every row starts 16-byte aligned and the kernels can use 16-byte lane accesses for any d."""
+    ld = round_up(max(d, 1), 4)
+    buf = torch.empty((n, ld), dtype=torch.float32, device=device)
+    if zero_pad and ld != d:
+        buf[:, d:].zero_()
+    return buf[:, :d] if ld != d else buf
+
+
+def padded_parent(t):
+    """For a [n, d] view created by alloc_rows return the [n, ld] parent view (pad columns included)."""
+    n, d = t.shape
+    ld = t.stride(0) if n > 1 else round_up(d, 4)
+    if ld == d:
+        return t
+    return torch.as_strided(t, (n, ld), (ld, 1), t.storage_offset())
+
+
+def upload_rows(x, device):
+    """host ndarray / tensor [n, d] (any float dtype / order) -> padded device buffer view [n, d] float32"""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    x = x.detach()
+    n, d = x.shape
+    out = alloc_rows(n, d, device)
+    out.copy_(x.to(dtype=torch.float32), non_blocking=False)
+    return out
+
+
+def _check_mat(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise TypeError(f"{name} must be a 2-D float32 CUDA tensor")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name} must be row-major (column stride 1)")
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        raise ValueError(f"{name}: row stride smaller than the row length")
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+class DeviceCSR:
+    """A CSR matrix resident on one GPU plus its SpMM execution plan (sgl_csr_create).
+
+    rowptr int64 [n_rows+1], col int32 [nnz], val float32 [nnz] -- CUDA tensors, kept alive here."""
+
+    def __init__(self, rowptr, col, val, shape, strict=False, item_nnz=0, long_row_nnz=0, xcd_remap=True):
+        _lib.require_gpu()
+        for t, dt, nm in ((rowptr, torch.int64, "rowptr"), (col, torch.int32, "col"), (val, torch.float32, "val")):
+            if not (t.is_cuda and t.dtype == dt and t.dim() == 1 and t.is_contiguous()):
+                raise TypeError(f"{nm} must be a contiguous 1-D CUDA tensor of dtype {dt}")
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.nnz = int(col.numel())
+        self.device = rowptr.device
+        self.strict = bool(strict)
+        flags = (_lib.SGL_CSR_STRICT_ORDER if strict else 0) | (0 if xcd_remap else _lib.SGL_CSR_NO_XCD_REMAP)
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().sgl_csr_create(ctypes.byref(h), self.shape[0], self.shape[1], self.nnz, ptr(rowptr), ptr(col),
+                                       ptr(val), flags, int(item_nnz), int(long_row_nnz), current_stream_ptr()),
+                  "sgl_csr_create")
+        self._h = h
+
+    @classmethod
+    def from_scipy(cls, adj, device="cuda", **kw):
+        """scipy CSR (any float dtype; values rounded to float32 here, where the reference rounds them,
+        operators/utils.py:32) -> device."""
+        import scipy.sparse as sp
+        if not sp.isspmatrix_csr(adj):
+            raise TypeError("expected a scipy.sparse.csr_matrix")
+        rowptr = torch.from_numpy(adj.indptr.astype(np.int64)).to(device)
+        col = torch.from_numpy(adj.indices.astype(np.int32)).to(device)
+        val = torch.from_numpy(adj.data.astype(np.float32)).to(device)
+        return cls(rowptr, col, val, adj.shape, **kw)
+
+    def info(self):
+        a = (c_int64 * 8)()
+        check(lib().sgl_csr_info(self._h, a), "sgl_csr_info")
+        keys = ("n_rows", "n_cols", "nnz", "n_items", "n_pieces", "n_long_rows", "flags", "workspace_bytes")
+        return dict(zip(keys, list(a)))
+
+    def spmm(self, x, out=None, accumulate=False):
+        """out = A @ x (+ out when accumulate).  x: [n_cols, d] float32 CUDA row-major; returns [n_rows, d]."""
+        _check_mat(x, "x")
+        if x.shape[0] != self.shape[1]:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        d = x.shape[1]
+        if out is None:
+            if accumulate:
+                raise ValueError("accumulate=True needs an `out` tensor")
+            out = alloc_rows(self.shape[0], d, x.device, zero_pad=True)
+        else:
+            _check_mat(out, "out")
+            if out.shape != (self.shape[0], d):
+                raise ValueError("out has the wrong shape")
+        with torch.cuda.device(self.device):
+            check(lib().sgl_spmm_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), d, int(bool(accumulate)),
+                                     current_stream_ptr()), "sgl_spmm_f32")
+        return out
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().sgl_csr_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False):
+    """Device adj_to_symmetric_norm (+ optional PPR mix): canonical CSR of A on device -> CSR of A_hat.
+    rowptr int64 [n+1], col int32, val float32 (CUDA).  Returns (rowptr, col, val[, val64])."""
+    _lib.require_gpu()
+    nnz = int(col.numel())
+    dev = rowptr.device
+    nnz_out = c_int64(0)
+    with torch.cuda.device(dev):
+        check(lib().sgl_norm_prepare(n, nnz, ptr(rowptr), ptr(col), ctypes.byref(nnz_out), current_stream_ptr()),
+              "sgl_norm_prepare")
+        m = nnz_out.value
+        o_ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        o_col = torch.empty(m, dtype=torch.int32, device=dev)
+        o_val = torch.empty(m, dtype=torch.float32, device=dev)
+        o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
+        check(lib().sgl_norm_execute(n, nnz, ptr(rowptr), ptr(col), ptr(val), float(r), int(alpha is not None),
+                                     float(alpha if alpha is not None else 0.0), m, ptr(o_ptr), ptr(o_col), ptr(o_val),
+                                     ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_execute")
+    return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
+
+
+# ------------------------------------------------------------------------------------------------
+# aggregators
+# ------------------------------------------------------------------------------------------------
+def _check_hops(feats):
+    if len(feats) < 1 or len(feats) > _lib.SGL_MAX_HOPS:
+        raise ValueError(f"between 1 and {_lib.SGL_MAX_HOPS} hop matrices are supported")
+    for i, f in enumerate(feats):
+        _check_mat(f, f"feat_list[{i}]")
+        if f.shape != feats[0].shape or f.device != feats[0].device:
+            raise ValueError("all hop matrices must have the same shape and device")
+
+
+def hop_reduce(op, feats, weights=None):
+    """sum / mean / max / min / 1-D weighted sum over the hop list -> new [n, d] tensor"""
+    _check_hops(feats)
+    n, d = feats[0].shape
+    out = alloc_rows(n, d, feats[0].device)
+    ptrs, lds = _lib.hop_arrays(feats)
+    w = None
+    if op == _lib.SGL_REDUCE_WSUM:
+        w = weights.detach().to(device=feats[0].device, dtype=torch.float32).contiguous()
+        if w.numel() != len(feats):
+            raise ValueError("The feature list and the weight list have different lengths!")
+    with torch.cuda.device(feats[0].device):
+        check(lib().sgl_hop_reduce_f32(op, len(feats), ptrs, lds, ptr(w) if w is not None else None, ptr(out), _ld(out),
+                                       n, d, current_stream_ptr()), "sgl_hop_reduce_f32")
+    return out
+
+
+def hop_concat(feats):
+    _check_hops(feats)
+    n, d = feats[0].shape
+    H = len(feats)
+    out = alloc_rows(n, H * d, feats[0].device)
+    ptrs, lds = _lib.hop_arrays(feats)
+    with torch.cuda.device(feats[0].device):
+        check(lib().sgl_hop_concat_f32(H, ptrs, lds, ptr(out), _ld(out), n, d, current_stream_ptr()), "sgl_hop_concat_f32")
+    return out
+
+
+class _WSum2D(torch.autograd.Function):
+    """out[n,:] = sum_h W[n,h] X_h[n,:]  (two_dim_weighted_add, operators/utils.py:105-116)"""
+
+    @staticmethod
+    def forward(ctx, w, *feats):
+        feats_d = [f.detach() for f in feats]
+        _check_hops(feats_d)
+        n, d = feats_d[0].shape
+        wd = w.detach().to(torch.float32).contiguous()
+        if wd.shape != (n, len(feats_d)):
+            raise ValueError("The feature list and the weight list have different lengths!")
+        out = alloc_rows(n, d, feats_d[0].device)
+        ptrs, lds = _lib.hop_arrays(feats_d)
+        with torch.cuda.device(out.device):
+            check(lib().sgl_hop_wsum2d_f32(len(feats_d), ptrs, lds, ptr(wd), _ld(wd), ptr(out), _ld(out), n, d,
+                                           current_stream_ptr()), "sgl_hop_wsum2d_f32")
+        ctx.save_for_backward(wd, *feats_d)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        wd, *feats = ctx.saved_tensors
+        n, d = feats[0].shape
+        H = len(feats)
+        g = gout.detach().to(torch.float32)
+        if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
+            g = g.contiguous()
+        need_w = ctx.needs_input_grad[0]
+        need_x = [ctx.needs_input_grad[1 + h] for h in range(H)]
+        dw = torch.empty((n, H), dtype=torch.float32, device=g.device) if need_w else None
+        dxs = [alloc_rows(n, d, g.device) if need_x[h] else None for h in range(H)]
+        ptrs, lds = _lib.hop_arrays(feats)
+        dx_ptrs = dx_lds = None
+        if any(need_x):
+            dx_ptrs = (c_void_p * H)(*[(t.data_ptr() if t is not None else None) for t in dxs])
+            dx_lds = (c_int64 * H)(*[(_ld(t) if t is not None else 0) for t in dxs])
+        with torch.cuda.device(g.device):
+            check(lib().sgl_hop_wsum2d_bwd_f32(H, ptrs, lds, ptr(wd), _ld(wd), ptr(g), _ld(g),
+                                               ptr(dw) if need_w else None, H, dx_ptrs, dx_lds, n, d,
+                                               current_stream_ptr()), "sgl_hop_wsum2d_bwd_f32")
+        return (dw, *dxs)
+
+
+def hop_wsum2d(feats, w):
+    return _WSum2D.apply(w, *feats)
+
+
+class _WSum1D(torch.autograd.Function):
+    """out = sum_h w[h] X_h  (one_dim_weighted_add, operators/utils.py:91-102)"""
+
+    @staticmethod
+    def forward(ctx, w, *feats):
+        feats_d = [f.detach() for f in feats]
+        out = hop_reduce(_lib.SGL_REDUCE_WSUM, feats_d, w)
+        ctx.save_for_backward(w.detach().to(torch.float32), *feats_d)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        wd, *feats = ctx.saved_tensors
+        n, d = feats[0].shape
+        H = len(feats)
+        g = gout.detach().to(torch.float32)
+        if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
+            g = g.contiguous()
+        dw = None
+        if ctx.needs_input_grad[0]:
+            dw = torch.empty(H, dtype=torch.float32, device=g.device)
+            scratch = torch.empty(int(lib().sgl_hop_wsum1d_bwd_scratch(H)), dtype=torch.float32, device=g.device)
+            ptrs, lds = _lib.hop_arrays(feats)
+            with torch.cuda.device(g.device):
+                check(lib().sgl_hop_wsum1d_bwd_f32(H, ptrs, lds, ptr(g), _ld(g), ptr(dw), ptr(scratch), n, d,
+                                                   current_stream_ptr()), "sgl_hop_wsum1d_bwd_f32")
+        dxs = []
+        for h in range(H):
+            dxs.append(g * wd[h] if ctx.needs_input_grad[1 + h] else None)  # rarely needed: features carry no grad
+        return (dw, *dxs)
+
+
+def hop_wsum1d(feats, w):
+    return _WSum1D.apply(w, *feats)
+
+
+def nafs_aggregate(feats, return_weights=False):
+    """OverSmoothDistanceWeightedOp._combine (over_smooth_distance_op.py:11-33) on device"""
+    _check_hops(feats)
+    n, d = feats[0].shape
+    H = len(feats)
+    out = alloc_rows(n, d, feats[0].device)
+    w = torch.empty((n, H), dtype=torch.float32, device=feats[0].device)
+    ptrs, lds = _lib.hop_arrays(feats)
+    with torch.cuda.device(out.device):
+        check(lib().sgl_nafs_f32(H, ptrs, lds, ptr(out), _ld(out), ptr(w), H, n, d, current_stream_ptr()), "sgl_nafs_f32")
+    return (out, w) if return_weights else out
+
+
+def gather_rows(x, idx):
+    """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60)"""
+    _check_mat(x, "x")
+    if not torch.is_tensor(idx):
+        idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, range) else np.arange(idx.start, idx.stop, idx.step))
+    idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
+    n_rows, d = x.shape
+    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
+        neg = idx < 0
+        if bool((idx[neg] < -n_rows).any()) or int(idx.max()) >= n_rows:
+            raise IndexError("index out of range in row gather")
+        idx = torch.where(neg, idx + n_rows, idx)
+    out = alloc_rows(idx.numel(), d, x.device)
+    with torch.cuda.device(x.device):
+        check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d,
+                                        current_stream_ptr()), "sgl_gather_rows_f32")
+    return out

@@ -1,0 +1,81 @@
+"""SGAP container: pre-propagation (GraphOp) -> hop aggregation (MessageOp) -> dense head.
+
+Public behaviour of sgl/models/base_model.py:8-66 (BaseSGAPModel) with the hot path on the MI355X:
+  * preprocess(): the K SpMMs and the non-learnable aggregation are HIP kernels; hop matrices stay in HBM;
+  * forward(): the per-step row gather `feat[idx]` runs on the GPU (sgl_gather_rows_f32) instead of a CPU
+    fancy-index + PCIe copy per hop (reference :58,:60);
+  * postprocess(): softmax -> propagate -> aggregate without leaving the device (reference :44-47 goes through numpy).
+The de-facto attribute interface used by the reference's tasks (`_pre_graph_op`, `_pre_msg_op`, `_base_model`,
+`_processed_feat_list`, `_processed_feature`, `_pre_msg_learnable`, ...) is kept."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import config
+from .. import device as dev
+
+_LEARNABLE = ("proj_concat", "learnable_weighted", "iterate_learnable_weighted")
+
+
+def take_rows(feat, idx, device):
+    """feat[idx].to(device) -- on the GPU when the hop matrix lives there"""
+    if torch.is_tensor(feat) and feat.is_cuda:
+        return dev.gather_rows(feat, idx).to(device)
+    if isinstance(idx, range):
+        idx = list(idx)
+    return feat[idx].to(device)
+
+
+class BaseSGAPModel(nn.Module):
+    def __init__(self, prop_steps, feat_dim, output_dim):
+        super(BaseSGAPModel, self).__init__()
+        self._prop_steps = prop_steps
+        self._feat_dim = feat_dim
+        self._output_dim = output_dim
+
+        self._pre_graph_op, self._pre_msg_op = None, None
+        self._post_graph_op, self._post_msg_op = None, None
+        self._base_model = None
+
+        self._processed_feat_list = None
+        self._processed_feature = None
+        self._pre_msg_learnable = False
+
+    def preprocess(self, adj, feature):
+        if self._pre_graph_op is None:
+            self._pre_msg_learnable = False
+            self._processed_feature = feature
+            return
+        self._processed_feat_list = self._pre_graph_op.propagate(adj, feature)
+        self._pre_msg_learnable = self._pre_msg_op.aggr_type in _LEARNABLE
+        if not self._pre_msg_learnable:
+            with torch.no_grad():
+                self._processed_feature = self._pre_msg_op.aggregate(self._processed_feat_list)
+
+    def postprocess(self, adj, output):
+        if self._post_graph_op is None:
+            return output
+        if self._post_msg_op.aggr_type in _LEARNABLE:
+            raise ValueError(
+                "Learnable weighted message operator is not supported in the post-processing phase!")
+        probs = F.softmax(output, dim=1).detach()
+        strict = self._post_graph_op._opt("strict_types") if hasattr(self._post_graph_op, "_opt") else config.strict_types
+        hops = self._post_graph_op.propagate(adj, probs.cpu().numpy() if strict else probs)
+        with torch.no_grad():
+            return self._post_msg_op.aggregate(hops)
+
+    # a wrapper of the forward function
+    def model_forward(self, idx, device):
+        return self.forward(idx, device)
+
+    def forward(self, idx, device):
+        if self._pre_msg_learnable:
+            hop_rows = [take_rows(feat, idx, device) for feat in self._processed_feat_list]
+            processed_feature = self._pre_msg_op.aggregate(hop_rows)
+        else:
+            feat = self._processed_feature
+            if isinstance(feat, np.ndarray):  # no pre-graph-op: the raw feature matrix
+                feat = torch.from_numpy(feat)
+            processed_feature = take_rows(feat, idx, device)
+        return self._base_model(processed_feature)

@@ -1,0 +1,15 @@
+"""GAMLP (JK attention).  Reference: sgl/models/homo/gamlp.py:7-13"""
+from ..base_model import BaseSGAPModel
+from ..simple_models import IdenticalMapping, LogisticRegression, MultiLayerPerceptron, ResMultiLayerPerceptron  # noqa: F401
+from ...operators.graph_op import LaplacianGraphOp, PprGraphOp  # noqa: F401
+from ...operators.message_op import (  # noqa: F401
+    ConcatMessageOp, IterateLearnableWeightedMessageOp, LastMessageOp, LearnableWeightedMessageOp, MeanMessageOp,
+    OverSmoothDistanceWeightedOp, SimpleWeightedMessageOp)
+
+
+class GAMLP(BaseSGAPModel):
+    def __init__(self, prop_steps, feat_dim, output_dim, hidden_dim, num_layers):
+        super(GAMLP, self).__init__(prop_steps, feat_dim, output_dim)
+        self._pre_graph_op = LaplacianGraphOp(prop_steps, r=0.5)
+        self._pre_msg_op = LearnableWeightedMessageOp(0, prop_steps + 1, "jk", prop_steps, feat_dim)
+        self._base_model = MultiLayerPerceptron(feat_dim, hidden_dim, num_layers, output_dim)

@@ -1,0 +1,118 @@
+"""GraphOp / MessageOp plugin base classes -- same public API as sgl/operators/base_op.py:11-60.
+
+GraphOp.propagate(adj, feature) -> [X, A_hat X, ..., A_hat^K X]; the K SpMMs run as hand-written HIP kernels on
+the MI355X with the normalised adjacency and every hop matrix resident in HBM (the reference re-creates
+its buffers and, in its cuSPARSE twin, re-uploads them on every hop: cudamatmul.c:57-74,129)."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import config
+from .. import device as dev
+
+
+def _fingerprint(adj):
+    """cheap identity of a scipy matrix for the normalised-adjacency cache (object, buffers, size, data sample)"""
+    data = adj.data
+    step = max(1, data.size // 1024)
+    return (id(adj), adj.shape, adj.nnz, data.ctypes.data, adj.indices.ctypes.data if hasattr(adj, "indices") else 0,
+            float(np.asarray(data[::step], dtype=np.float64).sum()))
+
+
+class GraphOp:
+    def __init__(self, prop_steps, device=None, host_output=None, strict_types=None, strict_order=None, cache_adj=None):
+        self._prop_steps = prop_steps
+        self._adj = None
+        self._device = device
+        self._host_output = host_output
+        self._strict_types = strict_types
+        self._strict_order = strict_order
+        self._cache_adj = cache_adj
+        self._adj_key = None
+
+    # ---- effective settings (ctor kwarg, else sgl_amd.config) ------------------------------------
+    def _opt(self, name):
+        v = getattr(self, "_" + name)
+        return getattr(config, name) if v is None else v
+
+    def _construct_adj(self, adj):
+        raise NotImplementedError
+
+    def _norm_params(self):
+        """(r, alpha) of A_hat = D^{r-1}(A+I)^T D^{-r} [PPR: (1-alpha) A_hat + alpha I]; subclasses override"""
+        raise NotImplementedError
+
+    def _device_adj(self, adj):
+        """normalise `adj` on the GPU (cached per matrix) -> DeviceCSR of A_hat"""
+        from .utils import adj_to_symmetric_norm_device
+        r, alpha = self._norm_params()
+        key = None
+        if self._opt("cache_adj"):
+            key = (_fingerprint(adj), r, alpha, bool(self._opt("strict_order")), str(self._opt("device")))
+            if key == self._adj_key and self._adj is not None:
+                return self._adj
+        rowptr, col, val = adj_to_symmetric_norm_device(adj, r, alpha, device=self._opt("device"))
+        csr = dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
+        self._adj_key = key
+        return csr
+
+    def propagate(self, adj, feature):
+        self._adj = self._construct_adj(adj)
+
+        if not isinstance(adj, sp.csr_matrix):
+            raise TypeError("The adjacency matrix must be a scipy csr sparse matrix!")
+        elif not isinstance(feature, np.ndarray) and not (isinstance(feature, Tensor) and not self._opt("strict_types")):
+            raise TypeError("The feature matrix must be a numpy.ndarray!")
+        elif self._adj.shape[1] != feature.shape[0]:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        if self._opt("strict_types") and feature.dtype != np.float32:
+            # the reference's ctypes ndpointer(float32) rejects anything else (operators/utils.py:22-26)
+            raise TypeError("The feature matrix must be a float32 numpy.ndarray!")
+        if feature.ndim != 2:
+            raise ValueError("The feature matrix must be two-dimensional!")
+
+        device = self._adj.device
+        x0 = feature if (isinstance(feature, Tensor) and feature.is_cuda and feature.dtype == torch.float32) else None
+        cur = dev.upload_rows(feature, device) if x0 is None else x0
+        if (cur.shape[1] > 1 and cur.stride(1) != 1) or cur.stride(0) % 4 != 0 or cur.data_ptr() % 16 != 0:
+            cur = dev.upload_rows(cur, device)  # re-pack into an aligned, row-padded buffer
+        prop_feat_list = [cur]
+        for _ in range(self._prop_steps):
+            # run over the padded width so every d gets 16-byte lanes (pad columns are zeros and stay zeros)
+            src = dev.padded_parent(prop_feat_list[-1]) if prop_feat_list[-1].stride(0) % 4 == 0 else prop_feat_list[-1]
+            dst = self._adj.spmm(src)
+            prop_feat_list.append(dst[:, :cur.shape[1]] if dst.shape[1] != cur.shape[1] else dst)
+
+        if self._opt("host_output"):
+            out = [f.cpu() for f in prop_feat_list]
+            if isinstance(feature, np.ndarray) and feature.dtype == np.float32:
+                out[0] = torch.from_numpy(feature)  # the reference's first element aliases the caller's array
+            return [o.contiguous() for o in out]
+        return prop_feat_list
+
+
+# Might include training parameters
+class MessageOp(nn.Module):
+    def __init__(self, start=None, end=None):
+        super(MessageOp, self).__init__()
+        self._aggr_type = None
+        self._start, self._end = start, end
+
+    @property
+    def aggr_type(self):
+        return self._aggr_type
+
+    def _combine(self, feat_list):
+        return NotImplementedError
+
+    def aggregate(self, feat_list):
+        if not isinstance(feat_list, list):
+            # reference quirk kept on purpose (base_op.py:55 RETURNS the exception instead of raising it)
+            return TypeError("The input must be a list consists of feature matrices!")
+        for feat in feat_list:
+            if not isinstance(feat, Tensor):
+                raise TypeError("The feature matrices must be tensors!")
+
+        return self._combine(feat_list)

@@ -1,0 +1,516 @@
+"""Parity of the HIP path (through the C ABI of libsgl_hip.so) against the CPU oracle and the committed golden
+vectors recorded from the reference.  Every test here needs a real MI355X: run with `-m gpu`.
+
+Bars: integer / index work (CSR structure, plans) bit-exact; the SpMM in strict-order mode bit-exact (same fmaf
+chain as csrc/matmul.c:23-40); everything else within the SURVEY 8(c) tolerance (1e-5, three-way criterion)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import oracle
+from inputs import hash_matrix
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    from sgl_amd import _lib
+    _lib.require_gpu()
+    torch.cuda.set_device(0)
+    return torch.device("cuda", 0)
+
+
+def norm_graph(goldens, name, r=0.5, alpha=None):
+    g = goldens.graph(name)
+    n = g.shape[0]
+    ptr, col, val = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, r, alpha)
+    return n, ptr, col, val.astype(np.float32)
+
+
+def device_csr(ptr, col, val, shape, dev, **kw):
+    from sgl_amd.device import DeviceCSR
+    return DeviceCSR(torch.from_numpy(np.asarray(ptr, np.int64)).to(dev), torch.from_numpy(np.asarray(col, np.int32)).to(dev),
+                     torch.from_numpy(np.asarray(val, np.float32)).to(dev), shape, **kw)
+
+
+def long_row_graph(n=1500, seed=5):
+    """power-law rows plus three huge rows and some empty ones (canonical CSR, not symmetric)"""
+    rng = np.random.default_rng(seed)
+    deg = np.minimum(rng.lognormal(1.2, 1.0, n).astype(np.int64), 200)
+    deg[[3, 700, n - 1]] = [1400, 900, 1499]
+    deg[rng.integers(0, n, 60)] = 0
+    rows, cols = [], []
+    for i in range(n):
+        c = np.sort(rng.choice(n, int(deg[i]), replace=False))
+        rows.append(np.full(len(c), i))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = rng.uniform(-1, 1, len(rows)).astype(np.float32)
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    a.sort_indices()
+    return a
+
+
+D_LIST = [1, 2, 3, 4, 7, 8, 16, 32, 47, 64, 100, 128, 147, 256, 500]
+
+
+@pytest.mark.parametrize("gname", ["pl2000", "dir40", "sym64"])
+def test_spmm_strict_is_bit_exact(goldens, cuda, gname):
+    from sgl_amd.device import alloc_rows, padded_parent
+    n, ptr, col, val = norm_graph(goldens, gname)
+    csr = device_csr(ptr, col, val, (n, n), cuda, strict=True)
+    bad = []
+    for d in D_LIST:
+        x = hash_matrix(n, d, seed=d)
+        ref = oracle.oracle_spmm(ptr, col, val, x)
+        # (a) contiguous [n, d]: exercises the 4-/8-/16-byte lane paths depending on d
+        y = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
+        if not np.array_equal(y, ref):
+            bad.append(("contig", d, oracle.parity_report(y, ref)))
+        # (b) row-padded buffer (the layout GraphOp.propagate uses): always 16-byte lanes
+        xp = alloc_rows(n, d, cuda)
+        xp.copy_(torch.from_numpy(x))
+        yp = csr.spmm(padded_parent(xp))[:, :d].cpu().numpy()
+        if not np.array_equal(yp, ref):
+            bad.append(("padded", d, oracle.parity_report(yp, ref)))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("gname", ["pl2000", "dir40"])
+def test_spmm_fast_within_tolerance(goldens, cuda, gname):
+    n, ptr, col, val = norm_graph(goldens, gname)
+    csr = device_csr(ptr, col, val, (n, n), cuda, strict=False)
+    exact = 0
+    for d in D_LIST:
+        x = hash_matrix(n, d, seed=d + 1)
+        ref = oracle.oracle_spmm(ptr, col, val, x)
+        y = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
+        rep = oracle.parity_report(y, ref, TOL)
+        assert rep["ok"], (d, rep)
+        exact += rep["bit_equal"]
+    print(f"fast mode: {exact}/{len(D_LIST)} widths bit-equal on {gname}")
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_spmm_long_rows_empty_rows_and_splitting(cuda, strict):
+    a = long_row_graph()
+    n = a.shape[0]
+    for d in (4, 100, 128, 37):
+        x = hash_matrix(n, d, seed=11)
+        ref = oracle.oracle_spmm(a.indptr, a.indices, a.data, x)
+        for item_nnz, long_nnz in ((512, 2048), (64, 256), (8, 100), (100000, 64)):
+            csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, item_nnz=item_nnz, long_row_nnz=long_nnz)
+            info = csr.info()
+            if strict:
+                assert info["n_pieces"] == 0
+            elif long_nnz < 1400:
+                assert info["n_long_rows"] >= 3 and info["n_pieces"] >= 3
+            y = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
+            if strict:
+                assert np.array_equal(y, ref), (d, item_nnz, long_nnz, oracle.parity_report(y, ref))
+            else:
+                rep = oracle.parity_report(y, ref, TOL)
+                assert rep["ok"], (d, item_nnz, long_nnz, rep)
+            # deterministic: same bits on a second run (no float atomics)
+            y2 = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
+            assert np.array_equal(y, y2)
+
+
+def test_spmm_accumulate_and_overwrite_semantics(goldens, cuda):
+    n, ptr, col, val = norm_graph(goldens, "pl256")
+    for strict in (True, False):
+        csr = device_csr(ptr, col, val, (n, n), cuda, strict=strict, long_row_nnz=16)
+        for d in (16, 100, 5):
+            x = hash_matrix(n, d, seed=3)
+            y0 = hash_matrix(n, d, seed=4)
+            ref_acc = oracle.oracle_spmm(ptr, col, val, x, out=y0.copy())       # matmul.c:37 semantics
+            ref_ovw = oracle.oracle_spmm(ptr, col, val, x)                      # cudamatmul.c:46 (beta = 0)
+            y = torch.from_numpy(y0.copy()).to(cuda)
+            csr.spmm(torch.from_numpy(x).to(cuda), out=y, accumulate=True)
+            z = torch.from_numpy(y0.copy()).to(cuda)
+            csr.spmm(torch.from_numpy(x).to(cuda), out=z, accumulate=False)
+            if strict:
+                assert np.array_equal(y.cpu().numpy(), ref_acc)
+                assert np.array_equal(z.cpu().numpy(), ref_ovw)
+            else:
+                assert oracle.parity_ok(y.cpu().numpy(), ref_acc, TOL)
+                assert oracle.parity_ok(z.cpu().numpy(), ref_ovw, TOL)
+
+
+def test_spmm_rectangular_shard_and_degenerate_shapes(goldens, cuda):
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    x = hash_matrix(n, 100, seed=8)
+    ref = oracle.oracle_spmm(ptr, col, val, x)
+    xd = torch.from_numpy(x).to(cuda)
+    # a row shard [r0, r1) of the matrix is a rectangular CSR over all n columns (what each rank owns)
+    for (r0, r1) in ((0, 700), (700, 1999), (1999, 2000), (500, 500)):
+        rp = (ptr[r0:r1 + 1] - ptr[r0]).astype(np.int64)
+        nb, ne = int(ptr[r0]), int(ptr[r1])
+        csr = device_csr(rp, col[nb:ne], val[nb:ne], (r1 - r0, n), cuda, strict=True)
+        y = csr.spmm(xd).cpu().numpy()
+        assert y.shape == (r1 - r0, 100) and np.array_equal(y, ref[r0:r1])
+    # all-empty matrix -> zeros; d = 0 columns -> empty
+    z = device_csr(np.zeros(n + 1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32), (n, n), cuda)
+    assert not z.spmm(xd).cpu().numpy().any()
+    csr = device_csr(ptr, col, val, (n, n), cuda)
+    assert csr.spmm(torch.empty((n, 0), device=cuda)).shape == (n, 0)
+    with pytest.raises(ValueError):
+        csr.spmm(xd[:10])
+
+
+def test_spmm_every_tuning_variant(goldens, cuda):
+    from sgl_amd import _lib
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    saved = {k: _lib.get_tuning(k) for k in ("spmm_unroll", "spmm_nt", "spmm_group", "spmm_waves", "spmm_xcd_remap")}
+    try:
+        for d in (100, 16, 500):
+            x = hash_matrix(n, d, seed=21)
+            ref = oracle.oracle_spmm(ptr, col, val, x)
+            xd = torch.from_numpy(x).to(cuda)
+            for unroll in (0, 1, 2):
+                for nt in (0, 1):
+                    for group in (0, 32, 64):
+                        for waves in (1, 4):
+                            for remap in (0, 1):
+                                for k, v in (("spmm_unroll", unroll), ("spmm_nt", nt), ("spmm_group", group),
+                                             ("spmm_waves", waves), ("spmm_xcd_remap", remap)):
+                                    _lib.set_tuning(k, v)
+                                csr = device_csr(ptr, col, val, (n, n), cuda, long_row_nnz=128)
+                                rep = oracle.parity_report(csr.spmm(xd).cpu().numpy(), ref, TOL)
+                                assert rep["ok"], (d, unroll, nt, group, waves, remap, rep)
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+
+
+def test_reference_signature_shims(goldens, cuda):
+    """FloatCSRMulDenseOMP / FloatCSRMulDense bound exactly like sgl/operators/utils.py:10-73 binds them"""
+    from sgl_amd.operators.utils import csr_sparse_dense_matmul, cuda_csr_sparse_dense_matmul
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    adj = sp.csr_matrix((val.astype(np.float64), col, ptr.astype(np.int32)), shape=(n, n))
+    for d in (37, 100):
+        x = hash_matrix(n, d, seed=2)
+        ref = oracle.oracle_spmm(ptr, col, val, x)
+        assert np.array_equal(csr_sparse_dense_matmul(adj, x), ref)
+        assert np.array_equal(cuda_csr_sparse_dense_matmul(adj, x), ref)
+    if oracle.load_reference_lib() is not None:
+        assert np.array_equal(csr_sparse_dense_matmul(adj, x), oracle.reference_spmm(ptr, col, val, x))
+
+
+G1_VARIANTS = [("lap", r, None) for r in (0.0, 0.3, 0.5, 1.0)] + \
+              [("ppr", 0.5, a) for a in (0.1, 0.15, 0.2, 0.3)] + [("ppr", 0.3, 0.15)]
+
+
+@pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
+def test_device_normalisation_matches_reference_goldens(goldens, cuda, gname):
+    from sgl_amd.operators.utils import adj_to_symmetric_norm_device
+    g = goldens.graph(gname)
+    g1 = goldens.npz("g1_norm")
+    worst, n_diff32, total = 0.0, 0, 0
+    for kind, r, a in G1_VARIANTS:
+        key = f"{gname}|{kind}|{r}" + ("" if a is None else f"|{a}")
+        ptr, col, v32, v64 = adj_to_symmetric_norm_device(g, r, a, device=cuda, return_fp64=True)
+        assert np.array_equal(ptr.cpu().numpy(), g1[gname + "|indptr"]), key          # structure: bit exact
+        assert np.array_equal(col.cpu().numpy(), g1[gname + "|indices"]), key
+        ref = g1[key]
+        got = v64.cpu().numpy()
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+        worst = max(worst, float(rel.max()))
+        assert rel.max() <= 1e-14, (key, rel.max())                                   # fp64, same operation order
+        d32 = v32.cpu().numpy() != ref.astype(np.float32)
+        n_diff32 += int(d32.sum())
+        total += d32.size
+        assert np.allclose(v32.cpu().numpy(), ref.astype(np.float32), rtol=1.2e-7, atol=0), key   # <= 1 ulp(fp32)
+    print(f"{gname}: worst fp64 rel err {worst:.2e}; fp32-rounded values differing: {n_diff32}/{total}")
+
+
+def test_adj_to_symmetric_norm_scipy_contract(goldens, cuda):
+    from sgl_amd.operators.utils import adj_to_symmetric_norm
+    g = goldens.graph("dir40")
+    out = adj_to_symmetric_norm(g.tocoo(), 0.5)
+    assert sp.issparse(out) and out.dtype == np.float64 and out.shape == g.shape
+    g1 = goldens.npz("g1_norm")
+    assert np.array_equal(out.indices, g1["dir40|indices"])
+    assert np.allclose(out.data, g1["dir40|lap|0.5"], rtol=1e-14, atol=0)
+
+
+def test_propagate_matches_reference_goldens(goldens, cuda):
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    g2 = goldens.npz("g2_prop")
+    meta = goldens.json("g2_prop")
+    n_exact = n_total = 0
+    for key, m in meta.items():
+        g = goldens.graph(m["graph"])
+        x = hash_matrix(g.shape[0], m["d"], seed=m["seed"], order=m["order"])
+        for strict in (True, False):
+            mk = (lambda K: LaplacianGraphOp(K, r=m["r"], strict_order=strict)) if m["kind"] == "lap" else \
+                 (lambda K: PprGraphOp(K, r=m["r"], alpha=m["alpha"], strict_order=strict))
+            hops = mk(m["K"]).propagate(g, x)
+            assert len(hops) == m["K"] + 1 and all(h.is_cuda and h.dtype == torch.float32 for h in hops)
+            assert np.array_equal(hops[0].cpu().numpy(), x)
+            check = range(1, m["K"] + 1) if m["keep"] == "all" else [m["K"]]
+            for h in check:
+                rep = oracle.parity_report(hops[h].cpu().numpy(), g2[f"{key}|h{h}"], TOL)
+                assert rep["ok"], (key, strict, h, rep)
+                if strict:
+                    n_total += 1
+                    n_exact += rep["bit_equal"]
+            sums = np.array([f.double().sum().item() for f in hops])
+            assert np.allclose(sums, g2[f"{key}|sums"], rtol=1e-4, atol=1e-3), key
+    print(f"propagate strict mode: {n_exact}/{n_total} golden hop matrices reproduced bit-for-bit")
+    assert n_exact >= 0.9 * n_total   # device A_hat may differ from scipy's by 1 ulp(fp32) in rare entries
+
+
+def test_propagate_host_output_and_input_types(goldens, cuda):
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g = goldens.graph("pl256")
+    x = hash_matrix(256, 16, seed=1)
+    ref = oracle.propagate(oracle.laplacian_adj(g.indptr, g.indices, g.data, 256, 0.5), x, 3)
+    host = LaplacianGraphOp(3, host_output=True, strict_order=True).propagate(g, x)
+    assert all((not h.is_cuda) and h.dtype == torch.float32 and h.is_contiguous() for h in host)
+    assert host[0].data_ptr() == x.ctypes.data                       # element 0 aliases the caller's array
+    for h in range(4):
+        assert oracle.parity_ok(host[h].numpy(), ref[h], TOL)
+    # superset inputs: torch CPU tensor, CUDA tensor, float64 ndarray, F-order
+    for feat in (torch.from_numpy(x), torch.from_numpy(x).to(cuda), x.astype(np.float64), np.asfortranarray(x)):
+        hops = LaplacianGraphOp(3).propagate(g, feat)
+        assert oracle.parity_ok(hops[3].cpu().numpy(), ref[3], TOL)
+    # cache: same matrix object -> the normalised adjacency is reused; a different r is not served from it
+    op = LaplacianGraphOp(1)
+    op.propagate(g, x)
+    first = op._adj
+    op.propagate(g, x)
+    assert op._adj is first
+    g2 = g.copy()
+    g2.data[:] = 2.0
+    op.propagate(g2, x)
+    assert op._adj is not first
+
+
+def test_error_contract_gpu(goldens, cuda):
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g5 = goldens.json("g5_errors")
+    g = goldens.graph("sym64")
+    x = hash_matrix(64, 4, seed=1)
+
+    def expect(case, fn):
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == case["raised"] and str(ei.value) == case["msg"], (ei.value, case)
+
+    expect(g5["propagate_coo_adj"], lambda: LaplacianGraphOp(2).propagate(g.tocoo(), x))
+    expect(g5["propagate_shape_mismatch"], lambda: LaplacianGraphOp(2).propagate(g, x[:10]))
+    expect(g5["propagate_tensor_feature"], lambda: LaplacianGraphOp(2, strict_types=True).propagate(g, torch.from_numpy(x)))
+
+
+# ---- aggregators ------------------------------------------------------------------------------------------
+def g3_feats(goldens, dev, requires_grad=False):
+    g3 = goldens.npz("g3_agg")
+    feats = [torch.from_numpy(g3[f"feat{j}"]).to(dev) for j in range(5)]
+    if requires_grad:
+        feats = [f.clone().requires_grad_(True) for f in feats]
+    return feats, g3
+
+
+def test_simple_aggregators_bit_exact(goldens, cuda):
+    from sgl_amd.operators import message_op as m
+    feats, g3 = g3_feats(goldens, cuda)
+    H = 5
+    assert np.array_equal(m.LastMessageOp().aggregate(feats).cpu().numpy(), g3["last"])
+    for (s, e) in ((0, H), (1, H - 1)):
+        tag = f"{s}_{e}"
+        for name, cls in (("concat", m.ConcatMessageOp), ("mean", m.MeanMessageOp), ("sum", m.SumMessageOp),
+                          ("max", m.MaxMessageOp), ("min", m.MinMessageOp)):
+            y = cls(s, e).aggregate(feats)
+            assert y.is_cuda
+            assert np.array_equal(y.cpu().numpy(), g3[f"{name}|{tag}"]), (name, tag)
+    # CPU tensors in -> CPU tensor out (computed on the GPU)
+    y = m.MeanMessageOp(0, H).aggregate([f.cpu() for f in feats])
+    assert not y.is_cuda and np.array_equal(y.numpy(), g3["mean|0_5"])
+
+
+def test_max_min_propagate_nan_like_torch(cuda):
+    from sgl_amd.operators import message_op as m
+    a = torch.tensor([[1.0, float("nan"), -2.0, 5.0]] * 3, device=cuda)
+    b = torch.tensor([[float("nan"), 0.0, 3.0, float("inf")]] * 3, device=cuda)
+    for cls, fn in ((m.MaxMessageOp, torch.max), (m.MinMessageOp, torch.min)):
+        got = cls(0, 2).aggregate([a, b]).cpu()
+        ref = fn(torch.stack([a.cpu(), b.cpu()], 0), dim=0)[0]
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        assert torch.equal(got[~torch.isnan(got)], ref[~torch.isnan(ref)])
+
+
+def test_weighted_and_nafs_aggregators(goldens, cuda):
+    from sgl_amd.device import nafs_aggregate
+    from sgl_amd.operators import message_op as m
+    feats, g3 = g3_feats(goldens, cuda)
+    H = 5
+    for (s, e) in ((0, H), (1, H)):
+        y = m.SimpleWeightedMessageOp(s, e, "alpha", 0.85).aggregate(feats).cpu().numpy()
+        assert oracle.parity_ok(y, g3[f"simple_weighted|alpha0.85|{s}_{e}"], 1e-6)
+    w = [float(v) for v in g3["simple_weighted|hand_crafted|w"]]
+    y = m.SimpleWeightedMessageOp(0, H, "hand_crafted", w).aggregate(feats).cpu().numpy()
+    assert oracle.parity_ok(y, g3["simple_weighted|hand_crafted|0_5"], 1e-6)
+    y = m.OverSmoothDistanceWeightedOp().aggregate(feats).cpu().numpy()
+    rep = oracle.parity_report(y, g3["over_smooth"], TOL)
+    assert rep["ok"], rep
+    _, wts = nafs_aggregate(feats, return_weights=True)
+    assert np.allclose(wts.cpu().numpy(), oracle.nafs_weights([f.cpu().numpy() for f in feats]), rtol=1e-5, atol=1e-6)
+    assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["simple", "simple_allow_neg", "gate", "ori_ref", "jk"])
+def test_learnable_aggregators_forward_and_backward(goldens, cuda, kind):
+    from sgl_amd.operators.message_op import LearnableWeightedMessageOp
+    _, g3 = g3_feats(goldens, cuda)
+    gout = torch.from_numpy(hash_matrix(96, 12, seed=777)).to(cuda)
+    args = {"simple": (4,), "simple_allow_neg": (4,), "gate": (12,), "ori_ref": (12,), "jk": (4, 12)}[kind]
+    for (s, e) in ((0, 5), (1, 5)):
+        tag = f"learnable|{kind}|{s}_{e}"
+        op = LearnableWeightedMessageOp(s, e, kind, *args)
+        op.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(v) for k, v in g3.items() if k.startswith(tag + "|param|")})
+        op = op.to(cuda)
+        feats, _ = g3_feats(goldens, cuda, requires_grad=True)
+        y = op.aggregate(feats)
+        rep = oracle.parity_report(y.detach().cpu().numpy(), g3[tag + "|out"], TOL)
+        assert rep["ok"], (tag, rep)
+        (y * gout).sum().backward()
+        for name, p in op.named_parameters():
+            rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), g3[tag + "|grad|" + name].reshape(1, -1), 1e-4)
+            assert rep["ok"], (tag, name, rep)
+        for j, f in enumerate(feats):
+            got = (f.grad if f.grad is not None else torch.zeros_like(f)).cpu().numpy()
+            rep = oracle.parity_report(got, g3[tag + f"|dfeat{j}"], 1e-4)
+            assert rep["ok"] or not g3[tag + f"|dfeat{j}"].any() and not got.any(), (tag, j, rep)
+
+
+def test_iterate_and_projected_concat(goldens, cuda):
+    from sgl_amd.operators.message_op import IterateLearnableWeightedMessageOp, ProjectedConcatMessageOp
+    _, g3 = g3_feats(goldens, cuda)
+    gout = torch.from_numpy(hash_matrix(96, 12, seed=777)).to(cuda)
+    op = IterateLearnableWeightedMessageOp(0, 5, "recursive", 12)
+    op.load_state_dict({k[len("iterate|0_5|param|"):]: torch.from_numpy(v) for k, v in g3.items() if k.startswith("iterate|0_5|param|")})
+    op = op.to(cuda)
+    feats, _ = g3_feats(goldens, cuda, requires_grad=True)
+    y = op.aggregate(feats)
+    rep = oracle.parity_report(y.detach().cpu().numpy(), g3["iterate|0_5|out"], TOL)
+    assert rep["ok"], rep
+    (y * gout).sum().backward()
+    for name, p in op.named_parameters():
+        rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), g3["iterate|0_5|grad|" + name].reshape(1, -1), 1e-4)
+        assert rep["ok"], (name, rep)
+    for j, f in enumerate(feats):
+        rep = oracle.parity_report(f.grad.cpu().numpy(), g3[f"iterate|0_5|dfeat{j}"], 1e-4)
+        assert rep["ok"], (j, rep)
+    pc = ProjectedConcatMessageOp(0, 5, 12, 8, 2)
+    pc.load_state_dict({k[len("proj_concat|0_5|param|"):]: torch.from_numpy(v) for k, v in g3.items() if k.startswith("proj_concat|0_5|param|")})
+    pc = pc.to(cuda).eval()
+    feats, _ = g3_feats(goldens, cuda)
+    with torch.no_grad():
+        y = pc.aggregate(feats)
+    rep = oracle.parity_report(y.cpu().numpy(), g3["proj_concat|0_5|out"], 1e-4)
+    assert rep["ok"], rep
+
+
+def test_gather_rows(cuda):
+    from sgl_amd.device import alloc_rows, gather_rows
+    for d in (100, 147, 3, 500):
+        x = alloc_rows(1000, d, cuda)
+        x.copy_(torch.from_numpy(hash_matrix(1000, d, seed=d)))
+        idx = torch.randint(0, 1000, (333,), generator=torch.Generator().manual_seed(1))
+        assert torch.equal(gather_rows(x, idx).cpu(), x.cpu()[idx])
+        assert torch.equal(gather_rows(x, range(5, 50)).cpu(), x.cpu()[5:50])
+        assert torch.equal(gather_rows(x, np.array([-1, 0, 999])).cpu(), x.cpu()[[-1, 0, 999]])
+        assert gather_rows(x, []).shape == (0, d)
+    with pytest.raises(IndexError):
+        gather_rows(x, [1000])
+
+
+def test_models_match_reference_goldens(goldens, cuda):
+    from sgl_amd.models import homo
+    g4 = goldens.npz("g4_models")
+    g = goldens.graph("pl2000")
+    n, d, C, K = 2000, 16, 5, 3
+    x = hash_matrix(n, d, seed=4242)
+    idx = g4["idx"]
+    ctor = {"SGC": (K, d, C), "SSGC": (K, d, C), "SIGN": (K, d, C, 32, 2), "GBP": (K, d, C, 32, 2),
+            "GAMLP": (K, d, C, 32, 2), "GAMLPRecursive": (K, d, C, 32, 2), "NAFS": (K, d, C),
+            "PASCA_V3": (K, 2, d, C, 32, 3)}
+    for name, args in ctor.items():
+        model = getattr(homo, name)(*args)
+        model.load_state_dict({k.split("|param|")[1]: torch.from_numpy(v) for k, v in g4.items() if k.startswith(name + "|param|")})
+        model = model.to(cuda).eval()
+        model.preprocess(g, x)
+        with torch.no_grad():
+            y = model.model_forward(idx, cuda)
+        rep = oracle.parity_report(y.cpu().numpy(), g4[f"{name}|out"], 1e-4)
+        assert rep["ok"], (name, rep)
+        if name == "PASCA_V3":
+            with torch.no_grad():
+                post = model.postprocess(g, model.model_forward(range(n), cuda))
+            rep = oracle.parity_report(post.cpu().numpy()[idx], g4["PASCA_V3|post"], 1e-4)
+            assert rep["ok"], (name, "post", rep)
+    # training step through the learnable aggregator on device
+    model = homo.GAMLP(K, d, C, 32, 2).to(cuda)
+    model.preprocess(g, x)
+    out = model.model_forward(range(0, 512), cuda)
+    out.logsumexp(1).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# ---- full-size, size-independent properties ------------------------------------------------------------------
+def test_products_scale_properties(cuda):
+    """ogbn-products-shaped graph (N = 2.45 M, nnz ~ 126 M, d = 100): sampled rows against the oracle, linearity,
+    row-stochasticity of D^-1 (A+I), strict == fast within tolerance."""
+    from sgl_amd import device as dev
+    from sgl_amd import synthetic
+    free, _ = torch.cuda.mem_get_info()
+    wl = synthetic.WORKLOADS["S1_products" if free > 60e9 else "S1_small"]
+    n, d = wl["n"], wl["d"]
+    a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=0, device=cuda)
+    # symmetric, no self loops, sorted
+    assert int(a_ptr[-1]) == a_col.numel() == 2 * wl["m"]
+    rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)
+    assert col.numel() == a_col.numel() + n
+    x = synthetic.features_torch(n, d, seed=0, device=cuda)
+    fast = dev.DeviceCSR(rowptr, col, val, (n, n))
+    strict = dev.DeviceCSR(rowptr, col, val, (n, n), strict=True)
+    y = fast.spmm(x)
+    ys = strict.spmm(x)
+    # (1) sampled rows vs the CPU oracle, bit-exact in strict mode
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:20000].sort().values
+    rp, cc, vv = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    xh = x.cpu().numpy()
+    sub_ptr = np.zeros(len(rows) + 1, np.int64)
+    segs = [(int(rp[r]), int(rp[r + 1])) for r in rows.tolist()]
+    sub_ptr[1:] = np.cumsum([e - b for b, e in segs])
+    sub_col = np.concatenate([cc[b:e] for b, e in segs])
+    sub_val = np.concatenate([vv[b:e] for b, e in segs])
+    ref = oracle.oracle_spmm(sub_ptr, sub_col, sub_val, xh)
+    assert np.array_equal(ys[rows.to(cuda)].cpu().numpy(), ref)
+    rep = oracle.parity_report(y[rows.to(cuda)].cpu().numpy(), ref, TOL)
+    assert rep["ok"], rep
+    # (2) strict vs fast over ALL rows (row-wise L2 criterion on device)
+    dn = (y - ys).norm(dim=1)
+    rn = ys.norm(dim=1).clamp_min(1e-30)
+    assert float((dn / rn).max()) <= TOL and float((y - ys).abs().max() / ys.abs().max()) <= TOL
+    # (3) linearity: A(2x + 3z) == 2Ax + 3Az
+    z = synthetic.features_torch(n, d, seed=5, device=cuda)
+    lhs = fast.spmm(2 * x + 3 * z)
+    rhs = 2 * y + 3 * fast.spmm(z)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= 5e-6
+    # (4) r = 1 gives the random-walk matrix (A+I)^T D^-1... columns scaled; use r = 0: rows of D^-1 (A+I) sum to 1
+    rp0, c0, v0 = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.0, None)
+    ones = torch.ones((n, 4), device=cuda)
+    rs = dev.DeviceCSR(rp0, c0, v0, (n, n)).spmm(ones)
+    assert float((rs - 1).abs().max()) <= 1e-5
+    # (5) k-step propagation through the operator API reproduces repeated SpMM
+    hop2 = strict.spmm(ys)
+    assert torch.equal(hop2, strict.spmm(strict.spmm(x)))

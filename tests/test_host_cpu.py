@@ -1,0 +1,246 @@
+"""CPU-side tests of the host logic and of the C-ABI boundary (no GPU compute): symbol export, execution plan,
+error contract, parameter layout, row-shard arithmetic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ROOT, has_gpu
+
+from sgl_amd import _lib
+from sgl_amd.dist import balanced_bounds, piece_bounds
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "sgl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int64_t|int|void|const char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 25, names
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/sgl_hip.h but not exported by libsgl_hip.so"
+    assert sorted(_lib.PROTOTYPES) == names, (sorted(set(names) ^ set(_lib.PROTOTYPES)))
+    assert _lib.lib().sgl_version() >= 100
+    assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
+
+
+def test_device_count_never_aborts():
+    assert _lib.device_count() >= 0
+
+
+def test_tuning_knobs():
+    _lib.set_tuning("spmm_unroll", 1)
+    assert _lib.get_tuning("spmm_unroll") == 1
+    _lib.set_tuning("spmm_unroll", 0)
+    with pytest.raises(_lib.SglHipError):
+        _lib.set_tuning("no_such_knob", 1)
+
+
+def build_plan(rowptr, item_nnz, long_row_nnz):
+    lib = _lib.lib()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    h = ctypes.c_void_p()
+    _lib.check(lib.sgl_plan_build(ctypes.byref(h), rp.ctypes.data_as(ctypes.c_void_p), len(rp) - 1, item_nnz, long_row_nnz))
+    counts = (ctypes.c_int64 * 8)()
+    _lib.check(lib.sgl_plan_counts(h, counts))
+    ni, npc, nl = counts[0], counts[1], counts[2]
+    items = np.zeros(2 * ni, np.int32)
+    pb, pl, pr = np.zeros(npc, np.int64), np.zeros(npc, np.int32), np.zeros(npc, np.int32)
+    lr, lf = np.zeros(nl, np.int32), np.zeros(nl + 1, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(lib.sgl_plan_export(h, p(items), p(pb), p(pl), p(pr), p(lr), p(lf)))
+    lib.sgl_plan_destroy(h)
+    return items.reshape(-1, 2), pb, pl, pr, lr, lf, list(counts)
+
+
+@pytest.mark.parametrize("seed,item_nnz,long_nnz", [(0, 64, 100), (1, 512, 2048), (2, 16, -1), (3, 1, 3)])
+def test_plan_partitions_every_row_exactly_once(seed, item_nnz, long_nnz):
+    rng = np.random.default_rng(seed)
+    n = 3000
+    deg = np.minimum(rng.lognormal(1.5, 1.4, n).astype(np.int64), 5000)
+    deg[rng.integers(0, n, 200)] = 0            # empty rows
+    deg[17] = 7001                               # a very long row
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    items, pb, pl, pr, lr, lf, counts = build_plan(rowptr, item_nnz, long_nnz)
+    covered = np.zeros(n, np.int32)
+    for b, e in items:
+        assert 0 <= b < e <= n and e - b <= 63
+        covered[b:e] += 1
+        nnz = rowptr[e] - rowptr[b]
+        # an item closes as soon as it reaches item_nnz, so it never exceeds item_nnz + one row
+        assert nnz < max(item_nnz, 1) + deg[b:e].max() + 1
+        if long_nnz > 0:
+            assert deg[b:e].max() <= long_nnz
+    if long_nnz > 0:
+        assert len(lr) == int((deg > long_nnz).sum())
+        for k, r in enumerate(lr):
+            covered[r] += 1
+            ps = range(lf[k], lf[k + 1])
+            assert all(pr[q] == r for q in ps)
+            assert pb[lf[k]] == rowptr[r] and pb[lf[k + 1] - 1] + pl[lf[k + 1] - 1] == rowptr[r + 1]
+            for q in ps:
+                assert 0 < pl[q] <= long_nnz
+                if q + 1 < lf[k + 1]:
+                    assert pb[q] + pl[q] == pb[q + 1]
+    else:
+        assert len(lr) == 0 and len(pb) == 0
+    assert (covered == 1).all()
+    assert counts[0] == len(items) and counts[5] == n
+
+
+def test_plan_rejects_bad_rowptr():
+    lib = _lib.lib()
+    rp = np.array([0, 5, 3], dtype=np.int64)
+    h = ctypes.c_void_p()
+    rc = lib.sgl_plan_build(ctypes.byref(h), rp.ctypes.data_as(ctypes.c_void_p), 2, 0, 0)
+    assert rc != 0 and "decrease" in _lib.last_error()
+
+
+def test_plan_empty_matrix():
+    items, pb, *_ = build_plan(np.zeros(1, np.int64), 0, 0)
+    assert len(items) == 0 and len(pb) == 0
+
+
+# ---- error contract (tests/golden/g5_errors.json, recorded from the reference) --------------------------
+def _raises_like(case, fn):
+    if case["raised"] is None:
+        r = fn()
+        assert type(r).__name__ == case["returned_type"] and str(r) == case["returned_msg"]
+    else:
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == case["raised"], (type(ei.value).__name__, case)
+        assert str(ei.value) == case["msg"]
+
+
+def test_error_contract_cpu(goldens):
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    from sgl_amd.operators.message_op import (IterateLearnableWeightedMessageOp, LearnableWeightedMessageOp,
+                                              MeanMessageOp, SimpleWeightedMessageOp)
+    g5 = goldens.json("g5_errors")
+    x = np.zeros((64, 4), np.float32)
+    g = goldens.graph("sym64")
+    _raises_like(g5["propagate_dense_adj"], lambda: LaplacianGraphOp(2).propagate(g.toarray(), x))
+    _raises_like(g5["ppr_dense_adj"], lambda: PprGraphOp(2).propagate(np.zeros((3, 3)), x))
+    _raises_like(g5["aggregate_not_list"], lambda: MeanMessageOp(0, 2).aggregate(torch.zeros(2, 2)))
+    _raises_like(g5["aggregate_not_tensor"], lambda: MeanMessageOp(0, 2).aggregate([np.zeros((2, 2)), np.zeros((2, 2))]))
+    _raises_like(g5["simple_weighted_bad_type"], lambda: SimpleWeightedMessageOp(0, 2, "nope", 0.5))
+    _raises_like(g5["simple_weighted_alpha_int"], lambda: SimpleWeightedMessageOp(0, 2, "alpha", 1))
+    _raises_like(g5["simple_weighted_alpha_range"], lambda: SimpleWeightedMessageOp(0, 2, "alpha", 1.5))
+    _raises_like(g5["simple_weighted_nargs"], lambda: SimpleWeightedMessageOp(0, 2, "alpha"))
+    _raises_like(g5["simple_weighted_hand_bad"], lambda: SimpleWeightedMessageOp(0, 2, "hand_crafted", 3))
+    _raises_like(g5["learnable_bad_type"], lambda: LearnableWeightedMessageOp(0, 2, "nope", 1))
+    _raises_like(g5["learnable_simple_nargs"], lambda: LearnableWeightedMessageOp(0, 2, "simple"))
+    _raises_like(g5["learnable_jk_nargs"], lambda: LearnableWeightedMessageOp(0, 2, "jk", 3))
+    _raises_like(g5["iterate_bad_type"], lambda: IterateLearnableWeightedMessageOp(0, 2, "nope", 4))
+    _raises_like(g5["iterate_nargs"], lambda: IterateLearnableWeightedMessageOp(0, 2, "recursive"))
+
+
+def test_aggr_type_strings():
+    from sgl_amd.operators import message_op as m
+    assert m.LastMessageOp().aggr_type == "last"
+    assert m.ConcatMessageOp(0, 2).aggr_type == "concat"
+    assert m.MeanMessageOp(0, 2).aggr_type == "mean"
+    assert m.SumMessageOp(0, 2).aggr_type == "sum"
+    assert m.MaxMessageOp(0, 2).aggr_type == "max"
+    assert m.MinMessageOp(0, 2).aggr_type == "min"
+    assert m.SimpleWeightedMessageOp(0, 2, "alpha", 0.5).aggr_type == "simple_weighted"
+    assert m.LearnableWeightedMessageOp(0, 2, "gate", 4).aggr_type == "learnable_weighted"
+    assert m.IterateLearnableWeightedMessageOp(0, 2, "recursive", 4).aggr_type == "iterate_learnable_weighted"
+    assert m.ProjectedConcatMessageOp(0, 2, 4, 8, 2).aggr_type == "proj_concat"
+    assert m.OverSmoothDistanceWeightedOp().aggr_type == "over_smooth_dis_weighted"
+
+
+def test_alpha_weights_bit_equal_to_reference_recurrence():
+    from sgl_amd.operators.message_op import SimpleWeightedMessageOp
+    for a in (0.85, 0.1, 0.5, 1.0, 0.0):
+        for (s, e, n) in ((0, 5, 5), (1, 5, 5), (2, 4, 11)):
+            w = SimpleWeightedMessageOp(s, e, "alpha", a).weights(n).numpy()
+            assert np.array_equal(w, oracle.alpha_weights(a, n, s, e))
+
+
+@pytest.mark.parametrize("kind", ["simple", "simple_allow_neg", "gate", "ori_ref", "jk"])
+def test_learnable_hop_weights_match_reference(goldens, kind):
+    """the gate-score decomposition (no repeat/hstack temporaries) reproduces the reference weights,
+    including the .view(-1, H) pairing of 'ori_ref' / 'jk' -- pure torch, runs on CPU"""
+    from sgl_amd.operators.message_op import LearnableWeightedMessageOp
+    g3 = goldens.npz("g3_agg")
+    feats = [torch.from_numpy(g3[f"feat{j}"]) for j in range(5)]
+    args = {"simple": (4,), "simple_allow_neg": (4,), "gate": (12,), "ori_ref": (12,), "jk": (4, 12)}[kind]
+    for (s, e) in ((0, 5), (1, 5)):
+        tag = f"learnable|{kind}|{s}_{e}"
+        op = LearnableWeightedMessageOp(s, e, kind, *args)
+        sd = {k[len(tag) + 7:]: torch.from_numpy(v) for k, v in g3.items() if k.startswith(tag + "|param|")}
+        op.load_state_dict(sd)
+        w = op.hop_weights(feats).detach().numpy()
+        if kind in ("simple", "simple_allow_neg"):
+            ref = oracle.learnable_weights([f.numpy() for f in feats], s, e, kind, param=list(sd.values())[0].numpy())
+        else:
+            ref = oracle.learnable_weights([f.numpy() for f in feats], s, e, kind,
+                                           weight=sd["_LearnableWeightedMessageOp__learnable_weight.weight"].numpy(),
+                                           bias=sd["_LearnableWeightedMessageOp__learnable_weight.bias"].numpy())
+        assert w.shape == ref.shape
+        assert np.allclose(w, ref, rtol=1e-5, atol=1e-6), np.abs(w - ref).max()
+
+
+def test_model_state_dicts_interchange_with_reference(goldens):
+    from sgl_amd.models import homo
+    g4 = goldens.npz("g4_models")
+    K, d, C = 3, 16, 5
+    ctor = {"SGC": (K, d, C), "SSGC": (K, d, C), "SIGN": (K, d, C, 32, 2), "GBP": (K, d, C, 32, 2),
+            "GAMLP": (K, d, C, 32, 2), "GAMLPRecursive": (K, d, C, 32, 2), "NAFS": (K, d, C),
+            "PASCA_V3": (K, 2, d, C, 32, 3)}
+    for name, args in ctor.items():
+        model = getattr(homo, name)(*args)
+        ref_keys = sorted(k.split("|param|")[1] for k in g4 if k.startswith(name + "|param|"))
+        assert sorted(model.state_dict().keys()) == ref_keys, name
+        model.load_state_dict({k.split("|param|")[1]: torch.from_numpy(v) for k, v in g4.items()
+                               if k.startswith(name + "|param|")})
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_hot_path_fails_loudly_without_gpu(goldens):
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    from sgl_amd.operators.message_op import MeanMessageOp
+    g = goldens.graph("sym64")
+    with pytest.raises(_lib.SglHipError):
+        LaplacianGraphOp(2).propagate(g, np.zeros((64, 4), np.float32))
+    with pytest.raises(_lib.SglHipError):
+        MeanMessageOp(0, 2).aggregate([torch.zeros(4, 4), torch.zeros(4, 4)])
+
+
+def test_sgl_amd_never_imports_the_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "sgl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+# ---- row sharding arithmetic -----------------------------------------------------------------------------
+def test_balanced_bounds_properties():
+    rng = np.random.default_rng(0)
+    deg = rng.lognormal(2.0, 1.3, 5000).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    for parts in (1, 2, 3, 8):
+        b = balanced_bounds(rowptr, parts)
+        assert b[0] == 0 and b[-1] == 5000 and (np.diff(b) >= 0).all() and len(b) == parts + 1
+        nnz = np.diff(rowptr[b])
+        assert nnz.max() <= rowptr[-1] / parts + deg.max() + 5000 / parts + 1
+    pb = piece_bounds(rowptr, 1000, 3000, 4)
+    assert pb[0] == 1000 and pb[-1] == 3000 and (np.diff(pb) >= 0).all()
+    # degenerate: more parts than rows
+    b = balanced_bounds(np.array([0, 2, 4], dtype=np.int64), 8)
+    assert b[0] == 0 and b[-1] == 2 and (np.diff(b) >= 0).all()
