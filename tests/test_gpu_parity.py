@@ -44,8 +44,8 @@ def long_row_graph(n=1500, seed=5):
     """power-law rows plus three huge rows and some empty ones (canonical CSR, not symmetric)"""
     rng = np.random.default_rng(seed)
     deg = np.minimum(rng.lognormal(1.2, 1.0, n).astype(np.int64), 200)
-    deg[[3, 700, n - 1]] = [1400, 900, 1499]
     deg[rng.integers(0, n, 60)] = 0
+    deg[[3, 700, n - 1]] = [1400, 900, 1499]
     rows, cols = [], []
     for i in range(n):
         c = np.sort(rng.choice(n, int(deg[i]), replace=False))
@@ -91,8 +91,9 @@ def test_spmm_fast_within_tolerance(goldens, cuda, gname):
     for d in D_LIST:
         x = hash_matrix(n, d, seed=d + 1)
         ref = oracle.oracle_spmm(ptr, col, val, x)
+        scale = oracle.oracle_spmm(ptr, col, np.abs(val), np.abs(x))      # |A| . |X|: see oracle.parity_report
         y = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
-        rep = oracle.parity_report(y, ref, TOL)
+        rep = oracle.parity_report(y, ref, TOL, scale=scale)
         assert rep["ok"], (d, rep)
         exact += rep["bit_equal"]
     print(f"fast mode: {exact}/{len(D_LIST)} widths bit-equal on {gname}")
@@ -105,6 +106,7 @@ def test_spmm_long_rows_empty_rows_and_splitting(cuda, strict):
     for d in (4, 100, 128, 37):
         x = hash_matrix(n, d, seed=11)
         ref = oracle.oracle_spmm(a.indptr, a.indices, a.data, x)
+        scale = oracle.oracle_spmm(a.indptr, a.indices, np.abs(a.data), np.abs(x))
         for item_nnz, long_nnz in ((512, 2048), (64, 256), (8, 100), (100000, 64)):
             csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, item_nnz=item_nnz, long_row_nnz=long_nnz)
             info = csr.info()
@@ -116,7 +118,7 @@ def test_spmm_long_rows_empty_rows_and_splitting(cuda, strict):
             if strict:
                 assert np.array_equal(y, ref), (d, item_nnz, long_nnz, oracle.parity_report(y, ref))
             else:
-                rep = oracle.parity_report(y, ref, TOL)
+                rep = oracle.parity_report(y, ref, TOL, scale=scale)
                 assert rep["ok"], (d, item_nnz, long_nnz, rep)
             # deterministic: same bits on a second run (no float atomics)
             y2 = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
@@ -249,6 +251,8 @@ def test_propagate_matches_reference_goldens(goldens, cuda):
     for key, m in meta.items():
         g = goldens.graph(m["graph"])
         x = hash_matrix(g.shape[0], m["d"], seed=m["seed"], order=m["order"])
+        norm = oracle.sym_norm_csr(g.indptr, g.indices, g.data, g.shape[0], m["r"], m["alpha"])
+        scales = oracle.propagate((norm[0], norm[1], np.abs(norm[2])), np.abs(x), m["K"])
         for strict in (True, False):
             mk = (lambda K: LaplacianGraphOp(K, r=m["r"], strict_order=strict)) if m["kind"] == "lap" else \
                  (lambda K: PprGraphOp(K, r=m["r"], alpha=m["alpha"], strict_order=strict))
@@ -257,7 +261,7 @@ def test_propagate_matches_reference_goldens(goldens, cuda):
             assert np.array_equal(hops[0].cpu().numpy(), x)
             check = range(1, m["K"] + 1) if m["keep"] == "all" else [m["K"]]
             for h in check:
-                rep = oracle.parity_report(hops[h].cpu().numpy(), g2[f"{key}|h{h}"], TOL)
+                rep = oracle.parity_report(hops[h].cpu().numpy(), g2[f"{key}|h{h}"], TOL, scale=scales[h])
                 assert rep["ok"], (key, strict, h, rep)
                 if strict:
                     n_total += 1
@@ -383,12 +387,14 @@ def test_learnable_aggregators_forward_and_backward(goldens, cuda, kind):
         assert rep["ok"], (tag, rep)
         (y * gout).sum().backward()
         for name, p in op.named_parameters():
-            rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), g3[tag + "|grad|" + name].reshape(1, -1), 1e-4)
+            gref = g3[tag + "|grad|" + name].reshape(1, -1)
+            # a single-element gradient (the gate bias) is one long sum of cancelling terms: 2e-3; vectors: 1e-4
+            rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), gref, 2e-3 if gref.size == 1 else 1e-4, rowwise=False)
             assert rep["ok"], (tag, name, rep)
         for j, f in enumerate(feats):
             got = (f.grad if f.grad is not None else torch.zeros_like(f)).cpu().numpy()
-            rep = oracle.parity_report(got, g3[tag + f"|dfeat{j}"], 1e-4)
-            assert rep["ok"] or not g3[tag + f"|dfeat{j}"].any() and not got.any(), (tag, j, rep)
+            rep = oracle.parity_report(got, g3[tag + f"|dfeat{j}"], 1e-4, rowwise=False)
+            assert rep["ok"], (tag, j, rep)
 
 
 def test_iterate_and_projected_concat(goldens, cuda):
@@ -404,10 +410,11 @@ def test_iterate_and_projected_concat(goldens, cuda):
     assert rep["ok"], rep
     (y * gout).sum().backward()
     for name, p in op.named_parameters():
-        rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), g3["iterate|0_5|grad|" + name].reshape(1, -1), 1e-4)
+        gref = g3["iterate|0_5|grad|" + name].reshape(1, -1)
+        rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), gref, 2e-3 if gref.size == 1 else 1e-4, rowwise=False)
         assert rep["ok"], (name, rep)
     for j, f in enumerate(feats):
-        rep = oracle.parity_report(f.grad.cpu().numpy(), g3[f"iterate|0_5|dfeat{j}"], 1e-4)
+        rep = oracle.parity_report(f.grad.cpu().numpy(), g3[f"iterate|0_5|dfeat{j}"], 1e-4, rowwise=False)
         assert rep["ok"], (j, rep)
     pc = ProjectedConcatMessageOp(0, 5, 12, 8, 2)
     pc.load_state_dict({k[len("proj_concat|0_5|param|"):]: torch.from_numpy(v) for k, v in g3.items() if k.startswith("proj_concat|0_5|param|")})

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Experiment harness for the SpMM kernel on the GPU box (not part of the product or of bench.py).
+
+    python tools/sweep_spmm.py --workload S1_products --exp knobs,plan,colblock,relabel,pad
+
+Prints one line per configuration: `EXP <name> <key=value ...> ms_per_hop=<t> frac=<algorithmic roofline fraction>`.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sgl_amd import _lib, synthetic  # noqa: E402
+from sgl_amd import device as dev  # noqa: E402
+
+
+def time_hops(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="S1_products")
+    ap.add_argument("--exp", default="knobs,plan,colblock,relabel,pad")
+    ap.add_argument("--k", type=int, default=3)
+    a = ap.parse_args()
+    exps = set(a.exp.split(","))
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    wl = synthetic.WORKLOADS[a.workload]
+    n, d, K = wl["n"], wl["d"], a.k
+    a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=0, device=device)
+    rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)
+    del a_ptr, a_col, a_val
+    nnz = col.numel()
+    x0 = synthetic.features_torch(n, d, seed=0, device=device)
+    alg = nnz * d * 4 + nnz * 8 + (n + 1) * 4 + n * d * 4
+    bufs = [torch.empty_like(x0) for _ in range(2)]
+
+    def report(name, ms_total, hops, **kv):
+        ms = ms_total / hops
+        frac = alg / (ms * 1e-3) / 8e12
+        print(f"EXP {name} " + " ".join(f"{k}={v}" for k, v in kv.items()) + f" ms_per_hop={ms:.3f} frac={frac:.3f}", flush=True)
+
+    def chain(csr, xin=x0, outs=bufs):
+        def f():
+            cur = xin
+            for h in range(K):
+                out = outs[h % 2]
+                csr.spmm(cur, out=out)
+                cur = out
+        return f
+
+    knobs = ("spmm_unroll", "spmm_nt", "spmm_group", "spmm_waves", "spmm_xcd_remap")
+    saved = {k: _lib.get_tuning(k) for k in knobs}
+
+    def set_knobs(**kw):
+        for k in knobs:
+            _lib.set_tuning(k, kw.get(k, saved[k]))
+
+    base = dev.DeviceCSR(rowptr, col, val, (n, n))
+    report("base", time_hops(chain(base)), K, **base.info())
+    strict = dev.DeviceCSR(rowptr, col, val, (n, n), strict=True)
+    report("strict", time_hops(chain(strict)), K)
+    del strict
+
+    if "knobs" in exps:
+        for unroll in (0, 1, 2):
+            for nt in (0, 1):
+                set_knobs(spmm_unroll=unroll, spmm_nt=nt)
+                report("knobs", time_hops(chain(base)), K, unroll=unroll, nt=nt)
+        for group in (32, 64):
+            set_knobs(spmm_group=group)
+            report("knobs", time_hops(chain(base)), K, group=group)
+        for waves in (1, 2, 4):
+            set_knobs(spmm_waves=waves)
+            report("knobs", time_hops(chain(base)), K, waves=waves)
+        for remap in (0, 1):
+            set_knobs(spmm_xcd_remap=remap)
+            report("knobs", time_hops(chain(base)), K, xcd_remap=remap)
+        set_knobs()
+
+    if "plan" in exps:
+        for item_nnz in (128, 256, 512, 1024, 2048, 4096):
+            for long_nnz in (512, 2048, 8192):
+                c = dev.DeviceCSR(rowptr, col, val, (n, n), item_nnz=item_nnz, long_row_nnz=long_nnz)
+                report("plan", time_hops(chain(c)), K, item_nnz=item_nnz, long_nnz=long_nnz, items=c.info()["n_items"],
+                       pieces=c.info()["n_pieces"])
+                del c
+
+    deg = rowptr[1:] - rowptr[:-1]
+    if "colblock" in exps or "relabel" in exps:
+        rows = torch.repeat_interleave(torch.arange(n, device=device), deg)
+
+    def col_blocks(rp, cc, vv, rws, edges):
+        out = []
+        for c0, c1 in zip(edges[:-1], edges[1:]):
+            m = (cc >= c0) & (cc < c1)
+            cnt = torch.bincount(rws[m], minlength=n)
+            p = torch.zeros(n + 1, dtype=torch.int64, device=device)
+            p[1:] = torch.cumsum(cnt, 0)
+            out.append(dev.DeviceCSR(p, cc[m].contiguous(), vv[m].contiguous(), (n, n)))
+        return out
+
+    def chain_blocks(blocks, xin):
+        def f():
+            cur = xin
+            for h in range(K):
+                out = bufs[h % 2]
+                for b, c in enumerate(blocks):
+                    c.spmm(cur, out=out, accumulate=(b > 0))
+                cur = out
+        return f
+
+    if "colblock" in exps:
+        for B in (2, 3, 4, 6, 8):
+            edges = [int(round(i * n / B)) for i in range(B + 1)]
+            blocks = col_blocks(rowptr, col, val, rows, edges)
+            report("colblock", time_hops(chain_blocks(blocks, x0)), K, B=B)
+            del blocks
+
+    if "relabel" in exps:
+        # relabel nodes by descending degree: hot rows of X become one contiguous, cache-resident slab
+        order = torch.argsort(deg, descending=True, stable=True)       # order[new] = old
+        new_id = torch.empty_like(order)
+        new_id[order] = torch.arange(n, device=device)
+        key = new_id[rows] * n + new_id[col.long()]
+        key, perm = torch.sort(key)
+        r2 = key // n
+        c2 = (key % n).to(torch.int32)
+        v2 = val[perm]
+        del key, perm
+        p2 = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        p2[1:] = torch.cumsum(torch.bincount(r2, minlength=n), 0)
+        x2 = x0[order].contiguous()
+        c = dev.DeviceCSR(p2, c2, v2, (n, n))
+        report("relabel", time_hops(chain(c, xin=x2)), K, order="degree_desc")
+        for B, hot_frac in ((2, 0.1), (2, 0.25), (3, 0.2), (4, 0.25)):
+            # first block = the hottest rows (what fits the 256 MiB Infinity Cache), rest equal width
+            hot = int(n * hot_frac)
+            edges = [0, hot] + [hot + int(round(i * (n - hot) / (B - 1))) for i in range(1, B)]
+            blocks = col_blocks(p2, c2, v2, r2, edges)
+            report("relabel+colblock", time_hops(chain_blocks(blocks, x2)), K, B=B, hot_frac=hot_frac)
+            del blocks
+        del c, p2, c2, v2, r2, x2
+
+    if "pad" in exps:
+        # rows padded to 128 floats (512 B, line aligned) instead of the native 400 B
+        xp = torch.zeros((n, 128), device=device)
+        xp[:, :d] = x0
+        outs = [torch.zeros((n, 128), device=device) for _ in range(2)]
+
+        def f():
+            cur = xp[:, :d]
+            for h in range(K):
+                out = outs[h % 2][:, :d]
+                base.spmm(cur, out=out)
+                cur = out
+        report("pad", time_hops(f), K, ld=128, d=d)
+
+        def g():
+            cur = xp
+            for h in range(K):
+                out = outs[h % 2]
+                base.spmm(cur, out=out)
+                cur = out
+        ms = time_hops(g)
+        alg128 = nnz * 128 * 4 + nnz * 8 + (n + 1) * 4 + n * 128 * 4
+        print(f"EXP d128 ms_per_hop={ms / K:.3f} frac={alg128 / (ms / K * 1e-3) / 8e12:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
