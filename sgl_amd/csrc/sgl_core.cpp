@@ -22,7 +22,7 @@ const char *get_error() { return g_err.c_str(); }
 static std::mutex g_tune_mu;
 static std::map<std::string, int64_t> &tune_map() {
     static std::map<std::string, int64_t> m = {
-        {"spmm_unroll", 0},      // 0 = default (8); 2/4/8: gathers in flight per lane
+        {"spmm_unroll", 0},      // 0 = auto; 1 / 3 / 2 = low / mid / high number of gathers in flight per lane
         {"spmm_nt", 0},          // 1 = non-temporal loads for the CSR stream / stores of Y
         {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
         {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)

@@ -426,11 +426,14 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
                       int accumulate, hipStream_t st) {
     const int lanes = d / vec;
     const bool strict = (h->flags & SGL_CSR_STRICT_ORDER) != 0;
+    // Lane layout (measured on MI355X, profiles/r01_sweep*.log): rows wider than 64 floats are gathered one
+    // non-zero per step by the whole wavefront (R = 1): as fast as two half-wave slots and it keeps the reference's
+    // sequential fmaf order; narrower rows pack R = 64/GROUP non-zeros per step or the lanes would idle.
     int group = 64, nch = 1;
     if (lanes > 64) {
         const int need = (lanes + 63) / 64;
         nch = need <= 2 ? need : 4;
-    } else if (!strict) {
+    } else if (!strict && lanes <= 16) {
         group = 8;
         while (group < lanes) group <<= 1;
     }
@@ -438,10 +441,12 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     if (forced == 8 || forced == 16 || forced == 32 || forced == 64) {
         if (nch == 1 && forced >= lanes) group = (int)forced;
     }
-    int ulevel = 1;
+    // gathers in flight per lane: 16 for the one-row-per-step layout, 8 for the packed ones (0 = this default)
+    int ulevel = (group == 64 && nch == 1) ? 2 : 1;
     const int64_t un = sgl::tuning("spmm_unroll", 0);
-    if (un == 1) ulevel = 0;   // half the default number of gathers in flight
-    if (un == 2) ulevel = 2;   // double
+    if (un == 1) ulevel = 0;
+    if (un == 2) ulevel = 2;
+    if (un == 3) ulevel = 1;
     const bool nt = sgl::tuning("spmm_nt", 0) != 0;
     int waves = (int)sgl::tuning("spmm_waves", 0);
     if (waves != 1 && waves != 2 && waves != 4) waves = 4;

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["balanced_bounds", "piece_bounds", "ShardedPropagator"]
+__all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "device_piece_spmms", "ShardedPropagator"]
 
 
 def balanced_bounds(rowptr, parts):
@@ -36,6 +36,30 @@ def piece_bounds(rowptr, lo, hi, pieces):
     rowptr = np.asarray(rowptr, dtype=np.int64)
     local = rowptr[lo:hi + 1] - rowptr[lo]
     return balanced_bounds(local, pieces) + lo
+
+
+def all_piece_bounds(rowptr_host, world, pieces):
+    """[world, pieces+1] absolute row boundaries: rank blocks balanced by non-zeros, each cut into `pieces`"""
+    bounds = balanced_bounds(rowptr_host, world)
+    return np.stack([piece_bounds(rowptr_host, int(bounds[g]), int(bounds[g + 1]), pieces) for g in range(world)])
+
+
+def device_piece_spmms(rowptr, col, val, n_cols, my_bounds, rowptr_host=None, strict=False):
+    """One DeviceCSR (rectangular: rows of the piece x all columns) per local row piece, as `f(x_full, out)`
+    callables for ShardedPropagator.  rowptr/col/val: the FULL normalised adjacency on this rank's device (only
+    views of the local rows are kept alive); my_bounds: this rank's row of all_piece_bounds()."""
+    from .device import DeviceCSR
+    if rowptr_host is None:
+        rowptr_host = rowptr.cpu().numpy()
+    fns, handles = [], []
+    for p in range(len(my_bounds) - 1):
+        r0, r1 = int(my_bounds[p]), int(my_bounds[p + 1])
+        nb, ne = int(rowptr_host[r0]), int(rowptr_host[r1])
+        rp_local = (rowptr[r0:r1 + 1] - rowptr[r0]).contiguous()
+        h = DeviceCSR(rp_local, col[nb:ne].contiguous(), val[nb:ne].contiguous(), (r1 - r0, n_cols), strict=strict)
+        handles.append(h)
+        fns.append(lambda x, out, h=h: h.spmm(x, out=out))
+    return fns, handles
 
 
 class ShardedPropagator:

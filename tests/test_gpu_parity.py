@@ -472,6 +472,33 @@ def test_models_match_reference_goldens(goldens, cuda):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
+    """every virtual rank's row pieces (rectangular device CSRs) reproduce the rows of the single-matrix result;
+    world = 1 ShardedPropagator == plain k-step propagation (the exchange itself is covered by the gloo tests)"""
+    from sgl_amd.dist import ShardedPropagator, all_piece_bounds, device_piece_spmms
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    rp = torch.from_numpy(ptr.astype(np.int64)).to(cuda)
+    cc = torch.from_numpy(col.astype(np.int32)).to(cuda)
+    vv = torch.from_numpy(val).to(cuda)
+    x = torch.from_numpy(hash_matrix(n, 100, seed=6)).to(cuda)
+    ref = oracle.propagate((ptr, col, val), x.cpu().numpy(), 3)
+    for world, pieces in ((1, 4), (3, 2), (8, 4)):
+        pb = all_piece_bounds(ptr, world, pieces)
+        assert pb[0, 0] == 0 and pb[-1, -1] == n and (pb[1:, 0] == pb[:-1, -1]).all()
+        y = torch.empty_like(x)
+        for g in range(world):
+            fns, _h = device_piece_spmms(rp, cc, vv, n, pb[g], strict=True)
+            for p, f in enumerate(fns):
+                r0, r1 = int(pb[g, p]), int(pb[g, p + 1])
+                if r1 > r0:
+                    f(x, y[r0:r1])
+        assert np.array_equal(y.cpu().numpy(), ref[1])
+    fns, _h = device_piece_spmms(rp, cc, vv, n, all_piece_bounds(ptr, 1, 4)[0], strict=True)
+    hops = ShardedPropagator(fns, all_piece_bounds(ptr, 1, 4), 0, 1, n).propagate(x, 3)
+    for h in range(4):
+        assert np.array_equal(hops[h].cpu().numpy(), ref[h])
+
+
 # ---- full-size, size-independent properties ------------------------------------------------------------------
 def test_products_scale_properties(cuda):
     """ogbn-products-shaped graph (N = 2.45 M, nnz ~ 126 M, d = 100): sampled rows against the oracle, linearity,

@@ -161,6 +161,78 @@ def main():
             del blocks
         del c, p2, c2, v2, r2, x2
 
+    if "dsweep" in exps:
+        # time per hop vs feature width on the same graph: separates per-line from per-gather cost
+        for dd in (16, 32, 64, 96, 100, 128, 192, 256):
+            xs = torch.randn((n, dd), device=device)
+            outs = [torch.empty_like(xs) for _ in range(2)]
+            for unroll in (0, 2):
+                set_knobs(spmm_unroll=unroll)
+                ms = time_hops(chain(base, xin=xs, outs=outs))
+                algd = nnz * dd * 4 + nnz * 8 + (n + 1) * 4 + n * dd * 4
+                print(f"EXP dsweep d={dd} unroll={unroll} ms_per_hop={ms / K:.3f} frac={algd / (ms / K * 1e-3) / 8e12:.3f} "
+                      f"Ggather_per_s={nnz / (ms / K * 1e-3) / 1e9:.2f}", flush=True)
+            del xs, outs
+        set_knobs()
+
+    if "wsweep" in exps:
+        # uniform-random gathers from a table of T rows (d floats each): where does the memory system saturate?
+        deg_u, rows_u = 48, 1 << 21
+        for dd in (100, 128, 32):
+            for T in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23):
+                g = torch.Generator(device=device)
+                g.manual_seed(1)
+                cc = torch.randint(0, T, (rows_u * deg_u,), generator=g, device=device, dtype=torch.int32)
+                cc = cc.view(rows_u, deg_u).sort(dim=1).values.reshape(-1).contiguous()
+                pp = torch.arange(0, rows_u + 1, device=device, dtype=torch.int64) * deg_u
+                vv = torch.ones(rows_u * deg_u, device=device)
+                cu = dev.DeviceCSR(pp, cc, vv, (rows_u, T))
+                xt = torch.randn((T, dd), device=device)
+                yo = torch.empty((rows_u, dd), device=device)
+                for unroll in (0, 2):
+                    set_knobs(spmm_unroll=unroll)
+                    ms = time_hops(lambda: cu.spmm(xt, out=yo), reps=5, warm=2)
+                    print(f"EXP wsweep d={dd} table_MB={T * dd * 4 / 2**20:.1f} unroll={unroll} ms={ms:.3f} "
+                          f"Ggather_per_s={rows_u * deg_u / (ms * 1e-3) / 1e9:.2f} "
+                          f"gathered_TBps={rows_u * deg_u * dd * 4 / (ms * 1e-3) / 1e12:.2f}", flush=True)
+                del cu, cc, pp, vv, xt, yo
+        set_knobs()
+
+    if "relabel2" in exps:
+        rows2 = torch.repeat_interleave(torch.arange(n, device=device), deg)
+        order = torch.argsort(deg, descending=True, stable=True)
+        new_id = torch.empty_like(order)
+        new_id[order] = torch.arange(n, device=device)
+        # relabel COLUMNS only (X rows sorted by hotness) but keep the original row order of the matrix, so the
+        # work distribution is unchanged and only the locality of the gathered table differs
+        c2 = new_id[col.long()].to(torch.int32)
+        key = rows2 * n + c2.long()
+        key, perm = torch.sort(key)
+        c2 = (key % n).to(torch.int32)
+        v2 = val[perm]
+        del key, perm, rows2
+        x2 = x0[order].contiguous()
+        c = dev.DeviceCSR(rowptr, c2, v2, (n, n))
+        for remap in (0, 1):
+            set_knobs(spmm_xcd_remap=remap)
+            ms = time_hops(lambda: c.spmm(x2, out=bufs[0]))
+            print(f"EXP relabel2 hot_columns_first xcd_remap={remap} ms_per_hop={ms:.3f}", flush=True)
+        set_knobs()
+        del c, c2, v2, x2
+
+    if "uns" in exps:
+        # unroll x group per width (default-selection table)
+        for dd in (8, 16, 32, 48, 64, 100, 128, 256, 500):
+            xs = torch.randn((n, dd), device=device)
+            outs = [torch.empty_like(xs) for _ in range(2)]
+            for group in (0, 64):
+                for unroll in (1, 0, 2):
+                    set_knobs(spmm_unroll=unroll, spmm_group=group)
+                    ms = time_hops(lambda: base.spmm(xs, out=outs[0]), reps=5, warm=1)
+                    print(f"EXP uns d={dd} group={group} unroll={unroll} ms_per_hop={ms:.3f}", flush=True)
+            del xs, outs
+        set_knobs()
+
     if "pad" in exps:
         # rows padded to 128 floats (512 B, line aligned) instead of the native 400 B
         xp = torch.zeros((n, 128), device=device)
