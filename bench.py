@@ -19,6 +19,8 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
                  cores on a bounded row sample of the same workload (N=1 only)
 """
 import argparse
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work needs dmabuf IPC on this driver
 import json
 import os
 import sys

@@ -141,6 +141,21 @@ __global__ __launch_bounds__(256) void hop_wsum2d_dx_kernel(const HopsOut dx, co
     }
 }
 
+// 16-byte row accesses are legal for any d when every row pitch is a multiple of 4 floats (the vector that
+// straddles column d stays inside the row's own padding); the elements beyond d are masked out of reductions.
+template <int VEC>
+__device__ __forceinline__ typename Vt<VEC>::type load_masked(const float *p, int c, int d) {
+    typename Vt<VEC>::type v = *reinterpret_cast<const typename Vt<VEC>::type *>(p + c);
+    if constexpr (VEC == 4) {
+        if (c + 4 > d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e >= d) v[e] = 0.f;
+        }
+    }
+    return v;
+}
+
 // ---- row-wise reductions: LPR lanes cooperate on one row, 64/LPR rows per wavefront ------------------------
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
@@ -164,8 +179,8 @@ __global__ __launch_bounds__(256) void hop_rowdot_kernel(const Hops hx, const in
         float acc = 0.f;
         if (live) {
             for (int c = l * VEC; c < d; c += LPR * VEC) {
-                const V gv = *reinterpret_cast<const V *>(g + r * ldg + c);
-                const V xv = *reinterpret_cast<const V *>(hx.p[h] + r * hx.ld[h] + c);
+                const V gv = load_masked<VEC>(g + r * ldg, c, d);
+                const V xv = load_masked<VEC>(hx.p[h] + r * hx.ld[h], c, d);
                 if constexpr (VEC == 1) {
                     acc = __builtin_fmaf(gv, xv, acc);
                 } else {
@@ -196,8 +211,8 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
         float dot = 0.f, sq = 0.f;
         if (live) {
             for (int c = l * VEC; c < d; c += LPR * VEC) {
-                const V a = *reinterpret_cast<const V *>(hx.p[0] + r * hx.ld[0] + c);
-                const V b = *reinterpret_cast<const V *>(hx.p[h] + r * hx.ld[h] + c);
+                const V a = load_masked<VEC>(hx.p[0] + r * hx.ld[0], c, d);
+                const V b = load_masked<VEC>(hx.p[h] + r * hx.ld[h], c, d);
                 if constexpr (VEC == 1) {
                     dot = __builtin_fmaf(a, b, dot);
                     sq = __builtin_fmaf(b, b, sq);
@@ -231,17 +246,99 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
     }
 }
 
+// Fused NAFS: one pass over the H hop rows held in registers -> cosine scores -> softmax -> weighted sum.
+// LPR lanes per row, CH float4 chunks per lane (d <= LPR*4*CH), H <= HMAX.  Same arithmetic as the two-pass path.
+template <int LPR, int CH, int HMAX>
+__global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void nafs_fused_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+                                                         const int64_t ldo, float *__restrict__ wout, const int64_t ldw,
+                                                         const int64_t n, const int d) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    f4 x[HMAX][CH];
+    bool on[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) on[c] = live && ((c * LPR + l) * 4 < d);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
+    float score[HMAX];
+    float n0 = 0.f, run_max = -INFINITY;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        score[h] = -INFINITY;
+        if (h < n_hops) {
+            float dot = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot = __builtin_fmaf(x[0][c][e], x[h][c][e], dot);
+                    sq = __builtin_fmaf(x[h][c][e], x[h][c][e], sq);
+                }
+            dot = group_sum<LPR>(dot);
+            sq = group_sum<LPR>(sq);
+            const float nh = __fadd_rn(__fsqrt_rn(sq), 1e-10f);
+            if (h == 0) n0 = nh;
+            score[h] = __fdiv_rn(__fdiv_rn(dot, nh), n0);
+            run_max = fmaxf(run_max, score[h]);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+        if (h < n_hops) {
+            score[h] = expf(score[h] - run_max);
+            sum += score[h];
+        }
+    f4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+        if (h < n_hops) {
+            const float w = __fdiv_rn(score[h], sum);
+            if (wout && live && l == 0) wout[r * ldw + h] = w;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] = __fadd_rn(acc[c][e], __fmul_rn(w, x[h][c][e]));
+        }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (on[c]) {
+            const int col = (c * LPR + l) * 4;
+            if (col + 4 <= d) {
+                *reinterpret_cast<f4 *>(out + r * ldo + col) = acc[c];
+            } else {  // the vector straddling column d: never write past the caller's d columns
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < d) out[r * ldo + col + e] = acc[c][e];
+            }
+        }
+}
+
 // out[i,:] = X[idx[i],:]
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int64_t ldx,
-                                                          const int64_t *__restrict__ idx, const int64_t n_idx,
-                                                          float *__restrict__ out, const int64_t ldo, const int d) {
+                                                          const int64_t n_rows, const int64_t *__restrict__ idx,
+                                                          const int64_t n_idx, float *__restrict__ out,
+                                                          const int64_t ldo, const int d) {
     using V = typename Vt<VEC>::type;
     constexpr int RPB = 256 / LPR;
     const int l = threadIdx.x % LPR;
     const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
     if (i >= n_idx) return;
-    const int64_t src = idx[i];
+    int64_t src = idx[i];
+    if (src < 0) src += n_rows;                       // python-style negative index
+    if (src < 0 || src >= n_rows) __builtin_trap();   // out of range: abort the kernel loudly (like torch's assert)
     for (int c = l * VEC; c < d; c += LPR * VEC)
         *reinterpret_cast<V *>(out + i * ldo + c) = *reinterpret_cast<const V *>(x + src * ldx + c);
 }
@@ -422,17 +519,18 @@ SGL_EXPORT int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const
                                       float *const *h_dx, const int64_t *h_lddx, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: bad sizes");
     Hops hx;
-    bool vec4 = (d % 4 == 0) && (lddo % 4 == 0) && aligned_to(d_dout, 16);
-    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    bool row4 = (lddo % 4 == 0) && aligned_to(d_dout, 16);   // 16-byte row accesses possible (any d, masked tail)
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, row4);
     if (rc != SGL_OK) return rc;
+    bool vec4 = row4 && (d % 4 == 0);                          // element-wise kernels need whole vectors
     if (n == 0 || d == 0) return SGL_OK;
     SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum2d_bwd_f32: bad dOut");
     hipStream_t st = sgl::as_stream(stream);
     if (d_dw) {
         SGL_REQUIRE(lddw >= n_hops, "sgl_hop_wsum2d_bwd_f32: lddw < n_hops");
-        const int lpr = pick_lpr(d, vec4 ? 4 : 1);
+        const int lpr = pick_lpr(d, row4 ? 4 : 1);
         SGL_REQUIRE((n + (256 / lpr) - 1) / (256 / lpr) < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: too many rows");
-        if (vec4)
+        if (row4)
             launch_rowdot<4>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
         else
             launch_rowdot<1>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
@@ -511,7 +609,7 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_nafs_f32: bad sizes");
     SGL_REQUIRE(d_w_out && ldw >= n_hops, "sgl_nafs_f32: the [n, n_hops] weight buffer is required");
     Hops hx;
-    bool vec4 = (d % 4 == 0);
+    bool vec4 = true;   // 16-byte row accesses with a masked tail: needs only 4-float row pitches
     int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
     if (rc != SGL_OK) return rc;
     if (n == 0 || d == 0) return SGL_OK;
@@ -519,6 +617,28 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     const int lpr = pick_lpr(d, vec4 ? 4 : 1);
     const int64_t blocks = (n + (256 / lpr) - 1) / (256 / lpr);
     SGL_REQUIRE(blocks < INT32_MAX, "sgl_nafs_f32: too many rows");
+    // single-pass kernel: the H hop rows of a node fit in registers (H <= 16, d <= 512, 16-byte lanes)
+    const bool out_vec4 = d_out && (ldo % 4 == 0) && aligned_to(d_out, 16);
+    if (vec4 && out_vec4 && n_hops <= 16 && d <= 512 && sgl::tuning("nafs_fused", 1) != 0) {
+        const int ch = (d > lpr * 4) ? 2 : 1;
+#define SGL_NF(L, C, HM) \
+    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d)
+#define SGL_NF_H(L, C)                                 \
+    do {                                               \
+        if (n_hops <= 4) SGL_NF(L, C, 4);              \
+        else if (n_hops <= 8) SGL_NF(L, C, 8);         \
+        else SGL_NF(L, C, 16);                         \
+    } while (0)
+        if (ch == 2) SGL_NF_H(64, 2);
+        else if (lpr == 8) SGL_NF_H(8, 1);
+        else if (lpr == 16) SGL_NF_H(16, 1);
+        else if (lpr == 32) SGL_NF_H(32, 1);
+        else SGL_NF_H(64, 1);
+#undef SGL_NF_H
+#undef SGL_NF
+        SGL_LAUNCH_CHECK("sgl_nafs_f32(fused)");
+        return SGL_OK;
+    }
 #define SGL_NW(L, V) \
     hipLaunchKernelGGL((nafs_weight_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_w_out, ldw, n, (int)d)
     if (vec4) {
@@ -554,7 +674,7 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
     const int64_t blocks = (n_idx + (256 / lpr) - 1) / (256 / lpr);
     SGL_REQUIRE(blocks < INT32_MAX, "sgl_gather_rows_f32: too many rows");
 #define SGL_GR(L, V) \
-    hipLaunchKernelGGL((gather_rows_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, d_idx, n_idx, d_out, ldo, (int)d)
+    hipLaunchKernelGGL((gather_rows_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, n_idx, d_out, ldo, (int)d)
     if (vec4) {
         switch (lpr) {
             case 8: SGL_GR(8, 4); break;

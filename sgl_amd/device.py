@@ -169,11 +169,27 @@ def _check_hops(feats):
             raise ValueError("all hop matrices must have the same shape and device")
 
 
+def _widened(feats, out):
+    """For d % 4 != 0: when every hop matrix and the (freshly allocated) output are row-padded to a multiple of
+    4 floats, run element-wise kernels over the padded width so they use 16-byte lanes.  Inputs' pad columns are
+    only read, the output's pad columns belong to us."""
+    n, d = out.shape
+    dp = round_up(d, 4)
+    if d == dp or n <= 1:
+        return feats, out, d
+    ok = all(f.stride(0) % 4 == 0 and f.stride(0) >= dp and f.data_ptr() % 16 == 0 for f in list(feats) + [out])
+    if not ok:
+        return feats, out, d
+    wide = [torch.as_strided(f, (n, dp), (f.stride(0), 1), f.storage_offset()) for f in feats]
+    return wide, torch.as_strided(out, (n, dp), (out.stride(0), 1), out.storage_offset()), dp
+
+
 def hop_reduce(op, feats, weights=None):
     """sum / mean / max / min / 1-D weighted sum over the hop list -> new [n, d] tensor"""
     _check_hops(feats)
     n, d = feats[0].shape
-    out = alloc_rows(n, d, feats[0].device)
+    result = alloc_rows(n, d, feats[0].device)
+    feats, out, d = _widened(feats, result)
     ptrs, lds = _lib.hop_arrays(feats)
     w = None
     if op == _lib.SGL_REDUCE_WSUM:
@@ -183,7 +199,7 @@ def hop_reduce(op, feats, weights=None):
     with torch.cuda.device(feats[0].device):
         check(lib().sgl_hop_reduce_f32(op, len(feats), ptrs, lds, ptr(w) if w is not None else None, ptr(out), _ld(out),
                                        n, d, current_stream_ptr()), "sgl_hop_reduce_f32")
-    return out
+    return result
 
 
 def hop_concat(feats):
@@ -208,13 +224,14 @@ class _WSum2D(torch.autograd.Function):
         wd = w.detach().to(torch.float32).contiguous()
         if wd.shape != (n, len(feats_d)):
             raise ValueError("The feature list and the weight list have different lengths!")
-        out = alloc_rows(n, d, feats_d[0].device)
-        ptrs, lds = _lib.hop_arrays(feats_d)
+        result = alloc_rows(n, d, feats_d[0].device)
+        wide, out, dw_ = _widened(feats_d, result)
+        ptrs, lds = _lib.hop_arrays(wide)
         with torch.cuda.device(out.device):
-            check(lib().sgl_hop_wsum2d_f32(len(feats_d), ptrs, lds, ptr(wd), _ld(wd), ptr(out), _ld(out), n, d,
+            check(lib().sgl_hop_wsum2d_f32(len(feats_d), ptrs, lds, ptr(wd), _ld(wd), ptr(out), _ld(out), n, dw_,
                                            current_stream_ptr()), "sgl_hop_wsum2d_f32")
         ctx.save_for_backward(wd, *feats_d)
-        return out
+        return result
 
     @staticmethod
     def backward(ctx, gout):
@@ -296,15 +313,20 @@ def nafs_aggregate(feats, return_weights=False):
 def gather_rows(x, idx):
     """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60)"""
     _check_mat(x, "x")
-    if not torch.is_tensor(idx):
-        idx = torch.as_tensor(np.asarray(idx) if not isinstance(idx, range) else np.arange(idx.start, idx.stop, idx.step))
-    idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
     n_rows, d = x.shape
-    if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
-        neg = idx < 0
-        if bool((idx[neg] < -n_rows).any()) or int(idx.max()) >= n_rows:
+    if not (torch.is_tensor(idx) and idx.is_cuda):
+        # host indices (range / list / ndarray / CPU tensor): validate here, like torch's CPU indexing does
+        if isinstance(idx, range):
+            idx = np.arange(idx.start, idx.stop, idx.step, dtype=np.int64)
+        host = idx.numpy() if torch.is_tensor(idx) else np.asarray(idx)
+        if host.dtype == np.bool_:
+            host = np.nonzero(host)[0]
+        host = host.astype(np.int64, copy=False).reshape(-1)
+        if host.size and (host.min() < -n_rows or host.max() >= n_rows):
             raise IndexError("index out of range in row gather")
-        idx = torch.where(neg, idx + n_rows, idx)
+        idx = torch.from_numpy(np.ascontiguousarray(host))
+    # device indices are range-checked inside the kernel (it traps on a bad index): no host round trip
+    idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
     out = alloc_rows(idx.numel(), d, x.device)
     with torch.cuda.device(x.device):
         check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d,

@@ -370,6 +370,52 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("d", [147, 7, 100, 500, 1])
+@pytest.mark.parametrize("padded", [True, False])
+def test_aggregators_any_width_and_layout(cuda, d, padded):
+    """every aggregator kernel against the numpy oracle for widths that are / are not multiples of 4, on row-padded
+    buffers (16-byte lanes, masked tail) and on plain contiguous tensors (4-byte lanes)"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    n, H = 777, 6
+    host = [hash_matrix(n, d, seed=50 + h) * (1.0 - 0.1 * h) + hash_matrix(n, d, seed=50) * (0.1 * h) for h in range(H)]
+    host = [np.ascontiguousarray(x, dtype=np.float32) for x in host]
+    if padded:
+        feats = []
+        for x in host:
+            t = dev.alloc_rows(n, d, cuda)
+            t.copy_(torch.from_numpy(x))
+            feats.append(t)
+    else:
+        feats = [torch.from_numpy(x).to(cuda) for x in host]
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_SUM, feats).cpu().numpy(), oracle.agg_sum(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MEAN, feats).cpu().numpy(), oracle.agg_mean(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MAX, feats).cpu().numpy(), oracle.agg_max(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MIN, feats).cpu().numpy(), oracle.agg_min(host, 0, H))
+    assert np.array_equal(dev.hop_concat(feats).cpu().numpy(), oracle.agg_concat(host, 0, H))
+    w1 = np.linspace(0.5, -0.2, H).astype(np.float32)
+    y = dev.hop_reduce(_lib.SGL_REDUCE_WSUM, feats, torch.from_numpy(w1)).cpu().numpy()
+    assert oracle.parity_ok(y, oracle.one_dim_weighted_add(host, w1), 1e-6, rowwise=False)
+    w2 = oracle.softmax32(hash_matrix(n, H, seed=9), 1)
+    w2t = torch.from_numpy(w2).to(cuda).requires_grad_(True)
+    out = dev.hop_wsum2d(feats, w2t)
+    assert oracle.parity_ok(out.detach().cpu().numpy(), oracle.two_dim_weighted_add(host, w2), 1e-6, rowwise=False)
+    g = hash_matrix(n, d, seed=77)
+    out.backward(torch.from_numpy(g).to(cuda))
+    dw_ref = np.stack([(g.astype(np.float64) * x).sum(1) for x in host], 1)
+    assert np.allclose(w2t.grad.cpu().numpy(), dw_ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(dw_ref).max()))
+    yn, wn = dev.nafs_aggregate(feats, return_weights=True)
+    assert np.allclose(wn.cpu().numpy(), oracle.nafs_weights(host), rtol=2e-5, atol=2e-6)
+    assert oracle.parity_ok(yn.cpu().numpy(), oracle.agg_over_smooth_distance(host), 1e-5, rowwise=False)
+    # the two-pass NAFS path gives the same answer as the fused single-pass kernel
+    _lib.set_tuning("nafs_fused", 0)
+    try:
+        y2 = dev.nafs_aggregate(feats)
+    finally:
+        _lib.set_tuning("nafs_fused", 1)
+    assert oracle.parity_ok(y2.cpu().numpy(), yn.cpu().numpy(), 1e-6, rowwise=False)
+
+
 @pytest.mark.parametrize("kind", ["simple", "simple_allow_neg", "gate", "ori_ref", "jk"])
 def test_learnable_aggregators_forward_and_backward(goldens, cuda, kind):
     from sgl_amd.operators.message_op import LearnableWeightedMessageOp

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Throughput of the MessageOp kernels at the products shape (N = 2 449 029, d = 100, H = 4 hops) on the GPU box.
+Prints achieved GB/s against the algorithmic bytes of each op."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgl_amd import _lib  # noqa: E402
+from sgl_amd import device as dev  # noqa: E402
+
+
+def timeit(fn, reps=7, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def main():
+    n = int(os.environ.get("AGG_N", 2_449_029))
+    device = torch.device("cuda", 0)
+    for d, H in ((100, 4), (128, 11), (147, 6), (16, 4)):
+        feats = [dev.alloc_rows(n, d, device) for _ in range(H)]
+        for f in feats:
+            f.normal_()
+        nb = n * d * 4
+
+        def rep(name, ms, bytes_):
+            print(f"AGG d={d} H={H} {name:28s} ms={ms:8.3f} GB/s={bytes_ / (ms * 1e-3) / 1e9:8.1f} frac_of_8TB/s={bytes_ / (ms * 1e-3) / 8e12:.3f}", flush=True)
+
+        for name, op in (("sum", _lib.SGL_REDUCE_SUM), ("mean", _lib.SGL_REDUCE_MEAN), ("max", _lib.SGL_REDUCE_MAX)):
+            rep(name, timeit(lambda: dev.hop_reduce(op, feats)), (H + 1) * nb)
+        w1 = torch.rand(H, device=device)
+        rep("wsum1d", timeit(lambda: dev.hop_reduce(_lib.SGL_REDUCE_WSUM, feats, w1)), (H + 1) * nb)
+        rep("concat", timeit(lambda: dev.hop_concat(feats)), 2 * H * nb)
+        w2 = torch.softmax(torch.randn(n, H, device=device), 1)
+        rep("wsum2d fwd", timeit(lambda: dev.hop_wsum2d(feats, w2)), (H + 1) * nb + n * H * 4)
+        w2g = w2.clone().requires_grad_(True)
+        out = dev.hop_wsum2d(feats, w2g)
+        g = torch.randn_like(out)
+        rep("wsum2d bwd (dW)", timeit(lambda: torch.autograd.grad(out, w2g, g, retain_graph=True)), (H + 1) * nb + n * H * 4)
+        rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
+        idx = torch.randint(0, n, (200_000,), device=device)
+        rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
+        # torch reference points for the same math (not part of the product): stack+sum, index_select
+        rep("[torch] sum of hops", timeit(lambda: sum(feats)), (H + 1) * nb)
+        rep("[torch] x[idx]", timeit(lambda: feats[0][idx]), 2 * 200_000 * d * 4)
+        del feats
+
+
+if __name__ == "__main__":
+    main()

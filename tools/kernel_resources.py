@@ -10,7 +10,7 @@ cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-con
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], {}
 for line in err.splitlines():
-    m = re.search(r"remark: (?:\s*)([A-Za-z ]+): (.+?) \[-Rpass", line)
+    m = re.search(r"remark:\s*(.+?): (.+?) \[-Rpass", line)
     if not m:
         continue
     k, v = m.group(1).strip(), m.group(2).strip()
