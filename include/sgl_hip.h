@@ -13,6 +13,8 @@
  *   sgl_csr_create/_destroy,   device-resident successor of the two above: the CSR lives on the GPU across the
  *   sgl_spmm_f32               K hops of GraphOp.propagate (sgl/operators/base_op.py:29-35) instead of being
  *                              re-uploaded per call (cudamatmul.c:57-74,129).
+ *   sgl_spmm_axpb_clamp_f32    label_propagation's update  out = alpha * spmm(adj, out) + (1-alpha) * H0 ; clamp
+ *                              (sgl/tricks/utils.py:41-58, used by sgl/tricks/correct_and_smooth.py:24-62).
  *   sgl_norm_*                 adj_to_symmetric_norm (sgl/operators/utils.py:76-88) + the Laplacian / PPR
  *                              _construct_adj wrappers (graph_op/laplacian_graph_op.py:12-19,
  *                              graph_op/ppr_graph_op.py:13-21), on device.
@@ -101,6 +103,12 @@ int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
  * (matmul.c:37).  X and Y must not overlap.  ldx, ldy >= d. */
 int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                  int accumulate, void *stream);
+
+/* Fused label-propagation step (sgl/tricks/utils.py:55-56, the inner loop of label_propagation and of
+ * CorrectAndSmooth):  Y = clamp( alpha * (A . X) + RES, lo, hi )  with the reference's rounding order (rounded product,
+ * rounded add, clamp that keeps NaN).  d_res may be NULL (no residual); lo = -INF / hi = +INF disable the clamp. */
+int sgl_spmm_axpb_clamp_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
+                            float alpha, const float *d_res, int64_t ldres, float lo, float hi, void *stream);
 
 /* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */
 /* matmul.h:5 -- accumulates into `answer` (caller pre-zeroes it, utils.py:31).  Errors are recorded in

@@ -20,6 +20,7 @@ __all__ = [
     "agg_simple_weighted", "learnable_weights", "agg_learnable_weighted",
     "agg_iterate_learnable", "nafs_weights", "agg_over_smooth_distance",
     "sigmoid32", "softmax32", "parity_ok", "parity_report",
+    "label_propagation", "cs_correct", "cs_smooth", "nafs_task_features",
 ]
 
 # ----------------------------------------------------------------------------------------------
@@ -363,6 +364,89 @@ def agg_over_smooth_distance(feats):
     for h, f in enumerate(feats):
         acc = acc + w[:, h:h + 1] * f.astype(np.float32)
     return acc
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 2 consumers: label propagation / Correct&Smooth / NAFS task pipeline
+# ----------------------------------------------------------------------------------------------
+def _one_hot(lab, C=None):
+    lab = np.asarray(lab).reshape(-1)
+    C = int(lab.max()) + 1 if C is None else C
+    out = np.zeros((len(lab), C), dtype=np.float32)
+    out[np.arange(len(lab)), lab] = 1.0
+    return out
+
+
+def label_propagation(labels, norm_csr, num_layers, alpha, clamp=(0.0, 1.0), mask=None, post=None):
+    """sgl/tricks/utils.py:41-58.  norm_csr = (indptr, indices, data) of the already-normalised adjacency
+    (float32-rounded like sparse_mx_to_torch_sparse_tensor does, :31-38)."""
+    ptr, col, val = norm_csr
+    val = np.asarray(val).astype(np.float32)
+    labels = np.asarray(labels)
+    if labels.dtype.kind in "iu":
+        labels = _one_hot(labels)
+    labels = labels.astype(np.float32)
+    out = labels.copy()
+    if mask is not None:
+        out = np.zeros_like(labels)
+        out[mask] = labels[mask]
+    a = np.float32(alpha)
+    res = (np.float32(1 - alpha) * out).astype(np.float32)           # :53
+    for _ in range(num_layers):
+        out = (a * oracle_spmm(ptr, col, val, out) + res).astype(np.float32)   # :55
+        if post is not None:
+            out = post(out)
+        elif clamp is not None:
+            out = np.clip(out, np.float32(clamp[0]), np.float32(clamp[1]))
+    return out
+
+
+def cs_correct(y_soft, y_true, mask, norm_csr, num_layers, alpha, autoscale=True, scale=1.0):
+    """CorrectAndSmooth.correct (sgl/tricks/correct_and_smooth.py:18-45); mask = index array"""
+    y_soft = np.asarray(y_soft, dtype=np.float32)
+    yt = _one_hot(y_true, y_soft.shape[1]) if np.asarray(y_true).dtype.kind in "iu" else np.asarray(y_true, np.float32)
+    error = np.zeros_like(y_soft)
+    error[mask] = yt[mask] - y_soft[mask]
+    num_true = len(mask)
+    if autoscale:
+        sm = label_propagation(error, norm_csr, num_layers, alpha, clamp=(-1.0, 1.0))
+        sigma = np.float32(np.abs(error[mask]).sum(dtype=np.float32) / np.float32(num_true))
+        with np.errstate(divide="ignore"):
+            sc = sigma / np.abs(sm).sum(1, keepdims=True, dtype=np.float32)
+        sc[np.isinf(sc) | (sc > 1000)] = 1.0
+        return (y_soft + sm * sc).astype(np.float32)
+
+    def fix(x):
+        x = x.copy()
+        x[mask] = error[mask]
+        return x
+    sm = label_propagation(error, norm_csr, num_layers, alpha, post=fix)
+    return (y_soft + sm * np.float32(scale)).astype(np.float32)
+
+
+def cs_smooth(y_soft, y_true, mask, norm_csr, num_layers, alpha):
+    """CorrectAndSmooth.smooth (sgl/tricks/correct_and_smooth.py:47-62)"""
+    y_soft = np.asarray(y_soft, dtype=np.float32).copy()
+    yt = _one_hot(y_true, y_soft.shape[1]) if np.asarray(y_true).dtype.kind in "iu" else np.asarray(y_true, np.float32)
+    y_soft[mask] = yt[mask]
+    return label_propagation(y_soft, norm_csr, num_layers, alpha)
+
+
+def nafs_task_features(indptr, indices, data, n, x, hops, r_list, method):
+    """NodeClusteringNAFS._k_hop_cluster up to the KMeans call (sgl/tasks/node_clustering.py:205-252)"""
+    x = np.asarray(x, dtype=np.float32)
+    per_r = []
+    for r in r_list:
+        norm = sym_norm_csr(indptr, indices, data, n, r)
+        feats = propagate(norm, x, hops)
+        if method == "simple":
+            return feats[-1]
+        per_r.append(agg_over_smooth_distance(feats))
+    if method == "mean":
+        return agg_mean(per_r, 0, len(per_r))
+    if method == "max":
+        return agg_max(per_r, 0, len(per_r))
+    return np.hstack(per_r)
 
 
 # ----------------------------------------------------------------------------------------------

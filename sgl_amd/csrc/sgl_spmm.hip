@@ -110,7 +110,25 @@ struct SpmmArgs {
     int64_t ldx, ldy, ldp;
     int32_t n_items, n_pieces, d, accumulate;
     int32_t piece_blocks, item_blocks_per_xcd, xcd_remap, waves;
+    // optional fused epilogue  Y = clamp(alpha * (A X) + res, lo, hi)   (label propagation / C&S step,
+    // reference: sgl/tricks/utils.py:55-56); epi == 0 -> plain store
+    const float *res;
+    int64_t ldres;
+    float epi_alpha, epi_lo, epi_hi;
+    int32_t epi;
 };
+
+struct Epilogue {
+    const float *res;   // row pointer already applied by the caller (may be nullptr)
+    float alpha, lo, hi;
+    int on;
+};
+
+__device__ __forceinline__ float epi_apply(float v, float r, const Epilogue &e, bool has_res) {
+    float t = __fmul_rn(e.alpha, v);          // alpha * spmm(...)   (rounded product, then rounded add: torch order)
+    if (has_res) t = __fadd_rn(t, r);
+    return t < e.lo ? e.lo : (t > e.hi ? e.hi : t);   // clamp that keeps NaN, like torch.clamp_
+}
 
 // One wavefront walks `nrows` consecutive rows whose non-zeros are colb/valb[0 .. tot) ; lane i of `my_rel`
 // holds the offset of row i's first non-zero (lane nrows holds tot).
@@ -118,7 +136,8 @@ template <int VEC, int GROUP, int NCH, int U, bool NT>
 __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const float *__restrict__ valb,
                                          const int my_rel, const int nrows, const int tot,
                                          const float *__restrict__ x, const int64_t ldx, float *__restrict__ out,
-                                         const int64_t ldo, const int d, const bool accumulate, const int lane) {
+                                         const int64_t ldo, const int d, const bool accumulate, const int lane,
+                                         const Epilogue epi, const int64_t ldres) {
     using V = typename VecT<VEC>::type;
     constexpr int R = 64 / GROUP;
     const int s = (R == 1) ? 0 : (lane / GROUP);
@@ -222,7 +241,21 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
         if (s == 0) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch)
-                if (on[ch]) st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), acc[ch]);
+                if (on[ch]) {
+                    V v = acc[ch];
+                    if (epi.on) {
+                        const bool has_res = epi.res != nullptr;
+                        V r = vzero<VEC>();
+                        if (has_res) r = *reinterpret_cast<const V *>(epi.res + (int64_t)ri * ldres + colofs[ch]);
+                        if constexpr (VEC == 1) {
+                            v = epi_apply(v, r, epi, has_res);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) v[e] = epi_apply(v[e], r[e], epi, has_res);
+                        }
+                    }
+                    st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
+                }
         }
     }
 }
@@ -237,8 +270,13 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         if (p >= a.n_pieces) return;
         const sgl::Piece pc = a.pieces[p];
         const int my_rel = (lane == 0) ? 0 : pc.len;
+        Epilogue none;
+        none.res = nullptr;
+        none.alpha = 1.f;
+        none.lo = none.hi = 0.f;
+        none.on = 0;   // pieces hold partial sums: the epilogue runs in the fix-up kernel
         run_rows<VEC, GROUP, NCH, U, NT>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
-                                         a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane);
+                                         a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0);
     } else {
         int ib = b - a.piece_blocks;
         if (a.xcd_remap) ib = (ib & 7) * a.item_blocks_per_xcd + (ib >> 3);
@@ -252,8 +290,15 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         const int64_t base = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
         const int my_rel = (int)(rp - base);
         const int tot = __builtin_amdgcn_readlane(my_rel, nrows);
+        Epilogue epi;
+        epi.res = a.res ? a.res + (int64_t)row_begin * a.ldres : nullptr;
+        epi.alpha = a.epi_alpha;
+        epi.lo = a.epi_lo;
+        epi.hi = a.epi_hi;
+        epi.on = a.epi;
         run_rows<VEC, GROUP, NCH, U, NT>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
-                                         a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane);
+                                         a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
+                                         a.ldres);
     }
 }
 
@@ -261,7 +306,8 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restrict__ long_row,
                                                          const int32_t *__restrict__ long_first,
                                                          const float *__restrict__ partial, int64_t ldp,
-                                                         float *__restrict__ y, int64_t ldy, int d, int accumulate) {
+                                                         float *__restrict__ y, int64_t ldy, int d, int accumulate,
+                                                         const float *__restrict__ res, int64_t ldres, Epilogue epi) {
     const int kblocks = (d + 255) / 256;
     const int lr = blockIdx.x / kblocks;
     const int k = (blockIdx.x % kblocks) * 256 + threadIdx.x;
@@ -271,6 +317,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     float *yp = y + (int64_t)row * ldy + k;
     float acc = accumulate ? *yp : 0.f;
     for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
+    if (epi.on) acc = epi_apply(acc, res ? res[(int64_t)row * ldres + k] : 0.f, epi, res != nullptr);
     *yp = acc;
 }
 
@@ -422,8 +469,15 @@ static int pick_vec(const float *d_x, int64_t ldx, const float *d_y, int64_t ldy
     return 1;
 }
 
+struct EpiHost {
+    int on = 0;
+    float alpha = 1.f, lo = 0.f, hi = 0.f;
+    const float *res = nullptr;
+    int64_t ldres = 0;
+};
+
 static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int d, int vec,
-                      int accumulate, hipStream_t st) {
+                      int accumulate, hipStream_t st, const EpiHost &eh) {
     const int lanes = d / vec;
     const bool strict = (h->flags & SGL_CSR_STRICT_ORDER) != 0;
     // Lane layout (measured on MI355X, profiles/r01_sweep*.log): rows wider than 64 floats are gathered one
@@ -467,6 +521,12 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.d = d;
     a.accumulate = accumulate;
     a.waves = waves;
+    a.res = eh.res;
+    a.ldres = eh.ldres;
+    a.epi_alpha = eh.alpha;
+    a.epi_lo = eh.lo;
+    a.epi_hi = eh.hi;
+    a.epi = eh.on;
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
     a.xcd_remap = (!(h->flags & SGL_CSR_NO_XCD_REMAP) && sgl::tuning("spmm_xcd_remap", 1) != 0) ? 1 : 0;
@@ -498,30 +558,62 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     if (h->n_long > 0) {
         const int64_t fg = (int64_t)((d + 255) / 256) * h->n_long;
         if (fg >= INT32_MAX) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_spmm_f32: fix-up grid too large");
+        Epilogue fe;
+        fe.res = nullptr;
+        fe.alpha = eh.alpha;
+        fe.lo = eh.lo;
+        fe.hi = eh.hi;
+        fe.on = eh.on;
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_long_row, h->d_long_first, h->d_partial, a.ldp,
-                           d_y, ldy, d, accumulate);
+                           d_y, ldy, d, accumulate, eh.res, eh.ldres, fe);
         e = hipGetLastError();
         if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: fix-up launch failed: %s", hipGetErrorString(e));
     }
     return SGL_OK;
 }
 
-SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
-                            int accumulate, void *stream) {
-    if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_spmm_f32: NULL handle");
-    SGL_REQUIRE(d >= 0 && d < INT32_MAX, "sgl_spmm_f32: bad d");
+static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, int accumulate,
+                     void *stream, EpiHost eh, const char *who) {
+    if (!h) return sgl::fail(SGL_ERR_INVALID, "%s: NULL handle", who);
+    SGL_REQUIRE(d >= 0 && d < INT32_MAX, "%s: bad d", who);
     if (d == 0 || h->n_rows == 0) return SGL_OK;
-    SGL_REQUIRE(d_x && d_y, "sgl_spmm_f32: NULL X or Y");
-    SGL_REQUIRE(ldx >= d && ldy >= d, "sgl_spmm_f32: leading dimension smaller than d");
-    SGL_REQUIRE(aligned_to(d_x, 4) && aligned_to(d_y, 4), "sgl_spmm_f32: X/Y not 4-byte aligned");
+    SGL_REQUIRE(d_x && d_y, "%s: NULL X or Y", who);
+    SGL_REQUIRE(ldx >= d && ldy >= d, "%s: leading dimension smaller than d", who);
+    SGL_REQUIRE(aligned_to(d_x, 4) && aligned_to(d_y, 4), "%s: X/Y not 4-byte aligned", who);
     hipStream_t st = sgl::as_stream(stream);
     // one launch covers up to 64 lanes x 4 chunks x VEC columns; wider matrices go in column slices
-    const int vec = pick_vec(d_x, ldx, d_y, ldy, d);
+    int vec = pick_vec(d_x, ldx, d_y, ldy, d);
+    if (eh.on && eh.res) {
+        SGL_REQUIRE(eh.ldres >= d && aligned_to(eh.res, 4), "%s: bad residual matrix", who);
+        if (vec == 4 && !(eh.ldres % 4 == 0 && aligned_to(eh.res, 16))) vec = (eh.ldres % 2 == 0 && aligned_to(eh.res, 8) && d % 2 == 0) ? 2 : 1;
+        if (vec == 2 && !(eh.ldres % 2 == 0 && aligned_to(eh.res, 8))) vec = 1;
+    }
     const int64_t max_cols = 64 * 4 * vec;
     for (int64_t c0 = 0; c0 < d; c0 += max_cols) {
         const int dc = (int)std::min<int64_t>(max_cols, d - c0);
-        int rc = spmm_slice(h, d_x + c0, ldx, d_y + c0, ldy, dc, vec, accumulate, st);
+        EpiHost es = eh;
+        if (es.res) es.res += c0;
+        int rc = spmm_slice(h, d_x + c0, ldx, d_y + c0, ldy, dc, vec, accumulate, st, es);
         if (rc != SGL_OK) return rc;
     }
     return SGL_OK;
+}
+
+SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
+                            int accumulate, void *stream) {
+    return spmm_impl(h, d_x, ldx, d_y, ldy, d, accumulate, stream, EpiHost(), "sgl_spmm_f32");
+}
+
+SGL_EXPORT int sgl_spmm_axpb_clamp_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
+                                       float alpha, const float *d_res, int64_t ldres, float lo, float hi,
+                                       void *stream) {
+    EpiHost eh;
+    eh.on = 1;
+    eh.alpha = alpha;
+    eh.lo = lo;
+    eh.hi = hi;
+    eh.res = d_res;
+    eh.ldres = ldres;
+    SGL_REQUIRE(!(lo > hi), "sgl_spmm_axpb_clamp_f32: lo > hi");
+    return spmm_impl(h, d_x, ldx, d_y, ldy, d, 0, stream, eh, "sgl_spmm_axpb_clamp_f32");
 }

@@ -124,6 +124,26 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
+    def spmm_axpb_clamp(self, x, alpha, res=None, lo=float("-inf"), hi=float("inf"), out=None):
+        """out = clamp(alpha * (A @ x) + res, lo, hi) in one kernel (the label-propagation step)"""
+        _check_mat(x, "x")
+        if x.shape[0] != self.shape[1]:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        d = x.shape[1]
+        if out is None:
+            out = alloc_rows(self.shape[0], d, x.device, zero_pad=True)
+        else:
+            _check_mat(out, "out")
+        if res is not None:
+            _check_mat(res, "res")
+            if res.shape != (self.shape[0], d):
+                raise ValueError("res has the wrong shape")
+        with torch.cuda.device(self.device):
+            check(lib().sgl_spmm_axpb_clamp_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), d, float(alpha),
+                                                ptr(res) if res is not None else None, _ld(res) if res is not None else 0,
+                                                float(lo), float(hi), current_stream_ptr()), "sgl_spmm_axpb_clamp_f32")
+        return out
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

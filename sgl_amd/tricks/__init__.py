@@ -1,0 +1,8 @@
+"""Consumers of the same device SpMM beyond GraphOp.propagate:
+label propagation / Correct&Smooth (reference: sgl/tricks) and the NAFS feature-smoothing pipeline of the
+NAFS clustering / link-prediction tasks (reference: sgl/tasks/node_clustering.py:205-258)."""
+from .correct_and_smooth import CorrectAndSmooth
+from .nafs_features import nafs_ensemble_features
+from .utils import label_propagation
+
+__all__ = ["CorrectAndSmooth", "label_propagation", "nafs_ensemble_features"]

@@ -354,6 +354,81 @@ def gen_g5():
         json.dump(cases, f, indent=1, sort_keys=True)
 
 
+# ------------------------------------------------------------------------------------------
+# G6: SURVEY 8(f) rank 2 consumers of the same SpMM: label propagation / Correct&Smooth (sgl/tricks) and the
+#     NAFS multi-r feature-smoothing pipeline of the NAFS tasks (tasks/node_clustering.py:205-258)
+# ------------------------------------------------------------------------------------------
+def gen_g6():
+    from sgl.tricks.utils import adj_to_symmetric_norm as tricks_norm, label_propagation
+    from sgl.tricks.correct_and_smooth import CorrectAndSmooth
+    out = {}
+    g = GRAPHS["pl2000"]
+    n, C = g.shape[0], 5
+    adj = tricks_norm(g, 0.5)
+    lab = torch.from_numpy((hash_matrix(n, 1, seed=31)[:, 0] * 1000).astype(np.int64) % C)
+    lab[:C] = torch.arange(C)                       # every class present (F.one_hot infers C from max)
+    mask = np.arange(0, n, 3)
+    out["lp|labels"] = lab.numpy()
+    out["lp|mask"] = mask
+    out["lp|long_masked"] = label_propagation(lab, adj, 5, 0.8, mask=torch.from_numpy(mask)).numpy().copy()
+    out["lp|long_nomask"] = label_propagation(lab, adj, 3, 0.5).numpy().copy()
+    soft = torch.softmax(torch.from_numpy(hash_matrix(n, C, seed=32)) * 3, 1)
+    out["lp|float_clamp11"] = label_propagation(soft - 0.3, adj, 4, 0.9,
+                                                post_process=lambda x: x.clamp_(-1., 1.)).numpy().copy()
+    for autoscale in (True, False):
+        cs = CorrectAndSmooth(4, 0.9, 3, 0.7, autoscale=autoscale, scale=1.5)
+        y1 = cs.correct(soft.clone(), lab, mask, adj)
+        y2 = cs.smooth(y1.clone(), lab, mask, adj)
+        out[f"cs|autoscale{int(autoscale)}|correct"] = y1.numpy().copy()
+        out[f"cs|autoscale{int(autoscale)}|smooth"] = y2.numpy().copy()
+
+    # NAFS task pipeline: run the reference's own _k_hop_cluster and capture what it hands to KMeans
+    for m in ["matplotlib", "matplotlib.pyplot", "munkres"]:
+        try:
+            importlib.import_module(m)
+        except ImportError:
+            sys.modules[m] = MagicMock()
+    pkg = types.ModuleType("sgl.tasks")
+    pkg.__path__ = [REF + "/sgl/tasks"]
+    sys.modules["sgl.tasks"] = pkg
+    import sgl.tasks.node_clustering as nc
+
+    class Captured(Exception):
+        pass
+
+    class FakeKMeans:
+        def __init__(self, *a, **k):
+            pass
+
+        def fit_predict(self, x):
+            FakeKMeans.seen = np.array(x, copy=True)
+            raise Captured()
+
+    nc.KMeans = FakeKMeans
+    g8 = GRAPHS["pl256"]
+    x8 = hash_positive(256, 8, seed=33)
+
+    class DS:
+        x = x8
+        adj = g8
+        num_node = 256
+
+    for method in ("mean", "max", "concat", "simple"):
+        task = object.__new__(nc.NodeClusteringNAFS)
+        task._NodeClusteringNAFS__dataset = DS
+        task._NodeClusteringNAFS__r_list = [0.5, 0.4, 0.3, 0.2, 0.1, 0]
+        task._NodeClusteringNAFS__method = method
+        task._NodeClusteringNAFS__n_clusters = 3
+        task._NodeClusteringNAFS__n_init = 1
+        task._NodeClusteringNAFS__seed = 0
+        try:
+            task._k_hop_cluster(3)
+        except Captured:
+            pass
+        out[f"nafs_task|{method}|hops3"] = FakeKMeans.seen.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g6_consumers.npz"), **out)
+
+
 def main():
     save_graphs()
     gen_g1()
@@ -364,6 +439,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g3_agg.npz"), **g3)
     gen_g4(mods)
     gen_g5()
+    gen_g6()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

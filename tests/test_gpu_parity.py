@@ -518,6 +518,73 @@ def test_models_match_reference_goldens(goldens, cuda):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_spmm_axpb_clamp_epilogue(cuda):
+    """fused Y = clamp(alpha * A X + RES): regular rows in the main kernel, split rows in the fix-up kernel"""
+    a = long_row_graph()
+    n = a.shape[0]
+    for d in (5, 47, 100):
+        x = hash_matrix(n, d, seed=13)
+        res = hash_matrix(n, d, seed=14)
+        ax = oracle.oracle_spmm(a.indptr, a.indices, a.data, x)
+        scale = oracle.oracle_spmm(a.indptr, a.indices, np.abs(a.data), np.abs(x))
+        for strict, long_nnz in ((True, 0), (False, 256)):
+            csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, long_row_nnz=long_nnz)
+            xd, rd = torch.from_numpy(x).to(cuda), torch.from_numpy(res).to(cuda)
+            ref = np.clip((np.float32(0.8) * ax + res).astype(np.float32), np.float32(-0.5), np.float32(0.75))
+            y = csr.spmm_axpb_clamp(xd, 0.8, rd, -0.5, 0.75).cpu().numpy()
+            if strict:
+                assert np.array_equal(y, ref), (d, oracle.parity_report(y, ref))
+            else:
+                # the clamp hides the magnitude the sums were formed at: normalise by the pre-clamp values
+                pre = np.abs(np.float32(0.8) * ax + res).max()
+                assert np.abs(y - ref).max() <= TOL * pre and y.min() >= -0.5 and y.max() <= 0.75
+            y = csr.spmm_axpb_clamp(xd, -1.5).cpu().numpy()                      # no residual, no clamp
+            ref2 = (np.float32(-1.5) * ax).astype(np.float32)
+            assert np.array_equal(y, ref2) if strict else oracle.parity_ok(y, ref2, TOL, scale=1.5 * scale)
+
+
+def test_label_propagation_and_correct_smooth_match_reference(goldens, cuda):
+    from sgl_amd.tricks import CorrectAndSmooth, label_propagation
+    g6 = goldens.npz("g6_consumers")
+    g = goldens.graph("pl2000")
+    n = g.shape[0]
+    ptr, col, val = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, 0.5)
+    adj = sp.csr_matrix((val, col, ptr.astype(np.int32)), shape=(n, n))          # what the reference passes in
+    lab = torch.from_numpy(g6["lp|labels"])
+    mask = g6["lp|mask"]
+    y = label_propagation(lab, adj, 5, 0.8, mask=torch.from_numpy(mask))
+    assert y.is_cuda and oracle.parity_ok(y.cpu().numpy(), g6["lp|long_masked"], TOL, rowwise=False)
+    y = label_propagation(lab, adj, 3, 0.5)
+    assert oracle.parity_ok(y.cpu().numpy(), g6["lp|long_nomask"], TOL, rowwise=False)
+    soft = torch.softmax(torch.from_numpy(hash_matrix(n, 5, seed=32)) * 3, 1)
+    y = label_propagation(soft - 0.3, adj, 4, 0.9, post_process=(-1., 1.))
+    assert oracle.parity_ok(y.cpu().numpy(), g6["lp|float_clamp11"], TOL, rowwise=False)
+    y = label_propagation(soft - 0.3, adj, 4, 0.9, post_process=lambda t: t.clamp_(-1., 1.))   # callable form
+    assert oracle.parity_ok(y.cpu().numpy(), g6["lp|float_clamp11"], TOL, rowwise=False)
+    for autoscale in (True, False):
+        cs = CorrectAndSmooth(4, 0.9, 3, 0.7, autoscale=autoscale, scale=1.5)
+        y1 = cs.correct(soft.clone(), lab, mask, adj)
+        rep = oracle.parity_report(y1.cpu().numpy(), g6[f"cs|autoscale{int(autoscale)}|correct"], TOL, rowwise=False)
+        assert rep["ok"], (autoscale, rep)
+        y2 = cs.smooth(y1.clone(), lab, mask, adj)
+        rep = oracle.parity_report(y2.cpu().numpy(), g6[f"cs|autoscale{int(autoscale)}|smooth"], TOL, rowwise=False)
+        assert rep["ok"], (autoscale, rep)
+
+
+def test_nafs_task_feature_pipeline_matches_reference(goldens, cuda):
+    from inputs import hash_positive
+    from sgl_amd.tricks import nafs_ensemble_features
+    g6 = goldens.npz("g6_consumers")
+    g = goldens.graph("pl256")
+    x = hash_positive(256, 8, seed=33)
+    for method in ("mean", "max", "concat", "simple"):
+        y = nafs_ensemble_features(g, x, 3, [0.5, 0.4, 0.3, 0.2, 0.1, 0], method)
+        rep = oracle.parity_report(y.cpu().numpy(), g6[f"nafs_task|{method}|hops3"], TOL)
+        assert rep["ok"], (method, rep)
+    with pytest.raises(ValueError):
+        nafs_ensemble_features(g, x, 3, method="median")
+
+
 def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
     """every virtual rank's row pieces (rectangular device CSRs) reproduce the rows of the single-matrix result;
     world = 1 ShardedPropagator == plain k-step propagation (the exchange itself is covered by the gloo tests)"""

@@ -129,3 +129,36 @@ def test_parity_metric_rejects_wrong():
     assert oracle.parity_ok(ref, ref)
     assert not oracle.parity_ok(bad, ref)
     assert not oracle.parity_ok(ref[:10], ref)
+
+
+def test_g6_label_propagation_and_correct_smooth(goldens):
+    g6 = goldens.npz("g6_consumers")
+    g = goldens.graph("pl2000")
+    n = g.shape[0]
+    norm = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, 0.5)
+    lab, mask = g6["lp|labels"], g6["lp|mask"]
+    y = oracle.label_propagation(lab, norm, 5, 0.8, mask=mask)
+    assert oracle.parity_ok(y, g6["lp|long_masked"], 1e-5, rowwise=False)
+    y = oracle.label_propagation(lab, norm, 3, 0.5)
+    assert oracle.parity_ok(y, g6["lp|long_nomask"], 1e-5, rowwise=False)
+    soft = oracle.softmax32(hash_matrix(n, 5, seed=32) * np.float32(3), 1)
+    y = oracle.label_propagation(soft - np.float32(0.3), norm, 4, 0.9, clamp=(-1.0, 1.0))
+    assert oracle.parity_ok(y, g6["lp|float_clamp11"], 1e-5, rowwise=False)
+    for autoscale in (True, False):
+        y1 = oracle.cs_correct(soft, lab, mask, norm, 4, 0.9, autoscale=autoscale, scale=1.5)
+        rep = oracle.parity_report(y1, g6[f"cs|autoscale{int(autoscale)}|correct"], 1e-5, rowwise=False)
+        assert rep["ok"], (autoscale, rep)
+        y2 = oracle.cs_smooth(y1, lab, mask, norm, 3, 0.7)
+        rep = oracle.parity_report(y2, g6[f"cs|autoscale{int(autoscale)}|smooth"], 1e-5, rowwise=False)
+        assert rep["ok"], (autoscale, rep)
+
+
+def test_g6_nafs_task_pipeline(goldens):
+    from inputs import hash_positive
+    g6 = goldens.npz("g6_consumers")
+    g = goldens.graph("pl256")
+    x = hash_positive(256, 8, seed=33)
+    for method in ("mean", "max", "concat", "simple"):
+        y = oracle.nafs_task_features(g.indptr, g.indices, g.data, 256, x, 3, [0.5, 0.4, 0.3, 0.2, 0.1, 0], method)
+        rep = oracle.parity_report(y, g6[f"nafs_task|{method}|hops3"], 1e-5)
+        assert rep["ok"], (method, rep)
