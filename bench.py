@@ -72,7 +72,59 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
             "ms_per_hop_sample": t * 1e3}
 
 
-def main():
+class GpuEngine:
+    """Everything device-specific in the bench: workload construction, the two step functions, timing.
+    tests/test_bench_orchestration.py substitutes a CPU/gloo engine to exercise the distributed orchestration
+    (broadcast, shard bounds, exchange, barrier/MAX timing, JSON contract) without GPUs."""
+    backend = "nccl"
+
+    def __init__(self, local_rank):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the sgl_amd hot path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+
+    def init_kwargs(self):
+        return {"device_id": self.device}
+
+    def build_workload(self, args, wl):
+        """rank 0: synthetic graph -> A_hat (LaplacianGraphOp r = 0.5) on device + features"""
+        from sgl_amd import device as dev
+        from sgl_amd import synthetic
+        n, d = wl["n"], wl["d"]
+        a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=args.seed, device=self.device)
+        rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)
+        x0 = synthetic.features_torch(n, d, seed=args.seed, device=self.device,
+                                      kind="pubmed" if args.workload.startswith("S0") else "normal")
+        return rowptr, col, val, x0
+
+    def single_step(self, args, rowptr, col, val, x0, n, d, K):
+        from sgl_amd import device as dev
+        csr = dev.DeviceCSR(rowptr, col, val, (n, n), strict=args.strict)
+        bufs = [dev.alloc_rows(n, d, self.device) for _ in range(K)]
+        src0 = dev.upload_rows(x0, self.device) if (d % 4) else x0
+
+        def step():
+            cur = dev.padded_parent(src0)
+            for h in range(K):
+                out = dev.padded_parent(bufs[h])
+                csr.spmm(cur, out=out)
+                cur = out
+        return step, csr.info()
+
+    def piece_spmms(self, args, rowptr, col, val, n, my_bounds, rp_host):
+        from sgl_amd.dist import device_piece_spmms
+        return device_piece_spmms(rowptr, col, val, n, my_bounds, rowptr_host=rp_host, strict=args.strict)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def timer(self):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        return (lambda: ev0.record()), (lambda: ev1.record()), (lambda: ev0.elapsed_time(ev1))
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -84,7 +136,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the row-piece (multi-GPU) code path even with one GPU")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
+    import torch.distributed as dist
+    from sgl_amd.dist import ShardedPropagator, all_piece_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,31 +150,24 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the sgl_amd hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-
-    import torch.distributed as dist
-    if world > 1:
+    engine = engine_cls(local_rank)
+    device = engine.device
+    own_group = False
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(engine.backend, rank=rank, world_size=world, **engine.init_kwargs())
+        own_group = True
 
-    from sgl_amd import device as dev
-    from sgl_amd import synthetic
-    from sgl_amd.dist import ShardedPropagator, all_piece_bounds, device_piece_spmms
-
-    wl = synthetic.WORKLOADS[args.workload]
+    if workloads is None:
+        from sgl_amd import synthetic
+        workloads = synthetic.WORKLOADS
+    wl = workloads[args.workload]
     n, d, K = wl["n"], wl["d"], wl["k"]
 
-    # ---- build the workload (untimed): graph -> A_hat on device, features -------------------------------
+    # ---- build the workload (untimed): rank 0 generates + normalises, everybody receives a replica --------
     t_setup = time.perf_counter()
     if rank == 0:
-        a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=args.seed, device=device)
-        rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)  # LaplacianGraphOp(r=0.5)
-        del a_ptr, a_col, a_val
-        x0 = synthetic.features_torch(n, d, seed=args.seed, device=device,
-                                      kind="pubmed" if args.workload.startswith("S0") else "normal")
+        rowptr, col, val, x0 = engine.build_workload(args, wl)
         meta = torch.tensor([col.numel()], dtype=torch.int64, device=device)
     else:
         meta = torch.zeros(1, dtype=torch.int64, device=device)
@@ -132,63 +182,54 @@ def main():
         for t in (rowptr, col, val, x0):
             dist.broadcast(t, 0)
     nnz = int(col.numel())
-    torch.cuda.synchronize()
+    engine.sync()
 
-    cpu = None
-    if world == 1 and not args.force_sharded:
-        csr = dev.DeviceCSR(rowptr, col, val, (n, n), strict=args.strict)
-        info = csr.info()
-        bufs = [dev.alloc_rows(n, d, device) for _ in range(K)]
-        src0 = dev.upload_rows(x0, device) if (d % 4) else x0
-
-        def step():
-            cur = dev.padded_parent(src0)
-            for h in range(K):
-                out = dev.padded_parent(bufs[h])
-                csr.spmm(cur, out=out)
-                cur = out
+    sharded = world > 1 or args.force_sharded
+    if not sharded:
+        step, info = engine.single_step(args, rowptr, col, val, x0, n, d, K)
     else:
         rp_host = rowptr.cpu().numpy()
         pb = all_piece_bounds(rp_host, world, args.pieces)
-        pieces, _handles = device_piece_spmms(rowptr, col, val, n, pb[rank], rowptr_host=rp_host, strict=args.strict)
+        pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
         prop = ShardedPropagator(pieces, pb, rank, world, n)
         xbufs = [torch.empty_like(x0) for _ in range(min(2, max(K - 1, 0)))]
         info = {"n_items": None, "n_pieces": None, "n_long_rows": None}
-        del rowptr  # keep col/val alive through the piece views
 
         def step():
             prop.propagate(x0, K, x_buffers=xbufs)
     setup_s = time.perf_counter() - t_setup
 
     def sync_all():
-        torch.cuda.synchronize()
+        engine.sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            engine.sync()
 
     for _ in range(args.warmup):
         step()
     sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start, t_stop, t_elapsed_ms = engine.timer()
     t0 = time.perf_counter()
-    ev0.record()
+    t_start()
     for _ in range(args.steps):
         step()
-    ev1.record()
+    t_stop()
     sync_all()
     elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+    gpu_ms = t_elapsed_ms()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    if world == 1 and not args.force_sharded and not args.no_cpu_baseline and rank == 0:
+    cpu = None
+    if not sharded and not args.no_cpu_baseline and rank == 0:
         try:
             cpu = cpu_baseline(rowptr, col, val, x0, d)
         except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
             cpu = {"value": None, "unit": "edge*featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
+    out = None
     if rank == 0:
         value = nnz * d * K * args.steps / elapsed
         hop_s = (gpu_ms * 1e-3) / (K * args.steps)           # average launch duration from HIP events
@@ -222,10 +263,17 @@ def main():
                          "avg_launch_ms": hop_s * 1e3},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
+    return out
+
+
+def main():
+    run(parse_args())
 
 
 if __name__ == "__main__":

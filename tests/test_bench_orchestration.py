@@ -1,0 +1,124 @@
+"""bench.py's distributed orchestration (replica broadcast, shard bounds, piece exchange, barrier + MAX-over-ranks
+timing, the one-line JSON contract) exercised with 2 gloo ranks on CPU.  The compute engine is substituted
+(CPU oracle SpMM instead of the HIP kernels) -- the GPU engine itself is covered by `-m gpu` tests and by the
+driver's bench runs; what cannot be run here, an N>1 launch, is exactly what this test pins down."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TINY = {"T_tiny": dict(n=3000, m=20_000, d_max=300, d=12, k=3)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_engine():
+    import time
+
+    import oracle
+    from sgl_amd.synthetic import chung_lu_numpy
+
+    class CpuEngine:
+        backend = "gloo"
+
+        def __init__(self, local_rank):
+            self.device = torch.device("cpu")
+
+        def init_kwargs(self):
+            return {}
+
+        def build_workload(self, args, wl):
+            ip, ix, dt = chung_lu_numpy(wl["n"], wl["m"], wl["d_max"], seed=args.seed)
+            ptr, col, val = oracle.laplacian_adj(ip, ix, dt, wl["n"], 0.5)
+            x = np.random.default_rng(0).standard_normal((wl["n"], wl["d"])).astype(np.float32)
+            return (torch.from_numpy(ptr), torch.from_numpy(col.astype(np.int32)),
+                    torch.from_numpy(val.astype(np.float32)), torch.from_numpy(x))
+
+        def single_step(self, args, rowptr, col, val, x0, n, d, K):
+            rp, c, v = rowptr.numpy(), col.numpy(), val.numpy()
+
+            def step():
+                cur = x0.numpy()
+                for _ in range(K):
+                    cur = oracle.oracle_spmm(rp, c, v, cur)
+                self.last = cur
+            return step, {"n_items": 0}
+
+        def piece_spmms(self, args, rowptr, col, val, n, my_bounds, rp_host):
+            fns = []
+            for p in range(len(my_bounds) - 1):
+                r0, r1 = int(my_bounds[p]), int(my_bounds[p + 1])
+                rp = (rp_host[r0:r1 + 1] - rp_host[r0]).astype(np.int64)
+                nb, ne = int(rp_host[r0]), int(rp_host[r1])
+                c, v = col[nb:ne].numpy(), val[nb:ne].numpy()
+                fns.append(lambda x, out, rp=rp, c=c, v=v, rows=r1 - r0:
+                           out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c, v, x.numpy(), n_rows=rows))))
+            return fns, None
+
+        def sync(self):
+            pass
+
+        def timer(self):
+            t = {}
+            return (lambda: t.__setitem__("a", time.perf_counter())), (lambda: t.__setitem__("b", time.perf_counter())), \
+                   (lambda: (t["b"] - t["a"]) * 1e3)
+
+    return CpuEngine
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import bench
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_tiny",
+                             "--pieces", "3", "--no-cpu-baseline"])
+    lines = []
+    out = bench.run(args, engine_cls=_make_engine(), workloads=TINY, emit=lines.append)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({"lines": lines, "returned": out is not None, "initialized_after": dist.is_initialized()}, f)
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    r1 = json.load(open(tmp_path / "rank1.json"))
+    assert len(r0["lines"]) == 1 and r1["lines"] == [] and not r0["initialized_after"]
+    j = json.loads(r0["lines"][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "strong"
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge*featdim/s" and j["vs_baseline"] is None
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] and j["cpu_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+
+
+def test_bench_single_rank_contract(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    import bench
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--workload", "T_tiny", "--no-cpu-baseline"])
+    lines = []
+    bench.run(args, engine_cls=_make_engine(), workloads=TINY, emit=lines.append)
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["config"]["parallelism"] == "single GPU" and j["value"] > 0
+    # default CLI values finish quickly and match the documented contract
+    d = bench.parse_args([])
+    assert d.gpus == 1 and d.steps == 10 and d.warmup == 2 and d.workload == "S1_products"

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""PaSca operator sweep (BASELINE config 5 shape, on the products-sized graph that fits one GPU):
+graph ops {Laplacian r=0.5, PPR alpha in {0.1, 0.2, 0.3}} x k = 10 hops, then every MessageOp over the 11 hop
+matrices.  Search space: sgl/search/search_config.py:14-15, search_models.py:19-46.  Prints wall time per stage
+(HIP events) -- the quantity PaSca's second objective `time_preprocess` measures (auto_search.py:29,54)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgl_amd import device as dev, synthetic  # noqa: E402
+from sgl_amd.operators import message_op as M  # noqa: E402
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), r
+
+
+def main():
+    wl = synthetic.WORKLOADS[os.environ.get("SWEEP_WORKLOAD", "S1_products")]
+    n, d, K = wl["n"], wl["d"], 10
+    device = torch.device("cuda", 0)
+    a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=0, device=device)
+    x0 = synthetic.features_torch(n, d, seed=0, device=device)
+    for name, r, alpha in (("laplacian r=0.5", 0.5, None), ("ppr a=0.1", 0.5, 0.1), ("ppr a=0.2", 0.5, 0.2), ("ppr a=0.3", 0.5, 0.3)):
+        t_norm, (rowptr, col, val) = timed(lambda: dev.normalize_adj(a_ptr, a_col, a_val, n, r, alpha), reps=1)
+        csr = dev.DeviceCSR(rowptr, col, val, (n, n))
+
+        def prop():
+            feats = [x0]
+            for _ in range(K):
+                feats.append(csr.spmm(feats[-1]))
+            return feats
+        t_prop, feats = timed(prop)
+        nnz = col.numel()
+        print(f"SWEEP graph_op={name:16s} normalise_ms={t_norm:8.2f} propagate_k10_ms={t_prop:8.2f} "
+              f"({nnz * d * K / (t_prop * 1e-3) / 1e12:.3f}e12 edge*feat/s)", flush=True)
+        if alpha not in (None, 0.1):
+            continue
+        ops = [("last", M.LastMessageOp()), ("concat", M.ConcatMessageOp(0, K + 1)), ("mean", M.MeanMessageOp(0, K + 1)),
+               ("sum", M.SumMessageOp(0, K + 1)), ("max", M.MaxMessageOp(0, K + 1)), ("min", M.MinMessageOp(0, K + 1)),
+               ("simple_weighted a=.85", M.SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85)),
+               ("learnable simple", M.LearnableWeightedMessageOp(0, K + 1, "simple", K).to(device)),
+               ("learnable gate", M.LearnableWeightedMessageOp(0, K + 1, "gate", d).to(device)),
+               ("nafs over_smooth", M.OverSmoothDistanceWeightedOp())]
+        for oname, op in ops:
+            with torch.no_grad():
+                t, _ = timed(lambda: op.aggregate(feats))
+            print(f"SWEEP   msg_op={oname:24s} aggregate_ms={t:8.3f}", flush=True)
+        del feats, csr
+
+
+if __name__ == "__main__":
+    main()
