@@ -130,7 +130,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SGL_BENCH_WORKLOAD", "S1_products"))
-    ap.add_argument("--pieces", type=int, default=4, help="row pieces per rank for comm/compute overlap (N>1)")
+    ap.add_argument("--pieces", type=int, default=2, help="row pieces per rank (N>1): transfers start per piece")
+    ap.add_argument("--col-chunks", type=int, default=2,
+                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
     ap.add_argument("--seed", type=int, default=0)
@@ -141,7 +143,7 @@ def parse_args(argv=None):
 
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     import torch.distributed as dist
-    from sgl_amd.dist import ShardedPropagator, all_piece_bounds
+    from sgl_amd.dist import ShardedPropagator, all_piece_bounds, column_chunks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -192,11 +194,21 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         pb = all_piece_bounds(rp_host, world, args.pieces)
         pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
         prop = ShardedPropagator(pieces, pb, rank, world, n)
-        xbufs = [torch.empty_like(x0) for _ in range(min(2, max(K - 1, 0)))]
-        info = {"n_items": None, "n_pieces": None, "n_long_rows": None}
+        chunks = column_chunks(d, args.col_chunks)
+        info = {"row_pieces": args.pieces, "col_chunks": chunks}
+        nbuf = min(2, max(K - 1, 0))
+        if len(chunks) == 1:
+            xbufs = [torch.empty_like(x0) for _ in range(nbuf)]
 
-        def step():
-            prop.propagate(x0, K, x_buffers=xbufs)
+            def step():
+                prop.propagate(x0, K, x_buffers=xbufs)
+        else:
+            # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
+            x_chunks = [x0[:, a:b].contiguous() for a, b in chunks]
+            cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
+
+            def step():
+                prop.propagate_chunked(x_chunks, K, buffers=cbufs)
     setup_s = time.perf_counter() - t_setup
 
     def sync_all():
@@ -254,7 +266,8 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             "config": {"workload": f"{args.workload}: SGC prop_steps={K} pre-propagation on an ogbn-products-shaped "
                                    f"Chung-Lu graph, LaplacianGraphOp r=0.5",
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
-                       "parallelism": "single GPU" if world == 1 else f"row-sharded x{world} + p2p all-gather, {args.pieces} pieces",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"row-sharded x{world} + grouped p2p all-gather, {args.pieces} row pieces x {args.col_chunks} column chunks",
                        "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
                        "plan": info, "setup_s": round(setup_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",

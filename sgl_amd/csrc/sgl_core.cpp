@@ -23,6 +23,7 @@ static std::mutex g_tune_mu;
 static std::map<std::string, int64_t> &tune_map() {
     static std::map<std::string, int64_t> m = {
         {"spmm_unroll", 0},      // 0 = auto; 1 / 3 / 2 = low / mid / high number of gathers in flight per lane
+        {"spmm_vec", 0},         // 0 = widest legal lane access; 2 / 1 = cap at 8 / 4 bytes per lane
         {"spmm_nt", 0},          // 1 = non-temporal loads for the CSR stream / stores of Y
         {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
         {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)

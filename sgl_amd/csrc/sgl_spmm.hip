@@ -339,6 +339,7 @@ hipError_t launch_u(const SpmmArgs &a, int grid, hipStream_t st, bool nt, int ul
     constexpr int UH = (NCH == 1) ? 8 : (NCH == 2 ? 4 : 2);
     constexpr int UL = UH / 2;
     if (ulevel == 2) return launch_nt<VEC, GROUP, NCH, UH * 2 / (NCH == 1 ? 1 : 2)>(a, grid, st, nt);
+    if (ulevel == 3) return launch_nt<VEC, GROUP, NCH, (NCH == 1 && GROUP == 64) ? 32 : UH>(a, grid, st, nt);
     return ulevel == 0 ? launch_nt<VEC, GROUP, NCH, UL>(a, grid, st, nt) : launch_nt<VEC, GROUP, NCH, UH>(a, grid, st, nt);
 }
 
@@ -501,6 +502,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     if (un == 1) ulevel = 0;
     if (un == 2) ulevel = 2;
     if (un == 3) ulevel = 1;
+    if (un == 4) ulevel = 3;   // 32 gathers in flight (one-row-per-step layout only)
     const bool nt = sgl::tuning("spmm_nt", 0) != 0;
     int waves = (int)sgl::tuning("spmm_waves", 0);
     if (waves != 1 && waves != 2 && waves != 4) waves = 4;
@@ -583,6 +585,8 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
     hipStream_t st = sgl::as_stream(stream);
     // one launch covers up to 64 lanes x 4 chunks x VEC columns; wider matrices go in column slices
     int vec = pick_vec(d_x, ldx, d_y, ldy, d);
+    const int64_t vcap = sgl::tuning("spmm_vec", 0);   // experiments: cap the lane width (2 or 1 floats)
+    if ((vcap == 1 || vcap == 2) && vcap < vec) vec = (int)vcap;
     if (eh.on && eh.res) {
         SGL_REQUIRE(eh.ldres >= d && aligned_to(eh.res, 4), "%s: bad residual matrix", who);
         if (vec == 4 && !(eh.ldres % 4 == 0 && aligned_to(eh.res, 16))) vec = (eh.ldres % 2 == 0 && aligned_to(eh.res, 8) && d % 2 == 0) ? 2 : 1;

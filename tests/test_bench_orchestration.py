@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TINY = {"T_tiny": dict(n=3000, m=20_000, d_max=300, d=12, k=3)}
+TINY = {"T_tiny": dict(n=3000, m=20_000, d_max=300, d=40, k=3)}
 
 
 def _free_port():
@@ -86,7 +86,7 @@ def _worker(rank, world, port, out_dir):
                       MASTER_PORT=str(port))
     import bench
     args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_tiny",
-                             "--pieces", "3", "--no-cpu-baseline"])
+                             "--pieces", "3", "--col-chunks", "2", "--no-cpu-baseline"])
     lines = []
     out = bench.run(args, engine_cls=_make_engine(), workloads=TINY, emit=lines.append)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

@@ -59,6 +59,14 @@ def _worker(rank, world, port, pieces, K, d, out_dir):
         # second call reuses nothing stale (buffers are ping-ponged per call)
         hops2 = prop.propagate(x, K)
         ok = ok and all(torch.equal(a, b) for a, b in zip(hops, hops2))
+        # column-chunked, software-pipelined schedule gives the same numbers (SpMM is separable over columns)
+        from sgl_amd.dist import column_chunks
+        for chunks in (column_chunks(d, 2), [(0, 3), (3, 4), (4, d)]):
+            xs = [x[:, a:b].contiguous() for a, b in chunks]
+            hc = prop.propagate_chunked(xs, K)
+            for h in range(K + 1):
+                got = torch.cat(hc[h], dim=1)
+                ok = ok and np.array_equal(got.numpy(), ref[h][lo:hi])
         with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
             f.write("ok" if ok else "mismatch")
     finally:

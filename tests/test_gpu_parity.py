@@ -612,6 +612,31 @@ def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
         assert np.array_equal(hops[h].cpu().numpy(), ref[h])
 
 
+def test_int64_offsets_beyond_2_31_elements(cuda):
+    """papers100M-shard shape: the dense operand has more than 2^31 elements (the reference's `int` offsets overflow
+    there, matmul.c:29,33) and the gathered rows sit at byte offsets beyond 8 GiB"""
+    from sgl_amd.device import DeviceCSR
+    free, _ = torch.cuda.mem_get_info()
+    n_cols, d = (40_000_000, 64) if free > 40e9 else (9_000_000, 256)
+    assert n_cols * d > 2 ** 31
+    rows, deg = 4096, 24
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.empty((n_cols, d), device=cuda)
+    x.normal_(generator=g)
+    # columns concentrated at the far end of the table, plus a few at the start
+    hi = torch.randint(n_cols - 1000, n_cols, (rows, deg - 2), generator=g, device=cuda)
+    lo = torch.randint(0, 1000, (rows, 2), generator=g, device=cuda)
+    cols = torch.cat([lo, hi], 1).sort(dim=1).values.to(torch.int32).reshape(-1).contiguous()
+    vals = torch.rand(rows * deg, generator=g, device=cuda) + 0.5
+    rowptr = torch.arange(0, rows + 1, device=cuda, dtype=torch.int64) * deg
+    for strict in (True, False):
+        y = DeviceCSR(rowptr, cols, vals, (rows, n_cols), strict=strict).spmm(x)
+        ref = (x[cols.long()].double() * vals.double()[:, None]).view(rows, deg, d).sum(1)
+        err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-6, err
+    del x
+
+
 # ---- full-size, size-independent properties ------------------------------------------------------------------
 def test_products_scale_properties(cuda):
     """ogbn-products-shaped graph (N = 2.45 M, nnz ~ 126 M, d = 100): sampled rows against the oracle, linearity,

@@ -68,7 +68,7 @@ def main():
                 cur = out
         return f
 
-    knobs = ("spmm_unroll", "spmm_nt", "spmm_group", "spmm_waves", "spmm_xcd_remap")
+    knobs = ("spmm_unroll", "spmm_nt", "spmm_group", "spmm_waves", "spmm_xcd_remap", "spmm_vec")
     saved = {k: _lib.get_tuning(k) for k in knobs}
 
     def set_knobs(**kw):
@@ -219,6 +219,15 @@ def main():
             print(f"EXP relabel2 hot_columns_first xcd_remap={remap} ms_per_hop={ms:.3f}", flush=True)
         set_knobs()
         del c, c2, v2, x2
+
+    if "vec" in exps:
+        for vec in (0, 2):
+            for unroll in (3, 2, 4):
+                for nt in (0, 1):
+                    set_knobs(spmm_vec=vec, spmm_unroll=unroll, spmm_nt=nt)
+                    ms = time_hops(lambda: base.spmm(x0, out=bufs[0]), reps=7, warm=2)
+                    print(f"EXP vec vec={vec} unroll={unroll} nt={nt} ms_per_hop={ms:.3f}", flush=True)
+        set_knobs()
 
     if "uns" in exps:
         # unroll x group per width (default-selection table)
