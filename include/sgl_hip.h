@@ -18,6 +18,8 @@
  *   sgl_norm_*                 adj_to_symmetric_norm (sgl/operators/utils.py:76-88) + the Laplacian / PPR
  *                              _construct_adj wrappers (graph_op/laplacian_graph_op.py:12-19,
  *                              graph_op/ppr_graph_op.py:13-21), on device.
+ *   sgl_coo_to_csr             the csr_matrix((w,(row,col))) adjacency build of Edge (sgl/data/base_data.py:29) that turns a
+ *                              raw adj_matrix.npz{row,col,data} dump (dataset/custom_dataset.py:52-54) into the CSR.
  *   sgl_hop_reduce_f32         Sum/Mean/Max/Min MessageOp._combine (message_op/{sum,mean,max,min}_message_op.py)
  *                              and one_dim_weighted_add (sgl/operators/utils.py:91-102).
  *   sgl_hop_wsum2d_f32(+_bwd)  two_dim_weighted_add (sgl/operators/utils.py:105-116, torch.bmm) and its autograd.
@@ -132,6 +134,15 @@ int sgl_norm_prepare(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int3
 int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
                      double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
                      int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream);
+
+/* ---- ingest: COO edge list -> canonical CSR on device (sgl/data/base_data.py:29, dataset/custom_dataset.py:52-54) ---- */
+/* d_row / d_col: int64 [nnz] (the reference keeps them as torch.LongTensor), d_val float32 [nnz].  Duplicate (row,col)
+ * pairs are summed in input order (fp32), columns come out sorted inside each row -- what scipy's
+ * csr_matrix((data,(row,col))) produces.  Outputs: d_out_rowptr [n_rows+1]; d_out_col / d_out_val sized for nnz
+ * entries, the first *h_nnz_out of them are valid.  Synchronises `stream`.  Fails on an out-of-range index. */
+int sgl_coo_to_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_row, const int64_t *d_col,
+                   const float *d_val, int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val, int64_t *h_nnz_out,
+                   void *stream);
 
 /* ---- per-hop aggregators (MessageOp._combine) -------------------------------------------------------------- */
 #define SGL_REDUCE_SUM 0  /* ((X0 + X1) + X2) + ...            sum_message_op.py:10   */

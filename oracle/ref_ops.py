@@ -20,7 +20,7 @@ __all__ = [
     "agg_simple_weighted", "learnable_weights", "agg_learnable_weighted",
     "agg_iterate_learnable", "nafs_weights", "agg_over_smooth_distance",
     "sigmoid32", "softmax32", "parity_ok", "parity_report",
-    "label_propagation", "cs_correct", "cs_smooth", "nafs_task_features",
+    "label_propagation", "cs_correct", "cs_smooth", "nafs_task_features", "coo_to_csr",
 ]
 
 # ----------------------------------------------------------------------------------------------
@@ -447,6 +447,29 @@ def nafs_task_features(indptr, indices, data, n, x, hops, r_list, method):
     if method == "max":
         return agg_max(per_r, 0, len(per_r))
     return np.hstack(per_r)
+
+
+def coo_to_csr(row, col, data, n):
+    """Edge's csr_matrix((w,(row,col)), shape=(n,n)) (sgl/data/base_data.py:29): float32, duplicates summed in input
+    order, sorted columns.  Returns (indptr int64, indices int32, values float32)."""
+    row = np.asarray(row, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    data = np.asarray(data, dtype=np.float32)
+    order = np.argsort(row * n + col, kind="stable")
+    r, c, v = row[order], col[order], data[order]
+    head = np.ones(len(r), dtype=bool)
+    head[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+    starts = np.flatnonzero(head)
+    ends = np.append(starts[1:], len(r))
+    vals = np.empty(len(starts), dtype=np.float32)
+    for k, (a, b) in enumerate(zip(starts, ends)):      # sequential fp32 adds, input order
+        acc = v[a]
+        for j in range(a + 1, b):
+            acc = np.float32(acc + v[j])
+        vals[k] = acc
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r[head], minlength=n), out=indptr[1:])
+    return indptr, c[head].astype(np.int32), vals
 
 
 # ----------------------------------------------------------------------------------------------

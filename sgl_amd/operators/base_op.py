@@ -46,8 +46,16 @@ class GraphOp:
 
     def _device_adj(self, adj):
         """normalise `adj` on the GPU (cached per matrix) -> DeviceCSR of A_hat"""
+        from ..io import DeviceAdjacency
         from .utils import adj_to_symmetric_norm_device
         r, alpha = self._norm_params()
+        if isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
+            key = ("dev", id(adj), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.nnz, r, alpha, bool(self._opt("strict_order")))
+            if self._opt("cache_adj") and key == self._adj_key and self._adj is not None:
+                return self._adj
+            rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, adj.shape[0], r, alpha)
+            self._adj_key = key if self._opt("cache_adj") else None
+            return dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
         key = None
         if self._opt("cache_adj"):
             key = (_fingerprint(adj), r, alpha, bool(self._opt("strict_order")), str(self._opt("device")))
@@ -61,7 +69,8 @@ class GraphOp:
     def propagate(self, adj, feature):
         self._adj = self._construct_adj(adj)
 
-        if not isinstance(adj, sp.csr_matrix):
+        from ..io import DeviceAdjacency
+        if not isinstance(adj, (sp.csr_matrix, DeviceAdjacency)):
             raise TypeError("The adjacency matrix must be a scipy csr sparse matrix!")
         elif not isinstance(feature, np.ndarray) and not (isinstance(feature, Tensor) and not self._opt("strict_types")):
             raise TypeError("The feature matrix must be a numpy.ndarray!")

@@ -13,6 +13,7 @@ class LaplacianGraphOp(GraphOp):
         return self.__r, None
 
     def _construct_adj(self, adj):
-        if not isinstance(adj, (sp.csr_matrix, sp.coo_matrix)):
+        from ...io import DeviceAdjacency
+        if not isinstance(adj, (sp.csr_matrix, sp.coo_matrix, DeviceAdjacency)):
             raise TypeError("The adjacency matrix must be a scipy.sparse.coo_matrix/csr_matrix!")
         return self._device_adj(adj)

@@ -15,6 +15,7 @@ class PprGraphOp(GraphOp):
         return self.__r, self.__alpha
 
     def _construct_adj(self, adj):
-        if not isinstance(adj, (sp.csr_matrix, sp.coo_matrix)):
+        from ...io import DeviceAdjacency
+        if not isinstance(adj, (sp.csr_matrix, sp.coo_matrix, DeviceAdjacency)):
             raise TypeError("The adjacency matrix must be a scipy.sparse.coo_matrix/csr_matrix!")
         return self._device_adj(adj)

@@ -429,6 +429,27 @@ def gen_g6():
     np.savez_compressed(os.path.join(HERE, "g6_consumers.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+# G7: ingest -- the reference's Edge (sgl/data/base_data.py:8-30) turning COO arrays into the CSR adjacency
+# ------------------------------------------------------------------------------------------
+def gen_g7():
+    import sgl.dataset  # noqa: F401  (circular import: must precede sgl.data)
+    from sgl.data.base_data import Edge
+    rng = np.random.default_rng(11)
+    n, m = 500, 6000
+    row = rng.integers(0, n, m)
+    col = rng.integers(0, n, m)
+    row[:300], col[:300] = row[300:600], col[300:600]          # 300 duplicated pairs
+    row[600:620], col[600:620] = 7, 9                            # one pair repeated 20 times
+    w = rng.uniform(0.1, 2.0, m).astype(np.float32)
+    e = Edge(row, col, w, "n__to__n", n)
+    a = e.sparse_matrix
+    a.sum_duplicates()
+    a.sort_indices()
+    np.savez_compressed(os.path.join(HERE, "g7_ingest.npz"), row=row, col=col, data=w, n=n,
+                        indptr=a.indptr.astype(np.int64), indices=a.indices.astype(np.int32), values=a.data.astype(np.float32))
+
+
 def main():
     save_graphs()
     gen_g1()
@@ -440,6 +461,7 @@ def main():
     gen_g4(mods)
     gen_g5()
     gen_g6()
+    gen_g7()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

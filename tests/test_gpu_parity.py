@@ -612,6 +612,33 @@ def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
         assert np.array_equal(hops[h].cpu().numpy(), ref[h])
 
 
+def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
+    """Custom_Homo raw layout -> device COO->CSR build (sgl_coo_to_csr) == the reference's Edge/scipy build (G7),
+    and a DeviceAdjacency drives GraphOp.propagate without touching the host"""
+    from sgl_amd import io
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g7 = goldens.npz("g7_ingest")
+    n = int(g7["n"])
+    x = hash_matrix(n, 20, seed=2)
+    io.save_custom_homo_raw(str(tmp_path), g7["row"], g7["col"], g7["data"], x=x, labels=np.arange(n) % 3,
+                            train_idx=np.arange(0, n, 2))
+    ds = io.load_custom_homo_raw(str(tmp_path), device=cuda)
+    adj = ds["adj"]
+    assert np.array_equal(adj.rowptr.cpu().numpy(), g7["indptr"]) and np.array_equal(adj.col.cpu().numpy(), g7["indices"])
+    v = adj.val.cpu().numpy()
+    assert (v != g7["values"]).sum() <= 2 and np.allclose(v, g7["values"], rtol=3e-7, atol=0)
+    assert ds["y"].shape == (n,) and len(ds["train_idx"]) == n // 2 and ds["val_idx"] is None
+    hops = LaplacianGraphOp(2, strict_order=True).propagate(adj, ds["x"])
+    ref = oracle.propagate(oracle.laplacian_adj(g7["indptr"], g7["indices"], v, n, 0.5), x, 2)
+    assert oracle.parity_ok(hops[2].cpu().numpy(), ref[2], TOL)
+    hops2 = LaplacianGraphOp(2, strict_order=True).propagate(adj.to_scipy(), ds["x"])        # same through scipy
+    assert torch.equal(hops[2], hops2[2])
+    with pytest.raises(Exception):
+        io.coo_to_csr_device([0, n], [0, 1], [1.0, 1.0], n, device=cuda)                       # index out of range
+    empty = io.coo_to_csr_device([], [], [], 5, device=cuda)
+    assert empty.nnz == 0 and empty.rowptr.cpu().tolist() == [0] * 6
+
+
 def test_int64_offsets_beyond_2_31_elements(cuda):
     """papers100M-shard shape: the dense operand has more than 2^31 elements (the reference's `int` offsets overflow
     there, matmul.c:29,33) and the gathered rows sit at byte offsets beyond 8 GiB"""

@@ -162,3 +162,14 @@ def test_g6_nafs_task_pipeline(goldens):
         y = oracle.nafs_task_features(g.indptr, g.indices, g.data, 256, x, 3, [0.5, 0.4, 0.3, 0.2, 0.1, 0], method)
         rep = oracle.parity_report(y, g6[f"nafs_task|{method}|hops3"], 1e-5)
         assert rep["ok"], (method, rep)
+
+
+def test_g7_ingest_coo_to_csr(goldens):
+    g7 = goldens.npz("g7_ingest")
+    n = int(g7["n"])
+    ptr, idx, val = oracle.coo_to_csr(g7["row"], g7["col"], g7["data"], n)
+    assert np.array_equal(ptr, g7["indptr"]) and np.array_equal(idx, g7["indices"])     # structure: bit exact
+    # scipy sorts duplicates with an UNSTABLE sort before adding them, so runs of >= 3 equal pairs may be summed in a
+    # different order: 1 ulp there, exact everywhere else
+    diff = val != g7["values"]
+    assert diff.sum() <= 2 and np.allclose(val, g7["values"], rtol=3e-7, atol=0)
