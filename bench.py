@@ -104,12 +104,11 @@ class GpuEngine:
         bufs = [dev.alloc_rows(n, d, self.device) for _ in range(K)]
         src0 = dev.upload_rows(x0, self.device) if (d % 4) else x0
 
+        x_in = dev.padded_parent(src0)
+        outs = [dev.padded_parent(b) for b in bufs]
+
         def step():
-            cur = dev.padded_parent(src0)
-            for h in range(K):
-                out = dev.padded_parent(bufs[h])
-                csr.spmm(cur, out=out)
-                cur = out
+            csr.spmm_chain(x_in, K, outs=outs)     # the k SpMM launches of one propagate(), issued from one call
         return step, csr.info()
 
     def piece_spmms(self, args, rowptr, col, val, n, my_bounds, rp_host):

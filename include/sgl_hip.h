@@ -106,6 +106,11 @@ int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
 int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                  int accumulate, void *stream);
 
+/* The hop loop of GraphOp.propagate (sgl/operators/base_op.py:29-35) in one call: Y_1 = A.X_0, Y_k = A.Y_{k-1}.
+ * h_y / h_ldy: HOST arrays of n_hops device pointers / leading dimensions.  A must be square. */
+int sgl_spmm_chain_f32(sgl_csr_t *csr, int n_hops, const float *d_x0, int64_t ldx0, float *const *h_y,
+                       const int64_t *h_ldy, int64_t d, void *stream);
+
 /* Fused label-propagation step (sgl/tricks/utils.py:55-56, the inner loop of label_propagation and of
  * CorrectAndSmooth):  Y = clamp( alpha * (A . X) + RES, lo, hi )  with the reference's rounding order (rounded product,
  * rounded add, clamp that keeps NaN).  d_res may be NULL (no residual); lo = -INF / hi = +INF disable the clamp. */

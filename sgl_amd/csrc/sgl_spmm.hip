@@ -394,7 +394,12 @@ SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, i
     SGL_HIP_CHECK(hipStreamSynchronize(st));
     SGL_REQUIRE(h_rowptr[0] == 0 && h_rowptr[n_rows] == nnz, "sgl_csr_create: rowptr[0]=%lld rowptr[n]=%lld but nnz=%lld",
                 (long long)h_rowptr[0], (long long)h_rowptr[n_rows], (long long)nnz);
-    if (item_nnz <= 0) item_nnz = sgl::kDefaultItemNnz;
+    if (item_nnz <= 0) {
+        // one wavefront per item: small matrices get smaller items so that the chip (256 CUs x 4 SIMDs x 8 waves)
+        // still sees enough wavefronts to hide memory latency; large ones use the 512-nnz default
+        const int64_t want_items = 256 * 4 * 8;
+        item_nnz = (int32_t)std::min<int64_t>(sgl::kDefaultItemNnz, std::max<int64_t>(32, nnz / want_items));
+    }
     if (long_row_nnz == 0) long_row_nnz = sgl::kDefaultLongRowNnz;
     if (flags & SGL_CSR_STRICT_ORDER) long_row_nnz = -1;
     sgl::Plan plan;
@@ -606,6 +611,24 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
 SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                             int accumulate, void *stream) {
     return spmm_impl(h, d_x, ldx, d_y, ldy, d, accumulate, stream, EpiHost(), "sgl_spmm_f32");
+}
+
+// X_1 = A X_0, X_2 = A X_1, ... : the whole hop loop of GraphOp.propagate (base_op.py:29-35) issued from one call, so a
+// small graph (Pubmed: tens of microseconds of kernel time per hop) is not dominated by per-hop host overhead.
+SGL_EXPORT int sgl_spmm_chain_f32(sgl_csr_t *h, int n_hops, const float *d_x0, int64_t ldx0, float *const *h_y,
+                                  const int64_t *h_ldy, int64_t d, void *stream) {
+    if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_spmm_chain_f32: NULL handle");
+    SGL_REQUIRE(n_hops >= 0 && (n_hops == 0 || (h_y && h_ldy)), "sgl_spmm_chain_f32: bad hop arrays");
+    SGL_REQUIRE(n_hops == 0 || h->n_rows == h->n_cols, "sgl_spmm_chain_f32: repeated products need a square matrix");
+    const float *cur = d_x0;
+    int64_t ldc = ldx0;
+    for (int k = 0; k < n_hops; ++k) {
+        int rc = spmm_impl(h, cur, ldc, h_y[k], h_ldy[k], d, 0, stream, EpiHost(), "sgl_spmm_chain_f32");
+        if (rc != SGL_OK) return rc;
+        cur = h_y[k];
+        ldc = h_ldy[k];
+    }
+    return SGL_OK;
 }
 
 SGL_EXPORT int sgl_spmm_axpb_clamp_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,

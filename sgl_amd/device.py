@@ -124,6 +124,30 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
+    def spmm_chain(self, x, n_hops, outs=None):
+        """[A x, A^2 x, ..., A^k x] with ONE library call (the hop loop runs in C).  x: [n, d] row-major CUDA; the
+        results are row-padded buffers of the same width as x (or the caller's `outs`)."""
+        _check_mat(x, "x")
+        if x.shape[0] != self.shape[1] or self.shape[0] != self.shape[1]:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        d = x.shape[1]
+        if outs is None:
+            outs = [alloc_rows(self.shape[0], d, x.device, zero_pad=True) for _ in range(n_hops)]
+        else:
+            if len(outs) != n_hops:
+                raise ValueError("need one output matrix per hop")
+            for o in outs:
+                _check_mat(o, "outs[*]")
+                if o.shape != (self.shape[0], d):
+                    raise ValueError("an output matrix has the wrong shape")
+        if n_hops:
+            ptrs = (c_void_p * n_hops)(*[o.data_ptr() for o in outs])
+            lds = (c_int64 * n_hops)(*[_ld(o) for o in outs])
+            with torch.cuda.device(self.device):
+                check(lib().sgl_spmm_chain_f32(self._h, n_hops, ptr(x), _ld(x), ptrs, lds, d, current_stream_ptr()),
+                      "sgl_spmm_chain_f32")
+        return outs
+
     def spmm_axpb_clamp(self, x, alpha, res=None, lo=float("-inf"), hi=float("inf"), out=None):
         """out = clamp(alpha * (A @ x) + res, lo, hi) in one kernel (the label-propagation step)"""
         _check_mat(x, "x")

@@ -87,12 +87,11 @@ class GraphOp:
         cur = dev.upload_rows(feature, device) if x0 is None else x0
         if (cur.shape[1] > 1 and cur.stride(1) != 1) or cur.stride(0) % 4 != 0 or cur.data_ptr() % 16 != 0:
             cur = dev.upload_rows(cur, device)  # re-pack into an aligned, row-padded buffer
-        prop_feat_list = [cur]
-        for _ in range(self._prop_steps):
-            # run over the padded width so every d gets 16-byte lanes (pad columns are zeros and stay zeros)
-            src = dev.padded_parent(prop_feat_list[-1]) if prop_feat_list[-1].stride(0) % 4 == 0 else prop_feat_list[-1]
-            dst = self._adj.spmm(src)
-            prop_feat_list.append(dst[:, :cur.shape[1]] if dst.shape[1] != cur.shape[1] else dst)
+        # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns
+        # are zeros and stay zeros under propagation)
+        src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
+        d = cur.shape[1]
+        prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
 
         if self._opt("host_output"):
             out = [f.cpu() for f in prop_feat_list]

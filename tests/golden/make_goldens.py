@@ -266,7 +266,8 @@ def import_models():
         spec.loader.exec_module(mod)
         return mod
 
-    return {n: load(n) for n in ("sgc", "ssgc", "sign", "gbp", "gamlp", "gamlp_recursive", "nafs", "pasca_v3")}
+    return {n: load(n) for n in ("sgc", "ssgc", "sign", "gbp", "gamlp", "gamlp_recursive", "nafs", "pasca_v1", "pasca_v2",
+                                 "pasca_v3")}
 
 
 def gen_g3_proj(out):
@@ -297,6 +298,8 @@ def gen_g4(mods):
         "GAMLP": (mods["gamlp"].GAMLP, (K, d, C, 32, 2)),
         "GAMLPRecursive": (mods["gamlp_recursive"].GAMLPRecursive, (K, d, C, 32, 2)),
         "NAFS": (mods["nafs"].NAFS, (K, d, C)),
+        "PASCA_V1": (mods["pasca_v1"].PASCA_V1, (K, d, C, 32, 3)),
+        "PASCA_V2": (mods["pasca_v2"].PASCA_V2, (K, d, C, 32, 3)),
         "PASCA_V3": (mods["pasca_v3"].PASCA_V3, (K, 2, d, C, 32, 3)),
     }
     for name, (cls, args) in specs.items():

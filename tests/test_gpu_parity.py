@@ -146,6 +146,25 @@ def test_spmm_accumulate_and_overwrite_semantics(goldens, cuda):
                 assert oracle.parity_ok(z.cpu().numpy(), ref_ovw, TOL)
 
 
+def test_spmm_chain_equals_repeated_spmm(goldens, cuda):
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    csr = device_csr(ptr, col, val, (n, n), cuda, strict=True)
+    for d in (100, 7):
+        x = torch.from_numpy(hash_matrix(n, d, seed=5)).to(cuda)
+        chain = csr.spmm_chain(x, 4)
+        cur = x
+        for k in range(4):
+            cur = csr.spmm(cur)
+            assert torch.equal(chain[k], cur)
+        pre = [torch.empty((n, d), device=cuda) for _ in range(2)]
+        got = csr.spmm_chain(x, 2, outs=pre)
+        assert got[1].data_ptr() == pre[1].data_ptr() and torch.equal(pre[1], chain[1])
+    assert csr.spmm_chain(x, 0) == []
+    rect = device_csr(ptr[:11] - ptr[0], col[:ptr[10]], val[:ptr[10]], (10, n), cuda)
+    with pytest.raises(ValueError):
+        rect.spmm_chain(x, 2)
+
+
 def test_spmm_rectangular_shard_and_degenerate_shapes(goldens, cuda):
     n, ptr, col, val = norm_graph(goldens, "pl2000")
     x = hash_matrix(n, 100, seed=8)
@@ -495,7 +514,7 @@ def test_models_match_reference_goldens(goldens, cuda):
     idx = g4["idx"]
     ctor = {"SGC": (K, d, C), "SSGC": (K, d, C), "SIGN": (K, d, C, 32, 2), "GBP": (K, d, C, 32, 2),
             "GAMLP": (K, d, C, 32, 2), "GAMLPRecursive": (K, d, C, 32, 2), "NAFS": (K, d, C),
-            "PASCA_V3": (K, 2, d, C, 32, 3)}
+            "PASCA_V1": (K, d, C, 32, 3), "PASCA_V2": (K, d, C, 32, 3), "PASCA_V3": (K, 2, d, C, 32, 3)}
     for name, args in ctor.items():
         model = getattr(homo, name)(*args)
         model.load_state_dict({k.split("|param|")[1]: torch.from_numpy(v) for k, v in g4.items() if k.startswith(name + "|param|")})

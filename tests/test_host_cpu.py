@@ -198,7 +198,7 @@ def test_model_state_dicts_interchange_with_reference(goldens):
     K, d, C = 3, 16, 5
     ctor = {"SGC": (K, d, C), "SSGC": (K, d, C), "SIGN": (K, d, C, 32, 2), "GBP": (K, d, C, 32, 2),
             "GAMLP": (K, d, C, 32, 2), "GAMLPRecursive": (K, d, C, 32, 2), "NAFS": (K, d, C),
-            "PASCA_V3": (K, 2, d, C, 32, 3)}
+            "PASCA_V1": (K, d, C, 32, 3), "PASCA_V2": (K, d, C, 32, 3), "PASCA_V3": (K, 2, d, C, 32, 3)}
     for name, args in ctor.items():
         model = getattr(homo, name)(*args)
         ref_keys = sorted(k.split("|param|")[1] for k in g4 if k.startswith(name + "|param|"))
