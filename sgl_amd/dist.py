@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "device_piece_spmms", "column_chunks",
-           "ShardedPropagator"]
+           "ShardedPropagator", "ShardedGraphOp"]
 
 
 def balanced_bounds(rowptr, parts):
@@ -187,3 +187,73 @@ class ShardedPropagator:
                 outs.append(y_local)
             hops.append(outs)
         return hops
+
+
+
+class ShardedGraphOp:
+    """GraphOp.propagate for one rank of a row-sharded job (BASELINE configs 4/5: NAFS / PaSca sweeps with the
+    adjacency row-sharded across the GPUs of a node).
+
+    Every rank passes the SAME full adjacency (scipy CSR or sgl_amd.io.DeviceAdjacency; it is normalised on the
+    rank's own GPU -- identical kernels on identical inputs, so all ranks hold bit-identical A_hat) and the same full
+    feature matrix, and gets back the K+1 hop matrices restricted to ITS rows `[self.lo, self.hi)`.  MessageOps are
+    row-wise, so they apply to the local shards unchanged (e.g. OverSmoothDistanceWeightedOp for NAFS).
+    288 GB per GPU make the replication affordable up to ogbn-papers100M (27 GB of CSR, two 57 GB feature replicas).
+
+    Works without torch.distributed (world size 1); with it, uses the default process group unless `group` is given."""
+
+    def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None, device=None):
+        self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
+        self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
+        self.device = device
+        self.lo = self.hi = None
+        self._cache = None
+
+    def _ranks(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def propagate(self, adj, feature):
+        from . import device as dev
+        from .io import DeviceAdjacency
+        rank, world = self._ranks()
+        device = torch.device(self.device or ("cuda", torch.cuda.current_device()))
+        if not isinstance(adj, DeviceAdjacency):
+            adj = DeviceAdjacency.from_scipy(adj, device=device)
+        n = adj.shape[0]
+        key = (id(adj), adj.col.data_ptr(), adj.nnz, world, rank)
+        if self._cache is None or self._cache[0] != key:
+            rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, n, self.r, self.alpha)
+            rp_host = rowptr.cpu().numpy()
+            pb = all_piece_bounds(rp_host, world, self.pieces)
+            fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rank], rowptr_host=rp_host, strict=self.strict_order)
+            self._cache = (key, ShardedPropagator(fns, pb, rank, world, n, group=self.group), handles)
+        prop = self._cache[1]
+        self.lo, self.hi = prop.lo, prop.hi
+        x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
+        x = x.to(device=device, dtype=torch.float32).contiguous()
+        if x.shape[0] != n:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
+        if len(chunks) == 1:
+            return prop.propagate(x, self.prop_steps)
+        hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+        return [torch.cat(h, dim=1) for h in hops]
+
+    def gather_rows(self, local):
+        """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (e.g. the final aggregated features)"""
+        rank, world = self._ranks()
+        if world == 1:
+            return local
+        prop = self._cache[1]
+        full = torch.empty((prop.n, local.shape[1]), dtype=local.dtype, device=local.device)
+        full[prop.lo:prop.hi].copy_(local)
+        ops = []
+        for k in range(1, world):
+            dst, src = (rank + k) % world, (rank - k) % world
+            ops.append(dist.P2POp(dist.isend, local.contiguous(), dst, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, full[int(prop.pb[src, 0]):int(prop.pb[src, -1])], src, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return full

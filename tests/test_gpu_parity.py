@@ -631,6 +631,25 @@ def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
         assert np.array_equal(hops[h].cpu().numpy(), ref[h])
 
 
+def test_sharded_graph_op_world1_and_nafs_on_shards(goldens, cuda):
+    """BASELINE config 4 flow on one rank: ShardedGraphOp == LaplacianGraphOp, NAFS on the local rows == NAFS on all"""
+    from sgl_amd.dist import ShardedGraphOp
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    from sgl_amd.operators.message_op import OverSmoothDistanceWeightedOp
+    g = goldens.graph("pl2000")
+    x = hash_matrix(2000, 100, seed=12)
+    for op, ref_op in ((ShardedGraphOp(4, r=0.5, strict_order=True), LaplacianGraphOp(4, r=0.5, strict_order=True)),
+                       (ShardedGraphOp(3, r=0.5, alpha=0.2, strict_order=True, pieces=3), PprGraphOp(3, r=0.5, alpha=0.2, strict_order=True))):
+        hops = op.propagate(g, x)
+        ref = ref_op.propagate(g, x)
+        assert (op.lo, op.hi) == (0, 2000) and len(hops) == len(ref)
+        for a, b in zip(hops, ref):
+            assert torch.equal(a, b)
+        nafs = OverSmoothDistanceWeightedOp()
+        assert torch.equal(nafs.aggregate([h.contiguous() for h in hops]), nafs.aggregate(ref))
+        assert op.gather_rows(hops[-1]) is hops[-1]
+
+
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
     """Custom_Homo raw layout -> device COO->CSR build (sgl_coo_to_csr) == the reference's Edge/scipy build (G7),
     and a DeviceAdjacency drives GraphOp.propagate without touching the host"""
