@@ -218,7 +218,7 @@ class ShardedGraphOp:
         from . import device as dev
         from .io import DeviceAdjacency
         rank, world = self._ranks()
-        device = torch.device(self.device or ("cuda", torch.cuda.current_device()))
+        device = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         if not isinstance(adj, DeviceAdjacency):
             adj = DeviceAdjacency.from_scipy(adj, device=device)
         n = adj.shape[0]
