@@ -1,12 +1,4 @@
-from .gamlp import GAMLP
-from .gamlp_recursive import GAMLPRecursive
-from .gbp import GBP
-from .nafs import NAFS
-from .pasca_v1 import PASCA_V1
-from .pasca_v2 import PASCA_V2
-from .pasca_v3 import PASCA_V3
-from .sgc import SGC
-from .sign import SIGN
-from .ssgc import SSGC
+"""SGL's homogeneous SGAP models on the MI355X path (same class names / signatures as sgl.models.homo)."""
+from .zoo import GAMLP, GBP, NAFS, PASCA_V1, PASCA_V2, PASCA_V3, SGC, SIGN, SSGC, GAMLPRecursive
 
-__all__ = ["SGC", "SSGC", "SIGN", "GBP", "GAMLP", "GAMLPRecursive", "NAFS", "PASCA_V1", "PASCA_V2", "PASCA_V3"]
+__all__ = ["GAMLP", "GAMLPRecursive", "GBP", "NAFS", "PASCA_V1", "PASCA_V2", "PASCA_V3", "SGC", "SIGN", "SSGC"]

@@ -1,0 +1,54 @@
+"""The parameter-free hop aggregators: last / concat / sum / mean / max / min.
+
+Reference classes: sgl/operators/message_op/{last,concat,sum,mean,max,min}_message_op.py (each a 10-line file around
+one torch expression: `feat_list[-1]`, `hstack`, Python `sum()`, `sum()/H`, `stack().max(0)[0]`, `stack().min(0)[0]`).
+Here the four reductions are ONE streaming HIP kernel (sgl_hop_reduce_f32: a single pass over the H hop matrices,
+no [H, N, d] stack is ever materialised) and concat is a strided copy kernel; results are bit-identical to the
+reference's (same left-to-right order, one true division for mean, NaN-propagating max/min)."""
+from ... import device as dev
+from ..base_op import MessageOp
+from ._common import back_home, device_hops, no_grad_inputs, reduce_hops
+
+
+class LastMessageOp(MessageOp):
+    """the deepest hop, untouched (and un-copied): ignores start / end like the reference"""
+
+    def __init__(self):
+        super(LastMessageOp, self).__init__()
+        self._aggr_type = "last"
+
+    def _combine(self, feat_list):
+        return feat_list[-1]
+
+
+class ConcatMessageOp(MessageOp):
+    """[X_start | ... | X_{end-1}] side by side -> [n, (end-start) d]"""
+
+    def __init__(self, start, end):
+        super(ConcatMessageOp, self).__init__(start, end)
+        self._aggr_type = "concat"
+
+    def _combine(self, feat_list):
+        feats, home = device_hops(feat_list[self._start:self._end])
+        no_grad_inputs(feats, "concat")
+        return back_home(dev.hop_concat(feats), home)
+
+
+def _reduction(kind, doc):
+    class _Op(MessageOp):
+        def __init__(self, start, end):
+            super(_Op, self).__init__(start, end)
+            self._aggr_type = kind
+
+        def _combine(self, feat_list):
+            return reduce_hops(kind, feat_list[self._start:self._end])
+
+    _Op.__name__ = _Op.__qualname__ = kind.capitalize() + "MessageOp"
+    _Op.__doc__ = doc
+    return _Op
+
+
+SumMessageOp = _reduction("sum", "X_start + ... + X_{end-1}, accumulated left to right")
+MeanMessageOp = _reduction("mean", "the hop sum followed by one true division by (end - start)")
+MaxMessageOp = _reduction("max", "element-wise maximum over the hops (NaN propagates, like torch.max)")
+MinMessageOp = _reduction("min", "element-wise minimum over the hops (NaN propagates, like torch.min)")
