@@ -146,6 +146,44 @@ def test_spmm_accumulate_and_overwrite_semantics(goldens, cuda):
                 assert oracle.parity_ok(z.cpu().numpy(), ref_ovw, TOL)
 
 
+def test_nan_inf_stay_in_the_rows_that_reference_them(goldens, cuda):
+    """a non-finite feature row must poison exactly the output rows whose adjacency references it -- no leakage through
+    masked lanes, padded slots or the packed (R > 1) layouts (the reference never multiplies what it does not read)"""
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    a = sp.csr_matrix((val, col, ptr), shape=(n, n))
+    bad_node = int(np.argmax(np.diff(ptr)))                         # a hub: many rows reference it
+    touched = np.zeros(n, bool)
+    touched[a[:, bad_node].nonzero()[0]] = True
+    for d in (1, 5, 16, 47, 100, 147, 500):
+        for strict in (True, False):
+            x = hash_matrix(n, d, seed=d)
+            x[bad_node, :] = np.nan
+            x[bad_node, 0] = np.inf
+            csr = device_csr(ptr, col, val, (n, n), cuda, strict=strict, long_row_nnz=64)
+            y = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
+            nonfinite_rows = ~np.isfinite(y).all(axis=1)
+            assert np.array_equal(nonfinite_rows, touched), (d, strict, nonfinite_rows.sum(), touched.sum())
+            clean = oracle.oracle_spmm(ptr, col, val, np.nan_to_num(x, nan=0.0, posinf=0.0))
+            assert oracle.parity_ok(y[~touched], clean[~touched], TOL, rowwise=False)
+
+
+def test_spmm_on_a_side_stream(goldens, cuda):
+    """every entry point is stream-ordered on the caller's stream: results are correct when launched on a non-default
+    torch stream with the producer of X on that same stream"""
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    csr = device_csr(ptr, col, val, (n, n), cuda, strict=True)
+    xh = hash_matrix(n, 64, seed=3)
+    ref = oracle.oracle_spmm(ptr, col, val, oracle.oracle_spmm(ptr, col, val, xh * np.float32(2.0)))
+    side = torch.cuda.Stream()
+    xd = torch.from_numpy(xh).to(cuda)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        x2 = xd * 2.0                      # produced on the side stream ...
+        y = csr.spmm(csr.spmm(x2))         # ... and consumed there, twice, without any host sync in between
+    side.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ref)
+
+
 def test_spmm_chain_equals_repeated_spmm(goldens, cuda):
     n, ptr, col, val = norm_graph(goldens, "pl2000")
     csr = device_csr(ptr, col, val, (n, n), cuda, strict=True)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""One rank's share of an ogbn-papers100M-shaped hop on ONE GPU (BASELINE configs 4/5 sizing): the rank owns 1/8 of the
+rows (13.9 M rows, ~418 M non-zeros) but gathers from the FULL 111 M x 128 fp32 feature replica (56.9 GB, far beyond
+the 256 MiB Infinity Cache).  Measures the per-rank SpMM time that the 8-GPU job's all-gather has to be weighed
+against."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sgl_amd import device as dev  # noqa: E402
+
+
+def main():
+    device = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    scale = 1.0 if free > 120e9 else 0.25
+    n_cols = int(111_059_956 * scale)
+    rows = n_cols // 8
+    d = 128
+    g = torch.Generator(device=device).manual_seed(0)
+    deg = torch.exp(torch.randn(rows, generator=g, device=device) * 1.1 + 2.8).clamp_(1, 20000).long()   # mean ~30
+    rowptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(rowptr[-1])
+    w = torch.exp(torch.randn(n_cols, generator=g, device=device) * 1.2)
+    cdf = torch.cumsum(w.double(), 0)
+    cdf /= cdf[-1].clone()
+    del w
+    col = torch.empty(nnz, dtype=torch.int32, device=device)
+    step = 1 << 26
+    for s in range(0, nnz, step):
+        e = min(nnz, s + step)
+        col[s:e] = torch.searchsorted(cdf, torch.rand(e - s, generator=g, device=device, dtype=torch.float64)).clamp_(0, n_cols - 1).int()
+    del cdf
+    val = torch.rand(nnz, generator=g, device=device) * 0.1
+    x = torch.empty((n_cols, d), device=device)
+    x.normal_(generator=g)
+    y = torch.empty((rows, d), device=device)
+    t0 = time.time()
+    csr = dev.DeviceCSR(rowptr, col, val, (rows, n_cols))
+    torch.cuda.synchronize()
+    print(f"PAPERS shard: rows={rows} n_cols={n_cols} nnz={nnz} d={d} X={n_cols * d * 4 / 1e9:.1f} GB  plan build {time.time() - t0:.2f}s  {csr.info()}", flush=True)
+    for _ in range(2):
+        csr.spmm(x, out=y)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        csr.spmm(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    alg = nnz * d * 4 + nnz * 8 + (rows + 1) * 4 + rows * d * 4
+    print(f"PAPERS shard: {ms:.2f} ms per hop per rank  = {nnz * d / (ms * 1e-3) / 1e12:.3f}e12 edge*feat/s per GPU, "
+          f"{nnz / (ms * 1e-3) / 1e9:.2f} G gathers/s, algorithmic-roofline fraction {alg / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    inbound = (7 / 8) * n_cols * d * 4
+    print(f"PAPERS shard: all-gather in-bound per rank per hop {inbound / 1e9:.1f} GB -> >= {inbound / 537e9 * 1e3:.0f} ms at 7 x 76.8 GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
