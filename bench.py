@@ -196,16 +196,13 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         chunks = column_chunks(d, args.col_chunks)
         info = {"row_pieces": args.pieces, "col_chunks": chunks}
         nbuf = min(2, max(K - 1, 0))
+        # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
+        x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
+        cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
         if len(chunks) == 1:
-            xbufs = [torch.empty_like(x0) for _ in range(nbuf)]
-
             def step():
-                prop.propagate(x0, K, x_buffers=xbufs)
+                prop.propagate(x0, K, x_buffers=cbufs[0])
         else:
-            # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
-            x_chunks = [x0[:, a:b].contiguous() for a, b in chunks]
-            cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
-
             def step():
                 prop.propagate_chunked(x_chunks, K, buffers=cbufs)
     setup_s = time.perf_counter() - t_setup
@@ -232,6 +229,29 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # ---- diagnostics (after the timed region, never part of `value`): the two halves of a sharded hop in isolation
+    diag = None
+    if sharded and nbuf > 0:
+        def timed_ms(fn, reps=3):
+            fn()
+            sync_all()
+            t_a = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync_all()
+            return (time.perf_counter() - t_a) * 1e3 / reps
+        ys = prop.spmm_only(x_chunks)
+        spmm_ms = timed_ms(lambda: prop.spmm_only(x_chunks))
+        xnext = [b[0] for b in cbufs]
+        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0
+        vals = torch.tensor([spmm_ms, exch_ms], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        inbound = (world - 1) / world * n * d * 4
+        diag = {"spmm_only_ms_per_hop_max_rank": float(vals[0]), "exchange_only_ms_per_hop_max_rank": float(vals[1]),
+                "inbound_bytes_per_rank_per_hop": inbound,
+                "exchange_inbound_GBps_per_rank": (inbound / (float(vals[1]) * 1e-3) / 1e9) if float(vals[1]) > 0 else None}
 
     cpu = None
     if not sharded and not args.no_cpu_baseline and rank == 0:
@@ -268,7 +288,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                        "parallelism": "single GPU" if world == 1 else
                        f"row-sharded x{world} + grouped p2p all-gather, {args.pieces} row pieces x {args.col_chunks} column chunks",
                        "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
-                       "plan": info, "setup_s": round(setup_s, 2)},
+                       "plan": info, "setup_s": round(setup_s, 2), "diagnostics": diag},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_BYTES, "traffic": traffic,
                          "kernel": "spmm_kernel", "algorithmic_bytes_per_launch": alg,

@@ -141,6 +141,31 @@ class ShardedPropagator:
             hops.append(y_local)
         return hops
 
+    # ---- diagnostics: the two halves of a hop in isolation (bench.py reports them next to the job time) ----------
+    def spmm_only(self, x_chunks):
+        """this rank's SpMM over every column chunk, no exchange -> list of local results"""
+        outs = []
+        for x in x_chunks:
+            y_local = torch.empty((self.hi - self.lo, x.shape[1]), dtype=x.dtype, device=x.device)
+            for p in range(self.pieces):
+                r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
+                if r1 > r0:
+                    self.spmm_pieces[p](x, y_local[r0:r1])
+            outs.append(y_local)
+        return outs
+
+    def exchange_only(self, y_chunks, x_next_chunks):
+        """one hop's all-gather of already computed local rows (no SpMM); blocks the stream until it has landed"""
+        for y_local, x_next in zip(y_chunks, x_next_chunks):
+            works = []
+            for p in range(self.pieces):
+                r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
+                if self.world > 1:
+                    works += self._exchange_piece(p, y_local[r0:r1], x_next)
+            x_next[self.lo:self.hi].copy_(y_local)
+            for w in works:
+                w.wait()
+
     def propagate_chunked(self, x_chunks, prop_steps, buffers=None):
         """Software-pipelined variant: the feature block is held as C column chunks (separate contiguous [N, w_c]
         matrices, see column_chunks()).  SpMM is separable over columns, so while chunk c's new rows are in flight
