@@ -102,7 +102,7 @@ class GpuEngine:
         from sgl_amd import device as dev
         csr = dev.DeviceCSR(rowptr, col, val, (n, n), strict=args.strict)
         bufs = [dev.alloc_rows(n, d, self.device) for _ in range(K)]
-        src0 = dev.upload_rows(x0, self.device) if (d % 4) else x0
+        src0 = dev.upload_rows(x0, self.device) if dev.row_pitch(d) != d else x0   # re-pack into the line-aware pitch
 
         x_in = dev.padded_parent(src0)
         outs = [dev.padded_parent(b) for b in bufs]

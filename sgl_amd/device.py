@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
-    "DeviceCSR", "round_up", "alloc_rows", "upload_rows", "normalize_adj",
+    "DeviceCSR", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "nafs_aggregate", "gather_rows",
 ]
 
@@ -21,10 +21,32 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def expected_lines(ld, d):
+    """average number of 128-byte cache lines a d-float row touches when rows are laid out at a pitch of ld floats"""
+    import math
+    step = math.gcd(ld * 4, 128)
+    offs = range(0, 128, step)
+    return sum((o + d * 4 + 127) // 128 for o in offs) / len(offs)
+
+
+def row_pitch(d):
+    """Leading dimension (floats) for a hop matrix of width d.
+
+    Always a multiple of 4 floats (16-byte aligned rows -> 16-byte lane accesses).  The SpMM is bound by the number of
+    128-byte lines it pulls through the fabric, so when rounding the pitch up to a whole number of lines
+    makes every gathered row touch measurably fewer lines, take it: d = 147 -> 160 floats (5 lines instead of 5.5 on
+    average, +8 % memory), d = 500 -> 512; d = 100 stays 100 (always exactly 4 lines either way)."""
+    d = max(int(d), 1)
+    ld4, ld32 = round_up(d, 4), round_up(d, 32)
+    if ld32 != ld4 and ld32 <= 1.25 * ld4 and expected_lines(ld32, d) <= 0.97 * expected_lines(ld4, d):
+        return ld32
+    return ld4
+
+
 def alloc_rows(n, d, device, zero_pad=True):
-    """[n, d] float32 view of a row-padded buffer whose leading dimension is a multiple of 4 floats, so
-    every row starts 16-byte aligned and the kernels can use 16-byte lane accesses for any d."""
-    ld = round_up(max(d, 1), 4)
+    """[n, d] float32 view of a row-padded buffer (pitch = row_pitch(d)): every row starts 16-byte aligned, so the
+    kernels use 16-byte lane accesses for any d, and rows are placed to touch as few cache lines as possible."""
+    ld = row_pitch(d)
     buf = torch.empty((n, ld), dtype=torch.float32, device=device)
     if zero_pad and ld != d:
         buf[:, d:].zero_()
@@ -34,7 +56,7 @@ def alloc_rows(n, d, device, zero_pad=True):
 def padded_parent(t):
     """For a [n, d] view created by alloc_rows return the [n, ld] parent view (pad columns included)."""
     n, d = t.shape
-    ld = t.stride(0) if n > 1 else round_up(d, 4)
+    ld = t.stride(0) if n > 1 else row_pitch(d)
     if ld == d:
         return t
     return torch.as_strided(t, (n, ld), (ld, 1), t.storage_offset())

@@ -85,8 +85,9 @@ class GraphOp:
         device = self._adj.device
         x0 = feature if (isinstance(feature, Tensor) and feature.is_cuda and feature.dtype == torch.float32) else None
         cur = dev.upload_rows(feature, device) if x0 is None else x0
-        if (cur.shape[1] > 1 and cur.stride(1) != 1) or cur.stride(0) % 4 != 0 or cur.data_ptr() % 16 != 0:
-            cur = dev.upload_rows(cur, device)  # re-pack into an aligned, row-padded buffer
+        if (cur.shape[1] > 1 and cur.stride(1) != 1) or cur.data_ptr() % 16 != 0 or \
+                (cur.shape[0] > 1 and cur.stride(0) != dev.row_pitch(cur.shape[1])):
+            cur = dev.upload_rows(cur, device)  # re-pack into an aligned buffer with the line-aware row pitch
         # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns
         # are zeros and stay zeros under propagation)
         src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
