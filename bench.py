@@ -72,6 +72,32 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
             "ms_per_hop_sample": t * 1e3}
 
 
+class _QuietStdout:
+    """RCCL prints a version banner through C stdio (flushed at exit, i.e. AFTER our JSON line).  The driver reads ONE
+    JSON line from stdout, so everything except that line is routed to stderr at the file-descriptor level."""
+
+    def __init__(self):
+        self.saved = None
+
+    def mute(self):
+        if self.saved is None:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+    def unmute(self):
+        if self.saved is not None:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)      # push buffered C-level output out while fd 1 still is stderr
+            except Exception:  # noqa: BLE001
+                pass
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+
+
 class GpuEngine:
     """Everything device-specific in the bench: workload construction, the two step functions, timing.
     tests/test_bench_orchestration.py substitutes a CPU/gloo engine to exercise the distributed orchestration
@@ -134,6 +160,9 @@ def parse_args(argv=None):
                     help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
+    ap.add_argument("--exchange", choices=("p2p", "push"), default=os.environ.get("SGL_BENCH_EXCHANGE", "p2p"),
+                    help="N>1 transport: grouped RCCL send/recv (p2p) or stores into peer replicas from the SpMM kernel "
+                         "through torch symmetric memory (push; falls back to p2p if the mapping cannot be set up)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the row-piece (multi-GPU) code path even with one GPU")
@@ -151,6 +180,9 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    quiet = _QuietStdout()
+    if emit is print:
+        quiet.mute()
     engine = engine_cls(local_rank)
     device = engine.device
     own_group = False
@@ -193,13 +225,29 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         pb = all_piece_bounds(rp_host, world, args.pieces)
         pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
         prop = ShardedPropagator(pieces, pb, rank, world, n)
+        exchange = args.exchange
         chunks = column_chunks(d, args.col_chunks)
         info = {"row_pieces": args.pieces, "col_chunks": chunks}
         nbuf = min(2, max(K - 1, 0))
         # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
         x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
         cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
-        if len(chunks) == 1:
+        if exchange == "push":
+            try:
+                if not dist.is_initialized():   # --force-sharded on one GPU: symmetric memory still needs a group
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29517")
+                    dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
+                    own_group = True
+                prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
+            except Exception as e:  # noqa: BLE001  (e.g. symmetric memory unavailable): use the RCCL transport
+                sys.stderr.write(f"[bench] push transport unavailable ({type(e).__name__}: {e}); using p2p\n")
+                exchange = "p2p"
+        info["exchange"] = exchange
+        if exchange == "push":
+            def step():
+                prop.propagate_push(x_chunks, K)
+        elif len(chunks) == 1:
             def step():
                 prop.propagate(x0, K, x_buffers=cbufs[0])
         else:
@@ -244,7 +292,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         ys = prop.spmm_only(x_chunks)
         spmm_ms = timed_ms(lambda: prop.spmm_only(x_chunks))
         xnext = [b[0] for b in cbufs]
-        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0
+        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0   # always the RCCL transport
         vals = torch.tensor([spmm_ms, exch_ms], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(vals, op=dist.ReduceOp.MAX)
@@ -295,12 +343,15 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                          "avg_launch_ms": hop_s * 1e3},
             "cpu_baseline": cpu,
         }
+        quiet.unmute()
         emit(json.dumps(out))
         sys.stdout.flush()
+        if emit is print:
+            quiet.mute()                      # late library chatter (communicator teardown) goes to stderr too
     if world > 1:
         dist.barrier()
-        if own_group:
-            dist.destroy_process_group()
+    if own_group and dist.is_initialized():
+        dist.destroy_process_group()
     return out
 
 

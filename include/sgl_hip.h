@@ -106,6 +106,12 @@ int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
 int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                  int accumulate, void *stream);
 
+/* Y_0 = Y_1 = ... = A . X stored into n_out (1..8) matrices with a common leading dimension.  h_y: HOST array of
+ * device pointers; entries beyond the first may point into peer GPUs' memory (IPC / symmetric memory): the kernel
+ * then pushes each finished row to every replica over xGMI (row-sharded multi-GPU propagation). */
+int sgl_spmm_multi_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, int n_out, float *const *h_y, int64_t ldy,
+                       int64_t d, void *stream);
+
 /* The hop loop of GraphOp.propagate (sgl/operators/base_op.py:29-35) in one call: Y_1 = A.X_0, Y_k = A.Y_{k-1}.
  * h_y / h_ldy: HOST arrays of n_hops device pointers / leading dimensions.  A must be square. */
 int sgl_spmm_chain_f32(sgl_csr_t *csr, int n_hops, const float *d_x0, int64_t ldx0, float *const *h_y,

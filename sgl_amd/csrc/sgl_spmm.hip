@@ -116,6 +116,16 @@ struct SpmmArgs {
     int64_t ldres;
     float epi_alpha, epi_lo, epi_hi;
     int32_t epi;
+    // optional replicas of Y: every output row is ALSO stored at the same (row, column) offset of these matrices
+    // (same leading dimension as y).  Used to push a rank's new rows straight into the peers' feature replicas
+    // over xGMI from the producing kernel (sgl_spmm_multi_f32); n_more == 0 otherwise.
+    float *y_more[7];
+    int32_t n_more;
+};
+
+struct MultiOut {
+    float *p[7];   // already offset to the item's first row
+    int n;
 };
 
 struct Epilogue {
@@ -132,12 +142,12 @@ __device__ __forceinline__ float epi_apply(float v, float r, const Epilogue &e, 
 
 // One wavefront walks `nrows` consecutive rows whose non-zeros are colb/valb[0 .. tot) ; lane i of `my_rel`
 // holds the offset of row i's first non-zero (lane nrows holds tot).
-template <int VEC, int GROUP, int NCH, int U, bool NT>
+template <int VEC, int GROUP, int NCH, int U, bool NT, bool MULTI>
 __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const float *__restrict__ valb,
                                          const int my_rel, const int nrows, const int tot,
                                          const float *__restrict__ x, const int64_t ldx, float *__restrict__ out,
                                          const int64_t ldo, const int d, const bool accumulate, const int lane,
-                                         const Epilogue epi, const int64_t ldres) {
+                                         const Epilogue epi, const int64_t ldres, const MultiOut mo) {
     using V = typename VecT<VEC>::type;
     constexpr int R = 64 / GROUP;
     const int s = (R == 1) ? 0 : (lane / GROUP);
@@ -255,12 +265,17 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                         }
                     }
                     st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
+                    if constexpr (MULTI) {
+#pragma unroll
+                        for (int q = 0; q < 7; ++q)  // replicas (peer memory): posted stores, nothing waits on them
+                            if (q < mo.n) *reinterpret_cast<V *>(mo.p[q] + (int64_t)ri * ldo + colofs[ch]) = v;
+                    }
                 }
         }
     }
 }
 
-template <int VEC, int GROUP, int NCH, int U, bool NT>
+template <int VEC, int GROUP, int NCH, int U, bool NT, bool MULTI>
 __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -275,8 +290,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         none.alpha = 1.f;
         none.lo = none.hi = 0.f;
         none.on = 0;   // pieces hold partial sums: the epilogue runs in the fix-up kernel
-        run_rows<VEC, GROUP, NCH, U, NT>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
-                                         a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0);
+        MultiOut solo;
+        solo.n = 0;
+        run_rows<VEC, GROUP, NCH, U, NT, false>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
+                                         a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0, solo);
     } else {
         int ib = b - a.piece_blocks;
         if (a.xcd_remap) ib = (ib & 7) * a.item_blocks_per_xcd + (ib >> 3);
@@ -296,9 +313,13 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         epi.lo = a.epi_lo;
         epi.hi = a.epi_hi;
         epi.on = a.epi;
-        run_rows<VEC, GROUP, NCH, U, NT>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
+        MultiOut mo;
+        mo.n = MULTI ? a.n_more : 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) mo.p[q] = (MULTI && q < a.n_more) ? a.y_more[q] + (int64_t)row_begin * a.ldy : nullptr;
+        run_rows<VEC, GROUP, NCH, U, NT, MULTI>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
                                          a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
-                                         a.ldres);
+                                         a.ldres, mo);
     }
 }
 
@@ -307,7 +328,8 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ long_first,
                                                          const float *__restrict__ partial, int64_t ldp,
                                                          float *__restrict__ y, int64_t ldy, int d, int accumulate,
-                                                         const float *__restrict__ res, int64_t ldres, Epilogue epi) {
+                                                         const float *__restrict__ res, int64_t ldres, Epilogue epi,
+                                                         MultiOut mo) {
     const int kblocks = (d + 255) / 256;
     const int lr = blockIdx.x / kblocks;
     const int k = (blockIdx.x % kblocks) * 256 + threadIdx.x;
@@ -319,11 +341,17 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
     if (epi.on) acc = epi_apply(acc, res ? res[(int64_t)row * ldres + k] : 0.f, epi, res != nullptr);
     *yp = acc;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+        if (q < mo.n) mo.p[q][(int64_t)row * ldy + k] = acc;
 }
 
 template <int VEC, int GROUP, int NCH, int U, bool NT>
 hipError_t launch_variant(const SpmmArgs &a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((spmm_kernel<VEC, GROUP, NCH, U, NT>), dim3(grid), dim3(64 * a.waves), 0, st, a);
+    if (a.n_more > 0)
+        hipLaunchKernelGGL((spmm_kernel<VEC, GROUP, NCH, U, NT, true>), dim3(grid), dim3(64 * a.waves), 0, st, a);
+    else
+        hipLaunchKernelGGL((spmm_kernel<VEC, GROUP, NCH, U, NT, false>), dim3(grid), dim3(64 * a.waves), 0, st, a);
     return hipGetLastError();
 }
 
@@ -480,6 +508,8 @@ struct EpiHost {
     float alpha = 1.f, lo = 0.f, hi = 0.f;
     const float *res = nullptr;
     int64_t ldres = 0;
+    int n_more = 0;             // replicas of Y (sgl_spmm_multi_f32)
+    float *y_more[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int d, int vec,
@@ -534,6 +564,8 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.epi_lo = eh.lo;
     a.epi_hi = eh.hi;
     a.epi = eh.on;
+    a.n_more = eh.n_more;
+    for (int q = 0; q < 7; ++q) a.y_more[q] = eh.y_more[q];
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
     a.xcd_remap = (!(h->flags & SGL_CSR_NO_XCD_REMAP) && sgl::tuning("spmm_xcd_remap", 1) != 0) ? 1 : 0;
@@ -571,8 +603,11 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         fe.lo = eh.lo;
         fe.hi = eh.hi;
         fe.on = eh.on;
+        MultiOut fmo;
+        fmo.n = eh.n_more;
+        for (int q = 0; q < 7; ++q) fmo.p[q] = eh.y_more[q];
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_long_row, h->d_long_first, h->d_partial, a.ldp,
-                           d_y, ldy, d, accumulate, eh.res, eh.ldres, fe);
+                           d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo);
         e = hipGetLastError();
         if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: fix-up launch failed: %s", hipGetErrorString(e));
     }
@@ -590,6 +625,11 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
     hipStream_t st = sgl::as_stream(stream);
     // one launch covers up to 64 lanes x 4 chunks x VEC columns; wider matrices go in column slices
     int vec = pick_vec(d_x, ldx, d_y, ldy, d);
+    for (int q = 0; q < eh.n_more; ++q) {
+        SGL_REQUIRE(eh.y_more[q] && aligned_to(eh.y_more[q], 4), "%s: bad replica pointer", who);
+        if (vec == 4 && !aligned_to(eh.y_more[q], 16)) vec = aligned_to(eh.y_more[q], 8) && d % 2 == 0 ? 2 : 1;
+        if (vec == 2 && !aligned_to(eh.y_more[q], 8)) vec = 1;
+    }
     const int64_t vcap = sgl::tuning("spmm_vec", 0);   // experiments: cap the lane width (2 or 1 floats)
     if ((vcap == 1 || vcap == 2) && vcap < vec) vec = (int)vcap;
     if (eh.on && eh.res) {
@@ -602,6 +642,7 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
         const int dc = (int)std::min<int64_t>(max_cols, d - c0);
         EpiHost es = eh;
         if (es.res) es.res += c0;
+        for (int q = 0; q < es.n_more; ++q) es.y_more[q] += c0;
         int rc = spmm_slice(h, d_x + c0, ldx, d_y + c0, ldy, dc, vec, accumulate, st, es);
         if (rc != SGL_OK) return rc;
     }
@@ -611,6 +652,19 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
 SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                             int accumulate, void *stream) {
     return spmm_impl(h, d_x, ldx, d_y, ldy, d, accumulate, stream, EpiHost(), "sgl_spmm_f32");
+}
+
+// Y_0 = Y_1 = ... = A X: the product is stored into n_out matrices (same leading dimension).  Matrix 0 is normally
+// local; the others may live in PEER GPUs' memory (IPC / symmetric-memory mappings): the producing wavefront pushes
+// its finished rows straight into every peer's replica of the feature block over xGMI -- the all-gather between
+// hops without copy kernels, staging buffers or a separate communication phase.
+SGL_EXPORT int sgl_spmm_multi_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, int n_out, float *const *h_y, int64_t ldy,
+                                  int64_t d, void *stream) {
+    SGL_REQUIRE(n_out >= 1 && n_out <= 8 && h_y, "sgl_spmm_multi_f32: n_out must be in [1, 8]");
+    EpiHost eh;
+    eh.n_more = n_out - 1;
+    for (int q = 1; q < n_out; ++q) eh.y_more[q - 1] = h_y[q];
+    return spmm_impl(h, d_x, ldx, h_y[0], ldy, d, 0, stream, eh, "sgl_spmm_multi_f32");
 }
 
 // X_1 = A X_0, X_2 = A X_1, ... : the whole hop loop of GraphOp.propagate (base_op.py:29-35) issued from one call, so a

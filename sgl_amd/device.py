@@ -146,6 +146,20 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
+    def spmm_multi(self, x, out_ptrs, ld):
+        """A @ x stored into several [n_rows, d] matrices given as RAW device addresses (the first is normally local,
+        the others typically peer-GPU replicas obtained from torch symmetric memory) with leading dimension `ld`."""
+        _check_mat(x, "x")
+        if x.shape[0] != self.shape[1]:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        n_out = len(out_ptrs)
+        if not 1 <= n_out <= 8:
+            raise ValueError("between 1 and 8 output replicas are supported")
+        arr = (c_void_p * n_out)(*[int(p) for p in out_ptrs])
+        with torch.cuda.device(self.device):
+            check(lib().sgl_spmm_multi_f32(self._h, ptr(x), _ld(x), n_out, arr, int(ld), x.shape[1], current_stream_ptr()),
+                  "sgl_spmm_multi_f32")
+
     def spmm_chain(self, x, n_hops, outs=None):
         """[A x, A^2 x, ..., A^k x] with ONE library call (the hop loop runs in C).  x: [n, d] row-major CUDA; the
         results are row-padded buffers of the same width as x (or the caller's `outs`)."""

@@ -166,6 +166,63 @@ class ShardedPropagator:
             for w in works:
                 w.wait()
 
+    # ---- fused push: the SpMM kernel itself writes each finished row into every peer's replica --------------------
+    def enable_push(self, chunk_widths, handles, device, group=None):
+        """Allocate the ping-pong feature replicas in torch symmetric memory (peer-mapped over xGMI) and exchange the
+        mappings.  Collective.  handles: the DeviceCSR objects of this rank's row pieces (device_piece_spmms)."""
+        import torch.distributed._symmetric_memory as symm
+        grp = group or self.group or dist.group.WORLD
+        self._push_handles = handles
+        self._push = []
+        for w in chunk_widths:
+            slots = []
+            for _ in range(2):
+                t = symm.empty((self.n, int(w)), dtype=torch.float32, device=device)
+                slots.append((t, symm.rendezvous(t, grp)))
+            self._push.append(slots)
+        return self
+
+    def propagate_push(self, x_chunks, prop_steps):
+        """Same result as propagate_chunked, different transport: no send/recv at all.  Every rank's SpMM kernel
+        stores its output rows into ALL ranks' next-hop replicas (sgl_spmm_multi_f32: local store + up to 7 posted
+        peer stores per row over xGMI), then one symmetric-memory barrier per hop orders the hop boundary.  Compute
+        and communication are the same instruction stream, so they overlap perfectly and no CU runs a copy kernel.
+        Needs enable_push().  Returns hops[h][c] = local shard [hi-lo, w_c] (copies: the replicas are recycled)."""
+        C = len(x_chunks)
+        assert hasattr(self, "_push") and len(self._push) == C
+        hops = [[x[self.lo:self.hi] for x in x_chunks]]
+        cur = list(x_chunks)
+        for h in range(1, prop_steps + 1):
+            last = h == prop_steps
+            outs = []
+            for c in range(C):
+                w_c = x_chunks[c].shape[1]
+                if last:
+                    y_local = torch.empty((self.hi - self.lo, w_c), dtype=torch.float32, device=x_chunks[c].device)
+                    for p in range(self.pieces):
+                        r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
+                        if r1 > r0:
+                            self.spmm_pieces[p](cur[c], y_local[r0:r1])
+                    outs.append(y_local)
+                    continue
+                t, hdl = self._push[c][(h - 1) % 2]
+                ptrs = list(hdl.buffer_ptrs)
+                order = [self.rank] + [q for q in range(self.world) if q != self.rank]     # local replica first
+                for p in range(self.pieces):
+                    r0, r1 = int(self.pb[self.rank, p]), int(self.pb[self.rank, p + 1])
+                    if r1 > r0:
+                        self._push_handles[p].spmm_multi(cur[c], [ptrs[q] + r0 * w_c * 4 for q in order], w_c)
+                outs.append(None)
+            if not last:
+                # all my rows of this hop are on their way; the barrier returns once every rank's kernels are done
+                self._push[0][(h - 1) % 2][1].barrier()
+                for c in range(C):
+                    t = self._push[c][(h - 1) % 2][0]
+                    outs[c] = t[self.lo:self.hi].clone()
+                    cur[c] = t
+            hops.append(outs)
+        return hops
+
     def propagate_chunked(self, x_chunks, prop_steps, buffers=None):
         """Software-pipelined variant: the feature block is held as C column chunks (separate contiguous [N, w_c]
         matrices, see column_chunks()).  SpMM is separable over columns, so while chunk c's new rows are in flight

@@ -184,6 +184,25 @@ def test_spmm_on_a_side_stream(goldens, cuda):
     assert np.array_equal(y.cpu().numpy(), ref)
 
 
+def test_spmm_multi_writes_every_replica(goldens, cuda):
+    """sgl_spmm_multi_f32: the same product lands in up to 8 destination matrices (in a multi-GPU job 7 of them are
+    peer replicas; here all are local), for regular rows, split rows and narrow / wide matrices"""
+    a = long_row_graph()
+    n = a.shape[0]
+    for d in (100, 16, 500):
+        x = torch.from_numpy(hash_matrix(n, d, seed=9)).to(cuda)
+        for strict, long_nnz in ((True, 0), (False, 128)):
+            csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, long_row_nnz=long_nnz)
+            ref = csr.spmm(x)
+            for n_out in (1, 3, 8):
+                outs = [torch.full((n, d), float("nan"), device=cuda) for _ in range(n_out)]
+                csr.spmm_multi(x, [o.data_ptr() for o in outs], d)
+                for o in outs:
+                    assert torch.equal(o, ref), (d, strict, n_out)
+    with pytest.raises(ValueError):
+        csr.spmm_multi(x, [], d)
+
+
 def test_spmm_chain_equals_repeated_spmm(goldens, cuda):
     n, ptr, col, val = norm_graph(goldens, "pl2000")
     csr = device_csr(ptr, col, val, (n, n), cuda, strict=True)
