@@ -66,10 +66,30 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
     t = float(np.median(times))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
-    return {"value": nnz_s * d / t, "unit": "edge*featdim/s", "cores": threads, "kind": kind,
-            "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}, one hop, median of {len(times)} reps, "
-                      f"OpenMP static schedule, {threads} threads",
-            "ms_per_hop_sample": t * 1e3}
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        pass
+    out = {"value": nnz_s * d / t, "unit": "edge*featdim/s", "cores": threads, "kind": kind,
+           "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}, one hop, median of {len(times)} reps, "
+                     f"OpenMP static schedule, {threads} threads on {cpu_model}",
+           "ms_per_hop_sample": t * 1e3}
+    # B2 of BASELINE.md: the reference's non-Linux branch `adj.dot(x)` (base_op.py:34), scipy, single thread, on a
+    # smaller slice of the same rows (bounded: a few seconds)
+    try:
+        import scipy.sparse as sp
+        r2 = min(rows, 50_000)
+        a = sp.csr_matrix((v[:int(rp[r2])], c[:int(rp[r2])], rp[:r2 + 1]), shape=(r2, xh.shape[0]))
+        t0 = time.perf_counter()
+        a.dot(xh)
+        ts = time.perf_counter() - t0
+        out["scipy_dot"] = {"value": int(rp[r2]) * d / ts, "unit": "edge*featdim/s", "cores": 1,
+                            "sample": f"scipy csr.dot on the first {r2} rows ({int(rp[r2])} nnz)"}
+    except Exception as e:  # noqa: BLE001
+        out["scipy_dot"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 class _QuietStdout:
