@@ -220,6 +220,40 @@ def main():
         set_knobs()
         del c, c2, v2, x2
 
+    if "community" in exps:
+        # same size / degree law, but 80 % of the edges stay inside contiguous blocks of `bs` nodes (community-ordered ids,
+        # as real co-purchase / citation graphs largely are): what the XCD-aware block->row mapping buys when there IS locality
+        for bs in (2048, 16384):
+            g = torch.Generator(device=device).manual_seed(7)
+            m = wl["m"]
+            w = torch.exp(torch.randn(n, generator=g, device=device, dtype=torch.float64) * 1.2)
+            cdf = torch.cumsum(w, 0); cdf /= cdf[-1].clone()
+            a_ = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device, dtype=torch.float64)).clamp_(0, n - 1)
+            local = torch.rand(m, generator=g, device=device) < 0.8
+            b_far = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device, dtype=torch.float64)).clamp_(0, n - 1)
+            b_near = ((a_ // bs) * bs + torch.randint(0, bs, (m,), generator=g, device=device)).clamp_(0, n - 1)
+            b_ = torch.where(local, b_near, b_far)
+            keep = a_ != b_
+            lo_, hi_ = torch.minimum(a_, b_)[keep], torch.maximum(a_, b_)[keep]
+            keys = torch.unique(lo_ * n + hi_)
+            full = torch.sort(torch.cat([keys, (keys % n) * n + keys // n])).values
+            rp = torch.zeros(n + 1, dtype=torch.int64, device=device)
+            rp[1:] = torch.cumsum(torch.bincount(full // n, minlength=n), 0)
+            cc = (full % n).to(torch.int32)
+            vv = torch.ones(cc.numel(), device=device)
+            del a_, b_, b_far, b_near, keys, full, lo_, hi_, keep, local, cdf, w
+            rpn, ccn, vvn = dev.normalize_adj(rp, cc, vv, n, 0.5, None)
+            cm = dev.DeviceCSR(rpn, ccn, vvn, (n, n))
+            nz = ccn.numel()
+            for remap in (1, 0):
+                set_knobs(spmm_xcd_remap=remap)
+                ms = time_hops(lambda: cm.spmm(x0, out=bufs[0]), reps=7, warm=2)
+                algc = nz * d * 4 + nz * 8 + (n + 1) * 4 + n * d * 4
+                print(f"EXP community block={bs} nnz={nz} xcd_remap={remap} ms_per_hop={ms:.3f} frac={algc / (ms * 1e-3) / 8e12:.3f} "
+                      f"Ggather_per_s={nz / (ms * 1e-3) / 1e9:.2f}", flush=True)
+            set_knobs()
+            del cm, rpn, ccn, vvn, rp, cc, vv
+
     if "vec" in exps:
         for vec in (0, 2):
             for unroll in (3, 2, 4):
