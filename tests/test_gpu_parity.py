@@ -184,6 +184,39 @@ def test_spmm_on_a_side_stream(goldens, cuda):
     assert np.array_equal(y.cpu().numpy(), ref)
 
 
+def test_spmm_fuzz_random_shapes(cuda):
+    """60 random rectangular matrices (empty rows / columns, huge rows, random widths, random plan parameters,
+    both layouts of X): strict order must be bit-exact, the fast layout within tolerance, accumulate must compose"""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n_rows, n_cols = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+        d = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 64, 65, 100, 128, 200, 257]))
+        dens = float(rng.choice([0.0, 0.002, 0.02, 0.2]))
+        deg = rng.binomial(n_cols, dens, n_rows)
+        if n_rows > 3 and rng.random() < 0.5:
+            deg[rng.integers(0, n_rows, 2)] = min(n_cols, int(rng.integers(200, 1500)))
+        rows = np.repeat(np.arange(n_rows), deg)
+        cols = np.concatenate([np.sort(rng.choice(n_cols, k, replace=False)) for k in deg]) if deg.sum() else np.zeros(0, np.int64)
+        vals = rng.standard_normal(len(rows)).astype(np.float32)
+        ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        x = rng.standard_normal((n_cols, d)).astype(np.float32)
+        ref = oracle.oracle_spmm(ptr, cols, vals, x, n_rows=n_rows)
+        scale = oracle.oracle_spmm(ptr, cols, np.abs(vals), np.abs(x), n_rows=n_rows)
+        item_nnz, long_nnz = int(rng.choice([0, 1, 7, 64, 512])), int(rng.choice([0, 16, 100, 2048]))
+        xd = torch.from_numpy(x).to(cuda)
+        ctx = (case, n_rows, n_cols, d, dens, item_nnz, long_nnz)
+        ys = device_csr(ptr, cols, vals, (n_rows, n_cols), cuda, strict=True, item_nnz=item_nnz).spmm(xd)
+        assert np.array_equal(ys.cpu().numpy(), ref), ctx
+        fast = device_csr(ptr, cols, vals, (n_rows, n_cols), cuda, item_nnz=item_nnz, long_row_nnz=long_nnz)
+        yf = fast.spmm(xd)
+        rep = oracle.parity_report(yf.cpu().numpy(), ref, TOL, scale=scale)
+        assert rep["ok"], (ctx, rep)
+        # accumulate composes: A x + (A x) == 2 A x up to one rounding per element
+        y2 = yf.clone()
+        fast.spmm(xd, out=y2, accumulate=True)
+        assert oracle.parity_ok(y2.cpu().numpy(), 2 * ref, TOL, scale=2 * scale), ctx
+
+
 def test_spmm_multi_writes_every_replica(goldens, cuda):
     """sgl_spmm_multi_f32: the same product lands in up to 8 destination matrices (in a multi-GPU job 7 of them are
     peer replicas; here all are local), for regular rows, split rows and narrow / wide matrices"""
