@@ -173,6 +173,11 @@ int sgl_hop_wsum2d_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx
 int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw,
                            const float *d_dout, int64_t lddo, float *d_dw, int64_t lddw, float *const *h_dx,
                            const int64_t *h_lddx, int64_t n, int64_t d, void *stream);
+/* out[n, h] = <X_h[n, :], v> for every hop in one pass: the gate scores Linear(d -> 1)(X_h) of
+ * LearnableWeightedMessageOp (message_op/learnable_weighted_messahe_op.py:69-86).  d_vec: d floats on device, readable
+ * up to round_up(d, 4) floats (zero padded) when 16-byte aligned. */
+int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float *d_out,
+                       int64_t ldo, int64_t n, int64_t d, void *stream);
 /* backward of SGL_REDUCE_WSUM w.r.t. the weights: d_dw[h] = sum_{n,k} dOut[n,k] * X_h[n,k]   (d_dw: H floats,
  * overwritten; deterministic two-level reduction; d_scratch: >= sgl_hop_wsum1d_bwd_scratch(n_hops) floats) */
 int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops);

@@ -561,6 +561,35 @@ SGL_EXPORT int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const
     return SGL_OK;
 }
 
+// out[n, h] = <X_h[n, :], v>  : the gate scores of LearnableWeightedMessageOp (Linear(d -> 1) applied to every hop,
+// learnable_weighted_messahe_op.py:69-71,74-86) for all hops in one pass -- the row-dot kernel with a row-invariant
+// second operand (leading dimension 0).
+SGL_EXPORT int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec,
+                                  float *d_out, int64_t ldo, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_rowdot_f32: bad sizes");
+    Hops hx;
+    bool row4 = aligned_to(d_vec, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, row4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_vec && d_out && ldo >= n_hops, "sgl_hop_rowdot_f32: bad arguments");
+    hipStream_t st = sgl::as_stream(stream);
+    if (d == 0) {
+        SGL_HIP_CHECK(hipMemset2DAsync(d_out, ldo * sizeof(float), 0, n_hops * sizeof(float), n, st));
+        return SGL_OK;
+    }
+    // the vector is read with the same 16-byte lanes as the rows: it must be readable up to round_up(d, 4) floats
+    // (callers pass a zero-padded copy), the masked tail ignores what lies beyond d
+    const int lpr = pick_lpr(d, row4 ? 4 : 1);
+    SGL_REQUIRE((n + (256 / lpr) - 1) / (256 / lpr) < INT32_MAX, "sgl_hop_rowdot_f32: too many rows");
+    if (row4)
+        launch_rowdot<4>(lpr, 0, st, hx, n_hops, d_vec, 0, d_out, ldo, n, (int)d);
+    else
+        launch_rowdot<1>(lpr, 0, st, hx, n_hops, d_vec, 0, d_out, ldo, n, (int)d);
+    SGL_LAUNCH_CHECK("sgl_hop_rowdot_f32");
+    return SGL_OK;
+}
+
 SGL_EXPORT int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops) { return (int64_t)kW1dBlocks * (n_hops > 0 ? n_hops : 1); }
 
 SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,

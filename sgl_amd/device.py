@@ -13,7 +13,7 @@ from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
     "DeviceCSR", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
-    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "nafs_aggregate", "gather_rows",
+    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
 ]
 
 
@@ -375,6 +375,43 @@ class _WSum1D(torch.autograd.Function):
 
 def hop_wsum1d(feats, w):
     return _WSum1D.apply(w, *feats)
+
+
+class _HopScores(torch.autograd.Function):
+    """scores[n, h] = <X_h[n, :], v>: forward is one HIP pass over all hops; backward (mini-batch sized in training) is
+    dv = sum_h X_h^T g[:, h] and dX_h = g[:, h] v^T in plain torch."""
+
+    @staticmethod
+    def forward(ctx, v, *feats):
+        feats_d = [f.detach() for f in feats]
+        _check_hops(feats_d)
+        n, d = feats_d[0].shape
+        H = len(feats_d)
+        vp = torch.zeros(round_up(d, 4), dtype=torch.float32, device=feats_d[0].device)
+        vp[:d] = v.detach().to(torch.float32).view(-1)
+        out = torch.empty((n, H), dtype=torch.float32, device=vp.device)
+        ptrs, lds = _lib.hop_arrays(feats_d)
+        with torch.cuda.device(vp.device):
+            check(lib().sgl_hop_rowdot_f32(H, ptrs, lds, ptr(vp), ptr(out), H, n, d, current_stream_ptr()), "sgl_hop_rowdot_f32")
+        ctx.save_for_backward(v.detach(), *feats_d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, *feats = ctx.saved_tensors
+        dv = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.zeros_like(v, dtype=torch.float32).view(-1)
+            for h, f in enumerate(feats):
+                dv += f.t() @ g[:, h]
+            dv = dv.view_as(v)
+        dxs = [(g[:, h:h + 1] * v.view(1, -1)) if ctx.needs_input_grad[1 + h] else None for h in range(len(feats))]
+        return (dv, *dxs)
+
+
+def hop_scores(feats, v):
+    """[n, H] matrix of <X_h[n, :], v> (differentiable w.r.t. v and the hops)"""
+    return _HopScores.apply(v, *feats)
 
 
 def nafs_aggregate(feats, return_weights=False):

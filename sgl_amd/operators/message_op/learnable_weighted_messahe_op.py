@@ -61,6 +61,12 @@ class LearnableWeightedMessageOp(MessageOp):
         d_ref = 0 if ref is None else ref.shape[1]
         shared = lin.bias if ref is None else ref @ w[:d_ref] + lin.bias           # [n] (or [1])
         w_x = w[d_ref:]
+        if hops[0].is_cuda and hops[0].dtype == torch.float32:
+            # all H per-hop products in ONE HIP pass over the hop matrices (sgl_hop_rowdot_f32)
+            from ... import device as dev
+            from ..utils import _rowmajor
+            per_hop = dev.hop_scores([_rowmajor(x) for x in hops], w_x)            # [n, H]
+            return (per_hop + shared.view(-1, 1)).t().reshape(-1)                  # hop-major flat [H*n]
         return torch.cat([(x @ w_x + shared) for x in hops], dim=0)                # [H*n]
 
     def hop_weights(self, feat_list):
