@@ -153,9 +153,16 @@ class GpuEngine:
         x_in = dev.padded_parent(src0)
         outs = [dev.padded_parent(b) for b in bufs]
 
+        info = csr.info()
+        if info["nnz"] < 5_000_000:
+            # small graph: the k launches are captured in a hipGraph and replayed (launch-bound regime)
+            graph = csr.capture_chain(x_in, outs)
+            info["hip_graph"] = True
+            return graph.replay, info
+
         def step():
             csr.spmm_chain(x_in, K, outs=outs)     # the k SpMM launches of one propagate(), issued from one call
-        return step, csr.info()
+        return step, info
 
     def piece_spmms(self, args, rowptr, col, val, n, my_bounds, rp_host):
         from sgl_amd.dist import device_piece_spmms

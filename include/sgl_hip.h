@@ -117,6 +117,15 @@ int sgl_spmm_multi_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, int n_out,
 int sgl_spmm_chain_f32(sgl_csr_t *csr, int n_hops, const float *d_x0, int64_t ldx0, float *const *h_y,
                        const int64_t *h_ldy, int64_t d, void *stream);
 
+/* The same hop loop captured once into a hipGraph and replayed with one launch: for small graphs the k kernels of a
+ * propagate() are launch-bound.  Pointers, sizes and the handle are baked in at creation (which runs the chain once,
+ * eagerly, and synchronises the device); launching replays onto `stream`.  The handle must outlive the graph. */
+typedef struct sgl_graph sgl_graph_t;
+int sgl_chain_graph_create(sgl_graph_t **out, sgl_csr_t *csr, int n_hops, const float *d_x0, int64_t ldx0,
+                           float *const *h_y, const int64_t *h_ldy, int64_t d);
+int sgl_chain_graph_launch(sgl_graph_t *graph, void *stream);
+int sgl_chain_graph_destroy(sgl_graph_t *graph);
+
 /* Fused label-propagation step (sgl/tricks/utils.py:55-56, the inner loop of label_propagation and of
  * CorrectAndSmooth):  Y = clamp( alpha * (A . X) + RES, lo, hi )  with the reference's rounding order (rounded product,
  * rounded add, clamp that keeps NaN).  d_res may be NULL (no residual); lo = -INF / hi = +INF disable the clamp. */

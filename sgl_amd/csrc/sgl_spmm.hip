@@ -685,6 +685,61 @@ SGL_EXPORT int sgl_spmm_chain_f32(sgl_csr_t *h, int n_hops, const float *d_x0, i
     return SGL_OK;
 }
 
+// ---- hipGraph of a whole propagate(): for small graphs (Pubmed / Cora sized) each hop is a few tens of microseconds
+// of kernel time, so the k launches (+ fix-ups) are captured once and replayed with a single hipGraphLaunch.
+struct sgl_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+SGL_EXPORT int sgl_chain_graph_create(sgl_graph_t **out, sgl_csr_t *h, int n_hops, const float *d_x0, int64_t ldx0,
+                                      float *const *h_y, const int64_t *h_ldy, int64_t d) {
+    if (!out) return sgl::fail(SGL_ERR_INVALID, "sgl_chain_graph_create: NULL out");
+    *out = nullptr;
+    SGL_REQUIRE(h && n_hops >= 1 && h_y && h_ldy, "sgl_chain_graph_create: bad arguments");
+    // everything that may allocate or synchronise happens BEFORE the capture: one eager run sizes the split-row
+    // workspace (and validates the arguments)
+    int rc = sgl_spmm_chain_f32(h, n_hops, d_x0, ldx0, h_y, h_ldy, d, nullptr);
+    if (rc != SGL_OK) return rc;
+    SGL_HIP_CHECK(hipDeviceSynchronize());
+    hipStream_t cap = nullptr;
+    SGL_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    sgl_graph_t *g = new (std::nothrow) sgl_graph_t();
+    if (!g) {
+        (void)hipStreamDestroy(cap);
+        return sgl::fail(SGL_ERR_ALLOC, "sgl_chain_graph_create: out of memory");
+    }
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        rc = sgl_spmm_chain_f32(h, n_hops, d_x0, ldx0, h_y, h_ldy, d, cap);
+        e = hipStreamEndCapture(cap, &g->graph);
+        if (rc != SGL_OK && e == hipSuccess) e = hipErrorUnknown;
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    (void)hipStreamDestroy(cap);
+    if (e != hipSuccess) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return sgl::fail((int)e, "sgl_chain_graph_create: capture/instantiate failed: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_chain_graph_launch(sgl_graph_t *g, void *stream) {
+    if (!g || !g->exec) return sgl::fail(SGL_ERR_INVALID, "sgl_chain_graph_launch: NULL graph");
+    SGL_HIP_CHECK(hipGraphLaunch(g->exec, sgl::as_stream(stream)));
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_chain_graph_destroy(sgl_graph_t *g) {
+    if (!g) return SGL_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return SGL_OK;
+}
+
 SGL_EXPORT int sgl_spmm_axpb_clamp_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                                        float alpha, const float *d_res, int64_t ldres, float lo, float hi,
                                        void *stream) {

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
-    "DeviceCSR", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
+    "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
 ]
 
@@ -184,6 +184,24 @@ class DeviceCSR:
                       "sgl_spmm_chain_f32")
         return outs
 
+    def capture_chain(self, x, outs):
+        """hipGraph of `spmm_chain(x, len(outs), outs)`: returns a ChainGraph whose replay() re-runs the k hops on the
+        current stream with one launch (x and outs are baked in: refill x in place between replays)."""
+        _check_mat(x, "x")
+        for o in outs:
+            _check_mat(o, "outs[*]")
+            if o.shape != (self.shape[0], x.shape[1]):
+                raise ValueError("an output matrix has the wrong shape")
+        n_hops = len(outs)
+        ptrs = (c_void_p * n_hops)(*[o.data_ptr() for o in outs])
+        lds = (c_int64 * n_hops)(*[_ld(o) for o in outs])
+        g = c_void_p()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            check(lib().sgl_chain_graph_create(ctypes.byref(g), self._h, n_hops, ptr(x), _ld(x), ptrs, lds, x.shape[1]),
+                  "sgl_chain_graph_create")
+        return ChainGraph(g, self, x, list(outs))
+
     def spmm_axpb_clamp(self, x, alpha, res=None, lo=float("-inf"), hi=float("inf"), out=None):
         """out = clamp(alpha * (A @ x) + res, lo, hi) in one kernel (the label-propagation step)"""
         _check_mat(x, "x")
@@ -208,6 +226,29 @@ class DeviceCSR:
         h, self._h = getattr(self, "_h", None), None
         if h:
             lib().sgl_csr_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class ChainGraph:
+    """a captured k-hop propagation (DeviceCSR.capture_chain); keeps the matrix and the buffers alive"""
+
+    def __init__(self, handle, csr, x, outs):
+        self._g, self.csr, self.x, self.outs = handle, csr, x, outs
+
+    def replay(self):
+        with torch.cuda.device(self.csr.device):
+            check(lib().sgl_chain_graph_launch(self._g, current_stream_ptr()), "sgl_chain_graph_launch")
+        return self.outs
+
+    def close(self):
+        g, self._g = getattr(self, "_g", None), None
+        if g:
+            lib().sgl_chain_graph_destroy(g)
 
     def __del__(self):
         try:

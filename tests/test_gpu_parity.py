@@ -217,6 +217,31 @@ def test_spmm_fuzz_random_shapes(cuda):
         assert oracle.parity_ok(y2.cpu().numpy(), 2 * ref, TOL, scale=2 * scale), ctx
 
 
+def test_hip_graph_replay_of_a_propagation(goldens, cuda):
+    """capture_chain: the k-hop launch sequence replayed from a hipGraph gives the same bits, also after the input
+    buffer has been refilled in place and on a side stream"""
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    csr = device_csr(ptr, col, val, (n, n), cuda, long_row_nnz=64)
+    x = torch.from_numpy(hash_matrix(n, 100, seed=1)).to(cuda)
+    outs = [torch.empty((n, 100), device=cuda) for _ in range(3)]
+    graph = csr.capture_chain(x, outs)
+    ref = [t.clone() for t in csr.spmm_chain(x, 3)]
+    for o in outs:
+        o.fill_(float("nan"))
+    got = graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    x.copy_(torch.from_numpy(hash_matrix(n, 100, seed=2)).to(cuda))         # new features, same buffers
+    ref2 = [t.clone() for t in csr.spmm_chain(x, 3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.replay()
+    side.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs, ref2))
+    graph.close()
+
+
 def test_spmm_multi_writes_every_replica(goldens, cuda):
     """sgl_spmm_multi_f32: the same product lands in up to 8 destination matrices (in a multi-GPU job 7 of them are
     peer replicas; here all are local), for regular rows, split rows and narrow / wide matrices"""
