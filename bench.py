@@ -187,9 +187,11 @@ def parse_args(argv=None):
                     help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
-    ap.add_argument("--exchange", choices=("p2p", "push"), default=os.environ.get("SGL_BENCH_EXCHANGE", "p2p"),
-                    help="N>1 transport: grouped RCCL send/recv (p2p) or stores into peer replicas from the SpMM kernel "
-                         "through torch symmetric memory (push; falls back to p2p if the mapping cannot be set up)")
+    ap.add_argument("--exchange", choices=("auto", "p2p", "allgather", "push"),
+                    default=os.environ.get("SGL_BENCH_EXCHANGE", "auto"),
+                    help="N>1 transport: grouped RCCL send/recv (p2p), RCCL all-gather on padded pieces (allgather), "
+                         "auto = time both during setup and keep the faster, or push = stores into peer replicas from "
+                         "the SpMM kernel through torch symmetric memory (opt-in; falls back to p2p if unavailable)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the row-piece (multi-GPU) code path even with one GPU")
@@ -270,6 +272,28 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             except Exception as e:  # noqa: BLE001  (e.g. symmetric memory unavailable): use the RCCL transport
                 sys.stderr.write(f"[bench] push transport unavailable ({type(e).__name__}: {e}); using p2p\n")
                 exchange = "p2p"
+        if exchange == "auto":
+            # time one hop's exchange with each RCCL transport (untimed setup) and keep the faster one; the decision
+            # is taken on the MAX over ranks so every rank picks the same
+            exchange = "p2p"
+            if world > 1 and nbuf > 0:
+                ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
+                cand = {}
+                for tname in ("p2p", "allgather"):
+                    prop.transport = tname
+                    for rep in range(3):
+                        if rep == 1:
+                            engine.sync(); dist.barrier(); engine.sync()
+                            t_a = time.perf_counter()
+                        prop.exchange_only(ys0, [b[0] for b in cbufs])
+                    engine.sync(); dist.barrier(); engine.sync()
+                    tt = torch.tensor([(time.perf_counter() - t_a) / 2], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    cand[tname] = float(tt.item())
+                exchange = min(cand, key=cand.get)
+                info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
+        if exchange in ("p2p", "allgather"):
+            prop.transport = exchange
         info["exchange"] = exchange
         if exchange == "push":
             def step():
@@ -319,7 +343,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         ys = prop.spmm_only(x_chunks)
         spmm_ms = timed_ms(lambda: prop.spmm_only(x_chunks))
         xnext = [b[0] for b in cbufs]
-        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0   # always the RCCL transport
+        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0   # the selected RCCL transport
         vals = torch.tensor([spmm_ms, exch_ms], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(vals, op=dist.ReduceOp.MAX)
@@ -361,7 +385,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                                    f"Chung-Lu graph, LaplacianGraphOp r=0.5",
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
                        "parallelism": "single GPU" if world == 1 else
-                       f"row-sharded x{world} + grouped p2p all-gather, {args.pieces} row pieces x {args.col_chunks} column chunks",
+                       f"row-sharded x{world} + per-hop all-gather ({info.get('exchange')}), {args.pieces} row pieces x {args.col_chunks} column chunks",
                        "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
                        "plan": info, "setup_s": round(setup_s, 2), "diagnostics": diag},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",

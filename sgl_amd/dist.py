@@ -85,7 +85,9 @@ class ShardedPropagator:
     all_piece_bounds: int64 array [world, pieces+1] of absolute row boundaries of every rank's pieces
                  (identical on all ranks)."""
 
-    def __init__(self, spmm_pieces, all_piece_bounds, rank, world, n_rows, group=None):
+    def __init__(self, spmm_pieces, all_piece_bounds, rank, world, n_rows, group=None, transport="p2p"):
+        self.transport = transport            # "p2p": grouped send/recv | "allgather": RCCL all-gather on padded pieces
+        self._ag_buf = {}
         self.spmm_pieces = spmm_pieces
         self.pb = np.asarray(all_piece_bounds, dtype=np.int64)
         self.rank, self.world, self.n = rank, world, int(n_rows)
@@ -94,8 +96,38 @@ class ShardedPropagator:
         assert self.pb.shape[0] == world and len(spmm_pieces) == self.pieces
         self.lo, self.hi = int(self.pb[rank, 0]), int(self.pb[rank, -1])
 
+    class _AllGatherWork:
+        """all_gather_into_tensor on equal-size padded pieces; wait() also scatters the valid rows into place"""
+
+        def __init__(self, work, staged, x_next, spans, max_rows):
+            self.work, self.staged, self.x_next, self.spans, self.max_rows = work, staged, x_next, spans, max_rows
+
+        def wait(self):
+            self.work.wait()
+            for q, (r0, r1) in enumerate(self.spans):
+                if r1 > r0:
+                    self.x_next[r0:r1].copy_(self.staged[q * self.max_rows:q * self.max_rows + (r1 - r0)])
+
+    def _exchange_piece_allgather(self, p, y_piece, x_next):
+        w = x_next.shape[1]
+        spans = [(int(self.pb[q, p]), int(self.pb[q, p + 1])) for q in range(self.world)]
+        max_rows = max(max(r1 - r0 for r0, r1 in spans), 1)
+        key = (p, x_next.data_ptr(), w, max_rows)       # one staging pair per (piece, destination buffer): never shared
+                                                          # between transfers that can be in flight together
+        if key not in self._ag_buf:
+            self._ag_buf[key] = (torch.zeros((max_rows, w), dtype=x_next.dtype, device=x_next.device),
+                                 torch.empty((self.world * max_rows, w), dtype=x_next.dtype, device=x_next.device))
+        inp, out = self._ag_buf[key]
+        inp[:y_piece.shape[0]].copy_(y_piece)
+        work = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+        mine = spans[self.rank]
+        spans_remote = [(r0, r1) if q != self.rank else (mine[0], mine[0]) for q, (r0, r1) in enumerate(spans)]
+        return [ShardedPropagator._AllGatherWork(work, out, x_next, spans_remote, max_rows)]
+
     def _exchange_piece(self, p, y_piece, x_next):
-        """post the point-to-point sends of my piece p and the receives of every peer's piece p"""
+        """post the transfers of my piece p to every peer and of every peer's piece p to me"""
+        if self.transport == "allgather":
+            return self._exchange_piece_allgather(p, y_piece, x_next)
         ops = []
         # stagger the peer order per rank so that at any moment every link carries one transfer
         for k in range(1, self.world):

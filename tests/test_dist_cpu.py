@@ -67,6 +67,12 @@ def _worker(rank, world, port, pieces, K, d, out_dir):
             for h in range(K + 1):
                 got = torch.cat(hc[h], dim=1)
                 ok = ok and np.array_equal(got.numpy(), ref[h][lo:hi])
+        # the collective transport (padded all_gather_into_tensor) is interchangeable with the send/recv one
+        prop_ag = ShardedPropagator(fns, pb, rank, world, n, transport="allgather")
+        hag = prop_ag.propagate(x, K)
+        ok = ok and all(np.array_equal(hag[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        hcg = prop_ag.propagate_chunked([x[:, :3].contiguous(), x[:, 3:].contiguous()], K)
+        ok = ok and all(np.array_equal(torch.cat(hcg[h], 1).numpy(), ref[h][lo:hi]) for h in range(K + 1))
         with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
             f.write("ok" if ok else "mismatch")
     finally:
