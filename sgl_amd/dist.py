@@ -124,10 +124,40 @@ class ShardedPropagator:
         spans_remote = [(r0, r1) if q != self.rank else (mine[0], mine[0]) for q, (r0, r1) in enumerate(spans)]
         return [ShardedPropagator._AllGatherWork(work, out, x_next, spans_remote, max_rows)]
 
+    class _StagedWork:
+        def __init__(self, works, recvs, x_next, keep):
+            self.works, self.recvs, self.x_next, self.keep = works, recvs, x_next, keep
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+            for buf, r0, r1 in self.recvs:
+                self.x_next[r0:r1].copy_(buf)
+
+    def _exchange_piece_staged(self, p, y_piece, x_next):
+        """Fallback for process groups that cannot move device memory (gloo): device -> host -> send/recv -> device.
+        Slow by construction (PCIe both ways, synchronises the stream); exists so that the sharded path also runs
+        where RCCL is unavailable -- and so that several ranks can be exercised end to end on ONE GPU in the tests."""
+        host = y_piece.detach().cpu()
+        ops, recvs = [], []
+        for k in range(1, self.world):
+            dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
+            if host.numel():
+                ops.append(dist.P2POp(dist.isend, host, dst, group=self.group))
+            r0, r1 = int(self.pb[src, p]), int(self.pb[src, p + 1])
+            if r1 > r0:
+                buf = torch.empty((r1 - r0, x_next.shape[1]), dtype=x_next.dtype)
+                ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+                recvs.append((buf, r0, r1))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return [ShardedPropagator._StagedWork(works, recvs, x_next, host)]
+
     def _exchange_piece(self, p, y_piece, x_next):
         """post the transfers of my piece p to every peer and of every peer's piece p to me"""
         if self.transport == "allgather":
             return self._exchange_piece_allgather(p, y_piece, x_next)
+        if self.transport == "staged":
+            return self._exchange_piece_staged(p, y_piece, x_next)
         ops = []
         # stagger the peer order per rank so that at any moment every link carries one transfer
         for k in range(1, self.world):
@@ -342,7 +372,10 @@ class ShardedGraphOp:
             rp_host = rowptr.cpu().numpy()
             pb = all_piece_bounds(rp_host, world, self.pieces)
             fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rank], rowptr_host=rp_host, strict=self.strict_order)
-            self._cache = (key, ShardedPropagator(fns, pb, rank, world, n, group=self.group), handles)
+            transport = "p2p"
+            if world > 1 and dist.get_backend(self.group) == "gloo":
+                transport = "staged"          # gloo cannot move device memory
+            self._cache = (key, ShardedPropagator(fns, pb, rank, world, n, group=self.group, transport=transport), handles)
         prop = self._cache[1]
         self.lo, self.hi = prop.lo, prop.hi
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
@@ -361,13 +394,15 @@ class ShardedGraphOp:
         if world == 1:
             return local
         prop = self._cache[1]
-        full = torch.empty((prop.n, local.shape[1]), dtype=local.dtype, device=local.device)
-        full[prop.lo:prop.hi].copy_(local)
+        staged = local.is_cuda and dist.get_backend(self.group) == "gloo"
+        send = local.detach().cpu() if staged else local.contiguous()
+        full = torch.empty((prop.n, local.shape[1]), dtype=local.dtype, device=send.device)
+        full[prop.lo:prop.hi].copy_(send)
         ops = []
         for k in range(1, world):
             dst, src = (rank + k) % world, (rank - k) % world
-            ops.append(dist.P2POp(dist.isend, local.contiguous(), dst, group=self.group))
+            ops.append(dist.P2POp(dist.isend, send, dst, group=self.group))
             ops.append(dist.P2POp(dist.irecv, full[int(prop.pb[src, 0]):int(prop.pb[src, -1])], src, group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        return full
+        return full.to(local.device) if staged else full

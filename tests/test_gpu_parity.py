@@ -765,6 +765,50 @@ def test_sharded_graph_op_world1_and_nafs_on_shards(goldens, cuda):
         assert op.gather_rows(hops[-1]) is hops[-1]
 
 
+def _two_rank_worker(rank, world, port, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle as orc
+    from inputs import hash_matrix as hm
+    from sgl_amd.dist import ShardedGraphOp
+    from sgl_amd.operators.message_op import OverSmoothDistanceWeightedOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(_os.path.join(root, "tests", "golden", "graphs.npz")))
+        adj = sp.csr_matrix((g["pl2000|data"], g["pl2000|indices"], g["pl2000|indptr"]), shape=(2000, 2000))
+        x = hm(2000, 100, seed=21)
+        op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, col_chunks=2)
+        hops = op.propagate(adj, x)                     # HIP kernels on cuda:0, exchange staged through gloo
+        ref = orc.propagate(orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5), x, 3)
+        ok = 0 < op.hi - op.lo < 2000
+        for h in range(4):
+            ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][op.lo:op.hi], 1e-5)
+        nafs = OverSmoothDistanceWeightedOp().aggregate([h.contiguous() for h in hops])
+        full = op.gather_rows(nafs.contiguous())         # config-4 flow: NAFS on the shards, then gather
+        ok = ok and orc.parity_ok(full.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_end_to_end(cuda, tmp_path):
+    """two processes, both driving cuda:0 with the HIP kernels, exchanging rows through gloo (staged transport):
+    the row-sharded NAFS flow (BASELINE config 4) end to end with a real multi-process group"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
     """Custom_Homo raw layout -> device COO->CSR build (sgl_coo_to_csr) == the reference's Edge/scipy build (G7),
     and a DeviceAdjacency drives GraphOp.propagate without touching the host"""
