@@ -123,6 +123,7 @@ class GpuEngine:
     tests/test_bench_orchestration.py substitutes a CPU/gloo engine to exercise the distributed orchestration
     (broadcast, shard bounds, exchange, barrier/MAX timing, JSON contract) without GPUs."""
     backend = "nccl"
+    transports = ("p2p", "allgather")     # process-group transports the auto-selection may choose from
 
     def __init__(self, local_rank):
         if not torch.cuda.is_available():
@@ -261,25 +262,30 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
         x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
         cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
-        if exchange == "push":
-            try:
-                if not dist.is_initialized():   # --force-sharded on one GPU: symmetric memory still needs a group
-                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                    os.environ.setdefault("MASTER_PORT", "29517")
-                    dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
-                    own_group = True
-                prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
-            except Exception as e:  # noqa: BLE001  (e.g. symmetric memory unavailable): use the RCCL transport
-                sys.stderr.write(f"[bench] push transport unavailable ({type(e).__name__}: {e}); using p2p\n")
-                exchange = "p2p"
+        def setup_push():
+            """collective; returns True iff every rank mapped every peer's replicas"""
+            nonlocal own_group
+            if not dist.is_initialized():   # --force-sharded on one GPU
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
+                own_group = True
+            prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
+            ok = prop.agree(prop.push_error is None, device)
+            if not ok and prop.push_error is not None:
+                sys.stderr.write(f"[bench] push transport unavailable on rank {rank}: {prop.push_error!r}\n")
+            return ok
+
+        if exchange == "push" and not setup_push():
+            exchange = "p2p"
         if exchange == "auto":
             # time one hop's exchange with each RCCL transport (untimed setup) and keep the faster one; the decision
             # is taken on the MAX over ranks so every rank picks the same
-            exchange = "p2p"
+            exchange = getattr(engine, "transports", ("p2p",))[0]
             if world > 1 and nbuf > 0:
                 ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
                 cand = {}
-                for tname in ("p2p", "allgather"):
+                for tname in getattr(engine, "transports", ("p2p", "allgather")):
                     prop.transport = tname
                     for rep in range(3):
                         if rep == 1:
@@ -292,7 +298,37 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                     cand[tname] = float(tt.item())
                 exchange = min(cand, key=cand.get)
                 info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
-        if exchange in ("p2p", "allgather"):
+                # third candidate: the fused push transport -- only if every rank could map its peers, its result
+                # matches the RCCL transport's, and a full propagation is measurably faster
+                if os.environ.get("SGL_BENCH_TRY_PUSH", "1") != "0" and hasattr(prop, "enable_push") and _handles:
+                    prop.transport = exchange
+                    if setup_push():
+                        ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+                        got_hops = prop.propagate_push(x_chunks, K)
+                        close = True
+                        for a_, b_ in zip(ref_hops[K], got_hops[K]):
+                            scale_ = float(a_.abs().max()) if a_.numel() else 0.0
+                            close = close and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
+                        if prop.agree(close, device):
+                            full = {}
+                            for tname, fn in ((exchange, lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
+                                              ("push", lambda: prop.propagate_push(x_chunks, K))):
+                                fn()
+                                engine.sync(); dist.barrier(); engine.sync()
+                                t_a = time.perf_counter()
+                                fn(); fn()
+                                engine.sync(); dist.barrier(); engine.sync()
+                                tt = torch.tensor([(time.perf_counter() - t_a) / 2], dtype=torch.float64, device=device)
+                                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                                full[tname] = float(tt.item())
+                            info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
+                            if full["push"] < 0.97 * full[exchange]:
+                                exchange = "push"
+                        else:
+                            info["push_rejected"] = "result mismatch"
+                    else:
+                        info["push_rejected"] = "mapping failed"
+        if exchange in ("p2p", "allgather", "staged"):
             prop.transport = exchange
         info["exchange"] = exchange
         if exchange == "push":

@@ -230,56 +230,103 @@ class ShardedPropagator:
 
     # ---- fused push: the SpMM kernel itself writes each finished row into every peer's replica --------------------
     def enable_push(self, chunk_widths, handles, device, group=None):
-        """Allocate the ping-pong feature replicas in torch symmetric memory (peer-mapped over xGMI) and exchange the
-        mappings.  Collective.  handles: the DeviceCSR objects of this rank's row pieces (device_piece_spmms)."""
-        import torch.distributed._symmetric_memory as symm
-        grp = group or self.group or dist.group.WORLD
+        """Allocate the ping-pong feature replicas (two per column chunk) and map every peer's replicas into this
+        process through CUDA/HIP IPC (torch.multiprocessing's tensor sharing: hipIpcGetMemHandle / OpenMemHandle with
+        lazy peer access -- needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver).  Collective.
+        handles: the DeviceCSR objects of this rank's row pieces (device_piece_spmms)."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        grp = group or self.group
         self._push_handles = handles
-        self._push = []
+        self._push_group = grp
+        self._push_local, self._push_ptrs, self._push_keep = [], [], []
         for w in chunk_widths:
-            slots = []
-            for _ in range(2):
-                t = symm.empty((self.n, int(w)), dtype=torch.float32, device=device)
-                slots.append((t, symm.rendezvous(t, grp)))
-            self._push.append(slots)
+            self._push_local.append([torch.empty((self.n, int(w)), dtype=torch.float32, device=device) for _ in range(2)])
+        if self.world == 1:
+            self._push_ptrs = [[[t.data_ptr()] for t in slots] for slots in self._push_local]
+            return self
+        # export (local, may fail) -> exchange (collective, every rank takes part even after a local failure, so
+        # nobody is left waiting) -> import (local, may fail).  The caller agrees on the outcome with agree().
+        self.push_error = None
+        try:
+            mine = [[reduce_tensor(t) for t in slots] for slots in self._push_local]
+        except Exception as e:  # noqa: BLE001
+            mine, self.push_error = None, e
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=grp)
+        try:
+            if self.push_error is None and any(m is None for m in everyone):
+                raise RuntimeError("a peer could not export its replicas")
+            for c, slots in enumerate(self._push_local):
+                per_slot = []
+                for b, t in enumerate(slots):
+                    ptrs = []
+                    for q in range(self.world):
+                        if q == self.rank:
+                            ptrs.append(t.data_ptr())
+                        else:
+                            fn, args = everyone[q][c][b]
+                            peer = fn(*args)                 # a tensor aliasing rank q's replica (IPC mapping)
+                            if tuple(peer.shape) != tuple(t.shape):
+                                raise RuntimeError("peer replica has an unexpected shape")
+                            self._push_keep.append(peer)
+                            ptrs.append(peer.data_ptr())
+                    per_slot.append(ptrs)
+                self._push_ptrs.append(per_slot)
+        except Exception as e:  # noqa: BLE001
+            self.push_error = self.push_error or e
         return self
+
+    def agree(self, ok, device):
+        """True iff `ok` holds on EVERY rank (all-reduce MIN): keeps the ranks' control flow identical"""
+        if self.world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
+    def _push_barrier(self, device):
+        """hop boundary of the push transport: my kernels (and with them my posted peer stores) have completed, then
+        every rank has said so -- after that all replicas hold the complete hop"""
+        torch.cuda.synchronize(device)
+        if self.world > 1:
+            dist.barrier(group=self._push_group)
 
     def propagate_push(self, x_chunks, prop_steps):
         """Same result as propagate_chunked, different transport: no send/recv at all.  Every rank's SpMM kernel
         stores its output rows into ALL ranks' next-hop replicas (sgl_spmm_multi_f32: local store + up to 7 posted
-        peer stores per row over xGMI), then one symmetric-memory barrier per hop orders the hop boundary.  Compute
-        and communication are the same instruction stream, so they overlap perfectly and no CU runs a copy kernel.
+        peer stores per row over xGMI); a device synchronise + process-group barrier closes the hop.  Compute and
+        communication are the same instruction stream, so they overlap perfectly and no CU runs a copy kernel.
         Needs enable_push().  Returns hops[h][c] = local shard [hi-lo, w_c] (copies: the replicas are recycled)."""
         C = len(x_chunks)
-        assert hasattr(self, "_push") and len(self._push) == C
+        assert hasattr(self, "_push_ptrs") and len(self._push_ptrs) == C
+        device = x_chunks[0].device
         hops = [[x[self.lo:self.hi] for x in x_chunks]]
         cur = list(x_chunks)
+        order = [self.rank] + [q for q in range(self.world) if q != self.rank]          # local replica first
         for h in range(1, prop_steps + 1):
             last = h == prop_steps
+            slot = (h - 1) % 2
             outs = []
             for c in range(C):
                 w_c = x_chunks[c].shape[1]
                 if last:
-                    y_local = torch.empty((self.hi - self.lo, w_c), dtype=torch.float32, device=x_chunks[c].device)
+                    y_local = torch.empty((self.hi - self.lo, w_c), dtype=torch.float32, device=device)
                     for p in range(self.pieces):
                         r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
                         if r1 > r0:
                             self.spmm_pieces[p](cur[c], y_local[r0:r1])
                     outs.append(y_local)
                     continue
-                t, hdl = self._push[c][(h - 1) % 2]
-                ptrs = list(hdl.buffer_ptrs)
-                order = [self.rank] + [q for q in range(self.world) if q != self.rank]     # local replica first
+                ptrs = self._push_ptrs[c][slot]
                 for p in range(self.pieces):
                     r0, r1 = int(self.pb[self.rank, p]), int(self.pb[self.rank, p + 1])
                     if r1 > r0:
                         self._push_handles[p].spmm_multi(cur[c], [ptrs[q] + r0 * w_c * 4 for q in order], w_c)
                 outs.append(None)
             if not last:
-                # all my rows of this hop are on their way; the barrier returns once every rank's kernels are done
-                self._push[0][(h - 1) % 2][1].barrier()
+                self._push_barrier(device)
                 for c in range(C):
-                    t = self._push[c][(h - 1) % 2][0]
+                    t = self._push_local[c][slot]
                     outs[c] = t[self.lo:self.hi].clone()
                     cur[c] = t
             hops.append(outs)

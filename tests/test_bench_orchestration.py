@@ -33,6 +33,7 @@ def _make_engine():
 
     class CpuEngine:
         backend = "gloo"
+        transports = ("p2p", "allgather")
 
         def __init__(self, local_rank):
             self.device = torch.device("cpu")
@@ -107,7 +108,7 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge*featdim/s" and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] and j["cpu_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather") and len(j["config"]["plan"]["exchange_candidates_ms"]) == 2
+    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather") and len(j["config"]["plan"]["exchange_candidates_ms"]) >= 1
     dg = j["config"]["diagnostics"]
     assert dg["spmm_only_ms_per_hop_max_rank"] > 0 and dg["exchange_only_ms_per_hop_max_rank"] > 0
     assert dg["exchange_inbound_GBps_per_rank"] > 0

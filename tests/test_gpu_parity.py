@@ -788,6 +788,25 @@ def _two_rank_worker(rank, world, port, out_dir):
         ok = 0 < op.hi - op.lo < 2000
         for h in range(4):
             ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][op.lo:op.hi], 1e-5)
+        # the fused push transport: each rank's SpMM kernel stores straight into the OTHER process's replica (HIP IPC)
+        from sgl_amd import device as dev_
+        from sgl_amd.dist import ShardedPropagator, all_piece_bounds, column_chunks, device_piece_spmms
+        ptr_, col_, val_ = orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5)
+        dv = torch.device("cuda", 0)
+        rp_d, c_d, v_d = (torch.from_numpy(ptr_).to(dv), torch.from_numpy(col_.astype(np.int32)).to(dv),
+                          torch.from_numpy(val_.astype(np.float32)).to(dv))
+        pb = all_piece_bounds(ptr_, world, 2)
+        fns, hs = device_piece_spmms(rp_d, c_d, v_d, 2000, pb[rank], strict=True)
+        prop = ShardedPropagator(fns, pb, rank, world, 2000)
+        chunks = column_chunks(100, 2)
+        xs = [torch.from_numpy(x[:, a:b].copy()).to(dv) for a, b in chunks]
+        prop.enable_push([b - a for a, b in chunks], hs, dv)
+        ok = ok and prop.agree(prop.push_error is None, torch.device("cpu"))
+        for rep in range(2):                                   # twice: the ping-pong replicas are recycled correctly
+            hp = prop.propagate_push(xs, 3)
+            for h in range(4):
+                got = torch.cat([t.contiguous() for t in hp[h]], dim=1).cpu().numpy()
+                ok = ok and orc.parity_ok(got, ref[h][prop.lo:prop.hi], 1e-5)
         nafs = OverSmoothDistanceWeightedOp().aggregate([h.contiguous() for h in hops])
         full = op.gather_rows(nafs.contiguous())         # config-4 flow: NAFS on the shards, then gather
         ok = ok and orc.parity_ok(full.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
@@ -807,6 +826,51 @@ def test_two_ranks_on_one_gpu_end_to_end(cuda, tmp_path):
     s.close()
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
+def _bench_worker(rank, world, port, out_dir):
+    import json as _json
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+
+    class OneGpuGlooEngine(bench.GpuEngine):
+        """both ranks on cuda:0; gloo cannot move device memory, so the process-group transport is the host-staged one"""
+        backend = "gloo"
+        transports = ("staged",)
+
+        def init_kwargs(self):
+            return {}
+
+    tiny = {"T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3)}
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_small", "--no-cpu-baseline"])
+    lines = []
+    bench.run(args, engine_cls=OneGpuGlooEngine, workloads=tiny, emit=lines.append)
+    with open(_os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        _json.dump(lines, f)
+
+
+def test_bench_auto_selects_validated_push_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """bench.py's N>1 path with REAL HIP kernels and two processes: the auto-selection times the process-group
+    transport, maps the peer replicas (HIP IPC), validates the fused push transport against it and adopts it"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    lines = json.load(open(tmp_path / "rank0.json"))
+    assert len(lines) == 1 and json.load(open(tmp_path / "rank1.json")) == []
+    j = json.loads(lines[0])
+    plan = j["config"]["plan"]
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert "push_rejected" not in plan, plan
+    assert set(plan["full_step_candidates_ms"]) == {"staged", "push"}
+    assert plan["exchange"] == "push"            # stores over IPC beat a PCIe round trip through the host
 
 
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
