@@ -272,6 +272,8 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                 own_group = True
             prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
             ok = prop.agree(prop.push_error is None, device)
+            if ok and getattr(prop, "push_skipped_fraction", None) is not None:
+                info["push_peer_rows_skipped"] = round(prop.push_skipped_fraction, 4)
             if not ok and prop.push_error is not None:
                 sys.stderr.write(f"[bench] push transport unavailable on rank {rank}: {prop.push_error!r}\n")
             return ok

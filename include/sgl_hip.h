@@ -110,7 +110,9 @@ int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int6
  * device pointers; entries beyond the first may point into peer GPUs' memory (IPC / symmetric memory): the kernel
  * then pushes each finished row to every replica over xGMI (row-sharded multi-GPU propagation). */
 int sgl_spmm_multi_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, int n_out, float *const *h_y, int64_t ldy,
-                       int64_t d, void *stream);
+                       int64_t d, const uint8_t *d_row_mask, void *stream);
+/* d_row_mask (optional, [n_rows] bytes on device): bit q set = destination q+1 receives this row; a peer whose shard
+ * never references column i does not need row i of the next feature block, so its store is skipped (NULL = all). */
 
 /* The hop loop of GraphOp.propagate (sgl/operators/base_op.py:29-35) in one call: Y_1 = A.X_0, Y_k = A.Y_{k-1}.
  * h_y / h_ldy: HOST arrays of n_hops device pointers / leading dimensions.  A must be square. */

@@ -121,11 +121,13 @@ struct SpmmArgs {
     // over xGMI from the producing kernel (sgl_spmm_multi_f32); n_more == 0 otherwise.
     float *y_more[7];
     int32_t n_more;
+    const uint8_t *row_mask;   // optional [n_rows]: bit q set = replica q needs this row (NULL = every replica gets it)
 };
 
 struct MultiOut {
     float *p[7];   // already offset to the item's first row
     int n;
+    const uint8_t *mask;   // already offset to the item's first row (or nullptr)
 };
 
 struct Epilogue {
@@ -266,9 +268,11 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                     }
                     st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
                     if constexpr (MULTI) {
+                        const int need = mo.mask ? (int)mo.mask[ri] : 0x7f;   // wave-uniform: one byte per row
 #pragma unroll
                         for (int q = 0; q < 7; ++q)  // replicas (peer memory): posted stores, nothing waits on them
-                            if (q < mo.n) *reinterpret_cast<V *>(mo.p[q] + (int64_t)ri * ldo + colofs[ch]) = v;
+                            if (q < mo.n && ((need >> q) & 1))
+                                *reinterpret_cast<V *>(mo.p[q] + (int64_t)ri * ldo + colofs[ch]) = v;
                     }
                 }
         }
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         none.on = 0;   // pieces hold partial sums: the epilogue runs in the fix-up kernel
         MultiOut solo;
         solo.n = 0;
+        solo.mask = nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, false>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
                                          a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0, solo);
     } else {
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         epi.on = a.epi;
         MultiOut mo;
         mo.n = MULTI ? a.n_more : 0;
+        mo.mask = (MULTI && a.row_mask) ? a.row_mask + row_begin : nullptr;
 #pragma unroll
         for (int q = 0; q < 7; ++q) mo.p[q] = (MULTI && q < a.n_more) ? a.y_more[q] + (int64_t)row_begin * a.ldy : nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, MULTI>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
@@ -341,9 +347,10 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
     if (epi.on) acc = epi_apply(acc, res ? res[(int64_t)row * ldres + k] : 0.f, epi, res != nullptr);
     *yp = acc;
+    const int need = mo.mask ? (int)mo.mask[row] : 0x7f;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
-        if (q < mo.n) mo.p[q][(int64_t)row * ldy + k] = acc;
+        if (q < mo.n && ((need >> q) & 1)) mo.p[q][(int64_t)row * ldy + k] = acc;
 }
 
 template <int VEC, int GROUP, int NCH, int U, bool NT>
@@ -510,6 +517,7 @@ struct EpiHost {
     int64_t ldres = 0;
     int n_more = 0;             // replicas of Y (sgl_spmm_multi_f32)
     float *y_more[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const uint8_t *row_mask = nullptr;
 };
 
 static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int d, int vec,
@@ -565,6 +573,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.epi_hi = eh.hi;
     a.epi = eh.on;
     a.n_more = eh.n_more;
+    a.row_mask = eh.row_mask;
     for (int q = 0; q < 7; ++q) a.y_more[q] = eh.y_more[q];
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
@@ -605,6 +614,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         fe.on = eh.on;
         MultiOut fmo;
         fmo.n = eh.n_more;
+        fmo.mask = eh.row_mask;
         for (int q = 0; q < 7; ++q) fmo.p[q] = eh.y_more[q];
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_long_row, h->d_long_first, h->d_partial, a.ldp,
                            d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo);
@@ -659,9 +669,10 @@ SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *
 // its finished rows straight into every peer's replica of the feature block over xGMI -- the all-gather between
 // hops without copy kernels, staging buffers or a separate communication phase.
 SGL_EXPORT int sgl_spmm_multi_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, int n_out, float *const *h_y, int64_t ldy,
-                                  int64_t d, void *stream) {
+                                  int64_t d, const uint8_t *d_row_mask, void *stream) {
     SGL_REQUIRE(n_out >= 1 && n_out <= 8 && h_y, "sgl_spmm_multi_f32: n_out must be in [1, 8]");
     EpiHost eh;
+    eh.row_mask = d_row_mask;
     eh.n_more = n_out - 1;
     for (int q = 1; q < n_out; ++q) eh.y_more[q - 1] = h_y[q];
     return spmm_impl(h, d_x, ldx, h_y[0], ldy, d, 0, stream, eh, "sgl_spmm_multi_f32");

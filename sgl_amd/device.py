@@ -146,9 +146,10 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
-    def spmm_multi(self, x, out_ptrs, ld):
+    def spmm_multi(self, x, out_ptrs, ld, row_mask=None):
         """A @ x stored into several [n_rows, d] matrices given as RAW device addresses (the first is normally local,
-        the others typically peer-GPU replicas obtained from torch symmetric memory) with leading dimension `ld`."""
+        the others peer-GPU replicas mapped through IPC) with leading dimension `ld`.  row_mask: optional uint8 CUDA
+        tensor [n_rows]; bit q set = destination q+1 gets that row."""
         _check_mat(x, "x")
         if x.shape[0] != self.shape[1]:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
@@ -157,7 +158,11 @@ class DeviceCSR:
             raise ValueError("between 1 and 8 output replicas are supported")
         arr = (c_void_p * n_out)(*[int(p) for p in out_ptrs])
         with torch.cuda.device(self.device):
-            check(lib().sgl_spmm_multi_f32(self._h, ptr(x), _ld(x), n_out, arr, int(ld), x.shape[1], current_stream_ptr()),
+            if row_mask is not None and not (row_mask.is_cuda and row_mask.dtype == torch.uint8 and row_mask.is_contiguous()
+                                             and row_mask.numel() == self.shape[0]):
+                raise ValueError("row_mask must be a contiguous uint8 CUDA tensor with one entry per row")
+            check(lib().sgl_spmm_multi_f32(self._h, ptr(x), _ld(x), n_out, arr, int(ld), x.shape[1],
+                                           ptr(row_mask) if row_mask is not None else None, current_stream_ptr()),
                   "sgl_spmm_multi_f32")
 
     def spmm_chain(self, x, n_hops, outs=None):

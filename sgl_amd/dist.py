@@ -243,6 +243,7 @@ class ShardedPropagator:
             self._push_local.append([torch.empty((self.n, int(w)), dtype=torch.float32, device=device) for _ in range(2)])
         if self.world == 1:
             self._push_ptrs = [[[t.data_ptr()] for t in slots] for slots in self._push_local]
+            self._push_masks, self.push_error = None, None
             return self
         # export (local, may fail) -> exchange (collective, every rank takes part even after a local failure, so
         # nobody is left waiting) -> import (local, may fail).  The caller agrees on the outcome with agree().
@@ -273,6 +274,29 @@ class ShardedPropagator:
                     per_slot.append(ptrs)
                 self._push_ptrs.append(per_slot)
         except Exception as e:  # noqa: BLE001
+            self.push_error = self.push_error or e
+        # which of MY rows does each peer actually gather?  rank q needs row i iff column i occurs in its shard, so the
+        # kernel skips the peer stores nobody would read (all-gather of one byte per node, once per graph)
+        self._push_masks = None
+        try:
+            needed = torch.zeros(self.n, dtype=torch.uint8, device=device)
+            for hd in handles:
+                if hd.col.numel():
+                    needed[hd.col.long()] = 1
+            gathered = [torch.empty_like(needed) for _ in range(self.world)]
+            dist.all_gather(gathered, needed, group=grp)
+            order = [q for q in range(self.world) if q != self.rank]
+            masks = []
+            for p in range(self.pieces):
+                r0, r1 = int(self.pb[self.rank, p]), int(self.pb[self.rank, p + 1])
+                m = torch.zeros(r1 - r0, dtype=torch.uint8, device=device)
+                for k, q in enumerate(order):
+                    m |= (gathered[q][r0:r1] << k)
+                masks.append(m.contiguous())
+            self._push_masks = masks
+            self.push_skipped_fraction = 1.0 - float(sum(int(torch.count_nonzero(gathered[q][self.lo:self.hi])) for q in order)) / \
+                max(1, (self.hi - self.lo) * len(order))
+        except Exception as e:  # noqa: BLE001  (the masks are an optimisation: without them every row goes everywhere)
             self.push_error = self.push_error or e
         return self
 
@@ -321,7 +345,8 @@ class ShardedPropagator:
                 for p in range(self.pieces):
                     r0, r1 = int(self.pb[self.rank, p]), int(self.pb[self.rank, p + 1])
                     if r1 > r0:
-                        self._push_handles[p].spmm_multi(cur[c], [ptrs[q] + r0 * w_c * 4 for q in order], w_c)
+                        mask = self._push_masks[p] if getattr(self, "_push_masks", None) else None
+                        self._push_handles[p].spmm_multi(cur[c], [ptrs[q] + r0 * w_c * 4 for q in order], w_c, row_mask=mask)
                 outs.append(None)
             if not last:
                 self._push_barrier(device)

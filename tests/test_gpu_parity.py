@@ -257,6 +257,15 @@ def test_spmm_multi_writes_every_replica(goldens, cuda):
                 csr.spmm_multi(x, [o.data_ptr() for o in outs], d)
                 for o in outs:
                     assert torch.equal(o, ref), (d, strict, n_out)
+                if n_out == 3:
+                    # row mask: destination 1 gets the even rows only, destination 2 the rows divisible by 3
+                    rows = torch.arange(n, device=cuda)
+                    mask = ((rows % 2 == 0).to(torch.uint8) | ((rows % 3 == 0).to(torch.uint8) << 1)).contiguous()
+                    outs = [torch.full((n, d), -7.0, device=cuda) for _ in range(3)]
+                    csr.spmm_multi(x, [o.data_ptr() for o in outs], d, row_mask=mask)
+                    assert torch.equal(outs[0], ref)
+                    for k, sel in ((1, rows % 2 == 0), (2, rows % 3 == 0)):
+                        assert torch.equal(outs[k][sel], ref[sel]) and bool((outs[k][~sel] == -7.0).all())
     with pytest.raises(ValueError):
         csr.spmm_multi(x, [], d)
 
