@@ -300,7 +300,11 @@ def _widened(feats, out):
     4 floats, run element-wise kernels over the padded width so they use 16-byte lanes.  Inputs' pad columns are
     only read, the output's pad columns belong to us."""
     n, d = out.shape
-    dp = round_up(d, 4)
+    strides = {t.stride(0) for t in list(feats) + [out]} if n > 1 else set()
+    if len(strides) == 1 and next(iter(strides)) % 4 == 0 and next(iter(strides)) > d:
+        dp = next(iter(strides))      # every buffer has the same pitch: stream whole rows, pad included (contiguous)
+    else:
+        dp = round_up(d, 4)
     if d == dp or n <= 1:
         return feats, out, d
     ok = all(f.stride(0) % 4 == 0 and f.stride(0) >= dp and f.data_ptr() % 16 == 0 for f in list(feats) + [out])

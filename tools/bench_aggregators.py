@@ -30,6 +30,8 @@ def timeit(fn, reps=7, warm=2):
 
 def main():
     n = int(os.environ.get("AGG_N", 2_449_029))
+    if os.environ.get("AGG_BLOCKS"):
+        _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)
     for d, H in ((100, 4), (128, 11), (147, 6), (16, 4)):
         feats = [dev.alloc_rows(n, d, device) for _ in range(H)]
