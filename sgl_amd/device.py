@@ -495,7 +495,11 @@ def gather_rows(x, idx):
     # device indices are range-checked inside the kernel (it traps on a bad index): no host round trip
     idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
     out = alloc_rows(idx.numel(), d, x.device)
+    # copy whole 16-byte lanes for any d: the source row's padding is readable and the destination's padding is ours
+    dp = round_up(d, 4)
+    d_copy = dp if (d != dp and n_rows > 1 and idx.numel() > 1 and x.stride(0) % 4 == 0 and x.stride(0) >= dp
+                    and out.stride(0) >= dp and x.data_ptr() % 16 == 0) else d
     with torch.cuda.device(x.device):
-        check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d,
+        check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d_copy,
                                         current_stream_ptr()), "sgl_gather_rows_f32")
     return out
