@@ -139,7 +139,8 @@ class GpuEngine:
         from sgl_amd import device as dev
         from sgl_amd import synthetic
         n, d = wl["n"], wl["d"]
-        a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=args.seed, device=self.device)
+        a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=args.seed, device=self.device,
+                                                       weight=2.0 if getattr(args, "dup2", False) else 1.0)
         rowptr, col, val = dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None)
         x0 = synthetic.features_torch(n, d, seed=args.seed, device=self.device,
                                       kind="pubmed" if args.workload.startswith("S0") else "normal")
@@ -194,6 +195,9 @@ def parse_args(argv=None):
                          "auto = time both during setup and keep the faster, or push = stores into peer replicas from "
                          "the SpMM kernel through torch symmetric memory (opt-in; falls back to p2p if unavailable)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dup2", action="store_true",
+                    help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "
+                         "bidirectional edge list and CSR construction sums the duplicates (dataset/ogbn.py:45-53)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the row-piece (multi-GPU) code path even with one GPU")
     return ap.parse_args(argv)
