@@ -170,6 +170,18 @@ class GpuEngine:
         from sgl_amd.dist import device_piece_spmms
         return device_piece_spmms(rowptr, col, val, n, my_bounds, rowptr_host=rp_host, strict=args.strict)
 
+    relay_transport = "relay"             # the grid layout's two-phase exchange over the process group
+
+    def pack_slice(self, x0, a, b):
+        """columns [a, b) of x0 as a contiguous matrix, zero-padded to a line-friendly row pitch (the pad columns are
+        multiplied too: zeros in, zeros out, no extra cache lines)"""
+        from sgl_amd import device as dev
+        w = b - a
+        out = torch.zeros((x0.shape[0], dev.row_pitch(w, growth=2.0) if w else 0), dtype=x0.dtype, device=x0.device)
+        if w:
+            out[:, :w] = x0[:, a:b]
+        return out
+
     def sync(self):
         torch.cuda.synchronize()
 
@@ -194,6 +206,11 @@ def parse_args(argv=None):
                     help="N>1 transport: grouped RCCL send/recv (p2p), RCCL all-gather on padded pieces (allgather), "
                          "auto = time both during setup and keep the faster, or push = stores into peer replicas from "
                          "the SpMM kernel through torch symmetric memory (opt-in; falls back to p2p if unavailable)")
+    ap.add_argument("--layout", choices=("auto", "rows", "cols", "grid"), default=os.environ.get("SGL_BENCH_LAYOUT", "auto"),
+                    help="N>1: rows = A_hat row-sharded + per-hop all-gather; cols = feature-sharded (each GPU runs the "
+                         "whole chain on d/N columns, no communication); grid = 2 row blocks x N/2 column slices with "
+                         "the pair exchange relayed over all links; auto = validate and time each, keep the fastest")
+    ap.add_argument("--grid-pieces", type=int, default=4, help="row pieces per rank of the grid layout")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dup2", action="store_true",
                     help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "
@@ -205,7 +222,7 @@ def parse_args(argv=None):
 
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     import torch.distributed as dist
-    from sgl_amd.dist import ShardedPropagator, all_piece_bounds, column_chunks
+    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_chunks, column_slices
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -252,107 +269,212 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     engine.sync()
 
     sharded = world > 1 or args.force_sharded
-    if not sharded:
-        step, info = engine.single_step(args, rowptr, col, val, x0, n, d, K)
-    else:
-        rp_host = rowptr.cpu().numpy()
-        pb = all_piece_bounds(rp_host, world, args.pieces)
-        pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
-        prop = ShardedPropagator(pieces, pb, rank, world, n)
-        exchange = args.exchange
-        chunks = column_chunks(d, args.col_chunks)
-        info = {"row_pieces": args.pieces, "col_chunks": chunks}
-        nbuf = min(2, max(K - 1, 0))
-        # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
-        x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
-        cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
-        def setup_push():
-            """collective; returns True iff every rank mapped every peer's replicas"""
-            nonlocal own_group
-            if not dist.is_initialized():   # --force-sharded on one GPU
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29517")
-                dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
-                own_group = True
-            prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
-            ok = prop.agree(prop.push_error is None, device)
-            if ok and getattr(prop, "push_skipped_fraction", None) is not None:
-                info["push_peer_rows_skipped"] = round(prop.push_skipped_fraction, 4)
-            if not ok and prop.push_error is not None:
-                sys.stderr.write(f"[bench] push transport unavailable on rank {rank}: {prop.push_error!r}\n")
-            return ok
-
-        if exchange == "push" and not setup_push():
-            exchange = "p2p"
-        if exchange == "auto":
-            # time one hop's exchange with each RCCL transport (untimed setup) and keep the faster one; the decision
-            # is taken on the MAX over ranks so every rank picks the same
-            exchange = getattr(engine, "transports", ("p2p",))[0]
-            if world > 1 and nbuf > 0:
-                ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
-                cand = {}
-                for tname in getattr(engine, "transports", ("p2p", "allgather")):
-                    prop.transport = tname
-                    for rep in range(3):
-                        if rep == 1:
-                            engine.sync(); dist.barrier(); engine.sync()
-                            t_a = time.perf_counter()
-                        prop.exchange_only(ys0, [b[0] for b in cbufs])
-                    engine.sync(); dist.barrier(); engine.sync()
-                    tt = torch.tensor([(time.perf_counter() - t_a) / 2], dtype=torch.float64, device=device)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    cand[tname] = float(tt.item())
-                exchange = min(cand, key=cand.get)
-                info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
-                # third candidate: the fused push transport -- only if every rank could map its peers, its result
-                # matches the RCCL transport's, and a full propagation is measurably faster
-                if os.environ.get("SGL_BENCH_TRY_PUSH", "1") != "0" and hasattr(prop, "enable_push") and _handles:
-                    prop.transport = exchange
-                    if setup_push():
-                        ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
-                        got_hops = prop.propagate_push(x_chunks, K)
-                        close = True
-                        for a_, b_ in zip(ref_hops[K], got_hops[K]):
-                            scale_ = float(a_.abs().max()) if a_.numel() else 0.0
-                            close = close and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
-                        if prop.agree(close, device):
-                            full = {}
-                            for tname, fn in ((exchange, lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
-                                              ("push", lambda: prop.propagate_push(x_chunks, K))):
-                                fn()
-                                engine.sync(); dist.barrier(); engine.sync()
-                                t_a = time.perf_counter()
-                                fn(); fn()
-                                engine.sync(); dist.barrier(); engine.sync()
-                                tt = torch.tensor([(time.perf_counter() - t_a) / 2], dtype=torch.float64, device=device)
-                                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                                full[tname] = float(tt.item())
-                            info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
-                            if full["push"] < 0.97 * full[exchange]:
-                                exchange = "push"
-                        else:
-                            info["push_rejected"] = "result mismatch"
-                    else:
-                        info["push_rejected"] = "mapping failed"
-        if exchange in ("p2p", "allgather", "staged"):
-            prop.transport = exchange
-        info["exchange"] = exchange
-        if exchange == "push":
-            def step():
-                prop.propagate_push(x_chunks, K)
-        elif len(chunks) == 1:
-            def step():
-                prop.propagate(x0, K, x_buffers=cbufs[0])
-        else:
-            def step():
-                prop.propagate_chunked(x_chunks, K, buffers=cbufs)
-    setup_s = time.perf_counter() - t_setup
+    prop = None
+    nbuf = min(2, max(K - 1, 0))
 
     def sync_all():
         engine.sync()
         if world > 1:
             dist.barrier()
             engine.sync()
+
+    def agree(ok):
+        """True iff `ok` holds on every rank: keeps the ranks' control flow identical"""
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def max_over_ranks(v):
+        if world == 1:
+            return float(v)
+        tt = torch.tensor([v], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    if not sharded:
+        step, info = engine.single_step(args, rowptr, col, val, x0, n, d, K)
+    else:
+        # Layout candidates for N ranks (sgl_amd/dist.py): "rows" = A_hat row-sharded + per-hop all-gather, "cols" =
+        # feature-sharded (every rank runs the whole chain on d/N columns, no communication), "grid" = 2 row blocks x
+        # N/2 column slices with the pair exchange relayed over all xGMI links.  auto: build each, validate its result
+        # against the single-GPU chain computed on this rank's own replica, time a full step, keep the fastest.
+        rp_host = rowptr.cpu().numpy()
+        info = {}
+        pack = getattr(engine, "pack_slice", lambda x, a, b: x[:, a:b].contiguous())
+        full_spmm = engine.piece_spmms(args, rowptr, col, val, n, np.array([0, n], dtype=np.int64), rp_host)[0][0]
+        ref_last = x0
+        for _ in range(K):
+            nxt = torch.empty_like(x0)
+            full_spmm(ref_last, nxt)
+            ref_last = nxt
+        ref_scale = max(float(ref_last.abs().max()), 1e-30)
+
+        def close(block, r0, r1, c0, c1):
+            want = ref_last[r0:r1, c0:c1]
+            return want.numel() == 0 or float((block - want).abs().max()) <= 1e-5 * ref_scale
+
+        def build_cols():
+            a, b = column_slices(d, world)[rank]
+            w = b - a
+            xs = pack(x0, a, b)
+            outs = [torch.empty_like(xs) for _ in range(K)]
+
+            def step_cols():
+                cur = xs
+                for h in range(K if w else 0):
+                    full_spmm(cur, outs[h])
+                    cur = outs[h]
+            return {"step": step_cols, "check": lambda: K == 0 or close(outs[K - 1][:, :w], 0, n, a, b),
+                    "describe": f"feature-sharded x{world} (each GPU: all rows x {w} of {d} columns, no communication)"}
+
+        def build_grid(row_groups):
+            layout = GridLayout(world, row_groups)
+            rg, cg = layout.coords(rank)
+            slices = column_slices(d, layout.col_groups)
+            pbg = all_piece_bounds(rp_host, row_groups, args.grid_pieces)
+            fns, _h = engine.piece_spmms(args, rowptr, col, val, n, pbg[rg], rp_host)
+            a, b = slices[cg]
+            w = b - a
+            xs = pack(x0, a, b)
+            widths = [pack(x0[:1], sa, sb).shape[1] for sa, sb in slices]
+            gprop = ShardedPropagator(fns, pbg, rg, row_groups, n, transport=getattr(engine, "relay_transport", "relay"),
+                                      layout=layout, me=rank, widths=widths)
+            bufs = [torch.empty_like(xs) for _ in range(nbuf)]
+
+            def check_grid():
+                hops = gprop.propagate(xs, K, x_buffers=bufs)
+                return close(hops[K][:, :w], gprop.lo, gprop.hi, a, b)
+            return {"step": lambda: gprop.propagate(xs, K, x_buffers=bufs), "check": check_grid,
+                    "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed "
+                                f"over all {world} ranks, {args.grid_pieces} row pieces"}
+
+        def build_rows():
+            nonlocal prop, own_group
+            pb = all_piece_bounds(rp_host, world, args.pieces)
+            pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
+            prop = ShardedPropagator(pieces, pb, rank, world, n)
+            exchange = args.exchange
+            chunks = column_chunks(d, args.col_chunks)
+            info.update({"row_pieces": args.pieces, "col_chunks": chunks})
+            # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
+            x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
+            cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
+
+            def setup_push():
+                """collective; returns True iff every rank mapped every peer's replicas"""
+                nonlocal own_group
+                if not dist.is_initialized():   # --force-sharded on one GPU
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29517")
+                    dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
+                    own_group = True
+                prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
+                ok = prop.agree(prop.push_error is None, device)
+                if ok and getattr(prop, "push_skipped_fraction", None) is not None:
+                    info["push_peer_rows_skipped"] = round(prop.push_skipped_fraction, 4)
+                if not ok and prop.push_error is not None:
+                    sys.stderr.write(f"[bench] push transport unavailable on rank {rank}: {prop.push_error!r}\n")
+                return ok
+
+            if exchange == "push" and not setup_push():
+                exchange = "p2p"
+            if exchange == "auto":
+                # time one hop's exchange with each RCCL transport (untimed setup) and keep the faster one; the decision
+                # is taken on the MAX over ranks so every rank picks the same
+                exchange = getattr(engine, "transports", ("p2p",))[0]
+                if world > 1 and nbuf > 0:
+                    ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
+                    cand = {}
+                    for tname in getattr(engine, "transports", ("p2p", "allgather")):
+                        prop.transport = tname
+                        for rep in range(3):
+                            if rep == 1:
+                                sync_all()
+                                t_a = time.perf_counter()
+                            prop.exchange_only(ys0, [b[0] for b in cbufs])
+                        sync_all()
+                        cand[tname] = max_over_ranks((time.perf_counter() - t_a) / 2)
+                    exchange = min(cand, key=cand.get)
+                    info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
+                    # third candidate: the fused push transport -- only if every rank could map its peers, its result
+                    # matches the RCCL transport's, and a full propagation is measurably faster
+                    if os.environ.get("SGL_BENCH_TRY_PUSH", "1") != "0" and hasattr(prop, "enable_push") and _handles:
+                        prop.transport = exchange
+                        if setup_push():
+                            ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+                            got_hops = prop.propagate_push(x_chunks, K)
+                            same = True
+                            for a_, b_ in zip(ref_hops[K], got_hops[K]):
+                                scale_ = float(a_.abs().max()) if a_.numel() else 0.0
+                                same = same and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
+                            if prop.agree(same, device):
+                                full = {}
+                                for tname, fn in ((exchange, lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
+                                                  ("push", lambda: prop.propagate_push(x_chunks, K))):
+                                    fn()
+                                    sync_all()
+                                    t_a = time.perf_counter()
+                                    fn(); fn()
+                                    sync_all()
+                                    full[tname] = max_over_ranks((time.perf_counter() - t_a) / 2)
+                                info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
+                                if full["push"] < 0.97 * full[exchange]:
+                                    exchange = "push"
+                            else:
+                                info["push_rejected"] = "result mismatch"
+                        else:
+                            info["push_rejected"] = "mapping failed"
+            if exchange in ("p2p", "allgather", "staged"):
+                prop.transport = exchange
+            info["exchange"] = exchange
+            if exchange == "push":
+                run_rows = lambda: prop.propagate_push(x_chunks, K)          # noqa: E731
+            elif len(chunks) == 1:
+                run_rows = lambda: [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0])]   # noqa: E731
+            else:
+                run_rows = lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)  # noqa: E731
+
+            def check_rows():
+                last = run_rows()[K]
+                return all(close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(last, chunks))
+            rows_diag.update(x_chunks=x_chunks, cbufs=cbufs)
+            return {"step": run_rows, "check": check_rows,
+                    "describe": f"row-sharded x{world} + per-hop all-gather ({exchange}), {args.pieces} row pieces x "
+                                f"{len(chunks)} column chunks"}
+
+        rows_diag = {}
+        builders = {"cols": build_cols, "rows": build_rows}
+        if world >= 4 and world % 2 == 0:
+            builders["grid"] = lambda: build_grid(2)
+        wanted = list(builders) if args.layout == "auto" else [args.layout]
+        if args.layout == "grid" and "grid" not in builders:
+            raise SystemExit("--layout grid needs an even number of at least 4 ranks")
+        cands, timing, rejected = {}, {}, []
+        for name in wanted:
+            c = builders[name]()
+            c["step"]()                                   # warm: plans, communicators, staging buffers
+            sync_all()
+            if not agree(bool(c["check"]())):
+                rejected.append(name)
+                continue
+            sync_all()
+            t_a = time.perf_counter()
+            c["step"](); c["step"]()
+            sync_all()
+            timing[name] = max_over_ranks((time.perf_counter() - t_a) / 2)
+            cands[name] = c
+        if not cands:
+            raise SystemExit(f"no multi-GPU layout reproduced the single-GPU result (tried {wanted})")
+        chosen = min(timing, key=timing.get)
+        info["layout"] = chosen
+        info["layout_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in timing.items()}
+        if rejected:
+            info["layout_rejected"] = rejected
+        info["parallelism"] = cands[chosen]["describe"]
+        step = cands[chosen]["step"]
+    setup_s = time.perf_counter() - t_setup
 
     for _ in range(args.warmup):
         step()
@@ -373,7 +495,9 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
 
     # ---- diagnostics (after the timed region, never part of `value`): the two halves of a sharded hop in isolation
     diag = None
-    if sharded and nbuf > 0:
+    if sharded and nbuf > 0 and rows_diag:
+        x_chunks, cbufs = rows_diag["x_chunks"], rows_diag["cbufs"]
+
         def timed_ms(fn, reps=3):
             fn()
             sync_all()
@@ -426,8 +550,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             "config": {"workload": f"{args.workload}: SGC prop_steps={K} pre-propagation on an ogbn-products-shaped "
                                    f"Chung-Lu graph, LaplacianGraphOp r=0.5",
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
-                       "parallelism": "single GPU" if world == 1 else
-                       f"row-sharded x{world} + per-hop all-gather ({info.get('exchange')}), {args.pieces} row pieces x {args.col_chunks} column chunks",
+                       "parallelism": info.get("parallelism", "single GPU") if sharded else "single GPU",
                        "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
                        "plan": info, "setup_s": round(setup_s, 2), "diagnostics": diag},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",

@@ -29,18 +29,27 @@ def expected_lines(ld, d):
     return sum((o + d * 4 + 127) // 128 for o in offs) / len(offs)
 
 
-def row_pitch(d):
+def row_pitch(d, growth=1.25):
     """Leading dimension (floats) for a hop matrix of width d.
 
     Always a multiple of 4 floats (16-byte aligned rows -> 16-byte lane accesses).  The SpMM is bound by the number of
     128-byte lines it pulls through the fabric, so when rounding the pitch up to a whole number of lines
-    makes every gathered row touch measurably fewer lines, take it: d = 147 -> 160 floats (5 lines instead of 5.5 on
-    average, +8 % memory), d = 500 -> 512; d = 100 stays 100 (always exactly 4 lines either way)."""
+    (or, for narrow rows, to a power of two that never straddles a line) makes every gathered row touch measurably
+    fewer lines, take it: d = 147 -> 160 floats (5 lines instead of 5.5 on average, +8 % memory), d = 500 -> 512,
+    d = 12 -> 16; d = 100 stays 100 (always exactly 4 lines either way).  `growth` caps the memory overhead."""
     d = max(int(d), 1)
     ld4, ld32 = round_up(d, 4), round_up(d, 32)
-    if ld32 != ld4 and ld32 <= 1.25 * ld4 and expected_lines(ld32, d) <= 0.97 * expected_lines(ld4, d):
-        return ld32
-    return ld4
+    cands = [(ld32, growth)]
+    if d < 32:
+        p2 = 4
+        while p2 < d:
+            p2 *= 2
+        cands.insert(0, (p2, max(growth, 1.34)))
+    best, best_lines = ld4, expected_lines(ld4, d)
+    for ld, cap in cands:
+        if ld != ld4 and ld <= cap * ld4 and expected_lines(ld, d) <= 0.97 * best_lines:
+            best, best_lines = ld, expected_lines(ld, d)
+    return best
 
 
 def alloc_rows(n, d, device, zero_pad=True):

@@ -11,13 +11,25 @@ and of every hop matrix.  Per hop:
                                                at once, no ring), while the next piece is still being computed
 
 The last hop needs no exchange.  Aggregators are row-wise, so they run on the local shards with zero traffic.
-Nothing here touches the data path on the host: buffers stay in HBM; torch.distributed is plumbing."""
+Nothing here touches the data path on the host: buffers stay in HBM; torch.distributed is plumbing.
+
+Grid layouts (GridLayout): SpMM is separable over feature columns, and 288 GB of HBM hold a replica of A_hat on every
+GPU, so the G ranks can also be arranged as Gr row blocks x Gc column slices.  A rank then multiplies its row block of
+A_hat with ITS column slice only and exchanges rows only inside its column group (Gr ranks):
+
+    Gc = G (feature-sharded): every rank runs the whole k-hop chain on d/G columns -- no exchange at all;
+    Gr = G (row-sharded):     the scheme above;
+    in between:               in-bound bytes per rank per hop drop to (Gr-1)/Gr * N * d/Gc * 4.
+
+xGMI is a point-to-point mesh, so an exchange inside a small column group would use only Gr-1 of a GPU's 7 links.  The
+"relay" transport spreads it over all of them: each row piece is cut into G stripes; phase 1 sends stripe q to rank q,
+phase 2 has q forward it to the ranks that need it (two link crossings per byte, but 7 links in parallel)."""
 import numpy as np
 import torch
 import torch.distributed as dist
 
 __all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "device_piece_spmms", "column_chunks",
-           "ShardedPropagator", "ShardedGraphOp"]
+           "column_slices", "GridLayout", "ShardedPropagator", "ShardedGraphOp"]
 
 
 def balanced_bounds(rowptr, parts):
@@ -77,6 +89,89 @@ def column_chunks(d, n_chunks=2):
     return out
 
 
+def column_slices(d, parts):
+    """Split d feature columns into `parts` contiguous slices of near-equal width (column groups of a GridLayout).
+    Slices may be empty when d < parts."""
+    base, extra = divmod(int(d), int(parts))
+    out, c = [], 0
+    for q in range(parts):
+        w = base + (1 if q < extra else 0)
+        out.append((c, c + w))
+        c += w
+    return out
+
+
+class GridLayout:
+    """world = row_groups x col_groups ranks.  Rank g works on row block g % row_groups of column slice
+    g // row_groups; the ranks of one column group exchange rows between hops, different column groups never talk
+    (except as relays of each other's traffic)."""
+
+    def __init__(self, world, row_groups):
+        world, row_groups = int(world), int(row_groups)
+        if row_groups < 1 or world % row_groups:
+            raise ValueError("row_groups must divide the world size")
+        self.world, self.row_groups, self.col_groups = world, row_groups, world // row_groups
+
+    def coords(self, g):
+        """(row block index, column group index) of global rank g"""
+        return g % self.row_groups, g // self.row_groups
+
+    def members(self, cg):
+        """global ranks of column group cg, ordered by row block"""
+        return [cg * self.row_groups + r for r in range(self.row_groups)]
+
+    def __repr__(self):
+        return f"GridLayout({self.row_groups} row blocks x {self.col_groups} column slices)"
+
+
+class _Works:
+    """a set of outstanding transfers: anything with .wait()"""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def advance(self):
+        pass
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+class _HostStagedXfer:
+    """device -> host copies are sent, host receive buffers are copied into their device views on wait()"""
+
+    def __init__(self, works, landings, keep):
+        self.works, self.landings, self.keep = works, landings, keep
+
+    def advance(self):
+        pass
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, buf in self.landings:
+            dst.copy_(buf)
+
+
+class _RelayExchange:
+    """two-phase transfer of one row piece: scatter the stripes to all ranks, then forward them"""
+
+    def __init__(self, prop, p, y_piece, x_next):
+        self.prop, self.p, self.y_piece, self.x_next = prop, p, y_piece, x_next
+        self.phase1 = prop._relay_phase1(p, y_piece, x_next)
+        self.phase2 = None
+
+    def advance(self):
+        if self.phase2 is None:
+            self.phase1.wait()
+            self.phase2 = self.prop._relay_phase2(self.p, self.y_piece, self.x_next)
+
+    def wait(self):
+        self.advance()
+        self.phase2.wait()
+
+
 class ShardedPropagator:
     """K-hop propagation of a row-sharded adjacency.
 
@@ -85,9 +180,16 @@ class ShardedPropagator:
     all_piece_bounds: int64 array [world, pieces+1] of absolute row boundaries of every rank's pieces
                  (identical on all ranks)."""
 
-    def __init__(self, spmm_pieces, all_piece_bounds, rank, world, n_rows, group=None, transport="p2p"):
-        self.transport = transport            # "p2p": grouped send/recv | "allgather": RCCL all-gather on padded pieces
+    def __init__(self, spmm_pieces, all_piece_bounds, rank, world, n_rows, group=None, transport="p2p",
+                 layout=None, me=None, widths=None):
+        """rank / world: this rank's row block index and the number of row blocks (= the size of its column group).
+        layout / me / widths: only for grid jobs -- the GridLayout, this rank's GLOBAL rank and the (padded) slice
+        width of every column group; without a layout the job is row-sharded over the whole process group and
+        global rank == row block index.  `group` is the process group the transports run on (the whole job's; the
+        "allgather" transport needs it to contain exactly the column group)."""
+        self.transport = transport            # "p2p" | "allgather" | "staged" | "relay" | "relay_staged"
         self._ag_buf = {}
+        self._relay_bufs = {}
         self.spmm_pieces = spmm_pieces
         self.pb = np.asarray(all_piece_bounds, dtype=np.int64)
         self.rank, self.world, self.n = rank, world, int(n_rows)
@@ -95,6 +197,35 @@ class ShardedPropagator:
         self.group = group
         assert self.pb.shape[0] == world and len(spmm_pieces) == self.pieces
         self.lo, self.hi = int(self.pb[rank, 0]), int(self.pb[rank, -1])
+        self.layout = layout
+        if layout is None:
+            self.me, self.members = rank, list(range(world))
+        else:
+            assert layout.row_groups == world and me is not None and layout.coords(me)[0] == rank
+            self.me, self.members = int(me), layout.members(layout.coords(me)[1])
+        self.widths = widths
+
+    # ---- transports -------------------------------------------------------------------------------------------------
+    def _xfer(self, sends, recvs, staged=False):
+        """post sends [(tensor, global peer)] and receives [(tensor view, global peer)] as one batch.  Per pair of
+        ranks the order of the sends equals the order of the matching receives on the other side."""
+        if not sends and not recvs:
+            return _Works([])
+        if not staged:
+            ops = [dist.P2POp(dist.isend, t, peer, group=self.group) for t, peer in sends] + \
+                  [dist.P2POp(dist.irecv, t, peer, group=self.group) for t, peer in recvs]
+            return _Works(dist.batch_isend_irecv(ops))
+        # process groups that cannot move device memory (gloo): device -> host -> send/recv -> device.  Slow by
+        # construction (PCIe both ways, synchronises the stream); exists so that the sharded paths also run where RCCL
+        # is unavailable -- and so that several ranks can be exercised end to end on ONE GPU in the tests.
+        keep = [t.detach().cpu() for t, _ in sends]
+        ops = [dist.P2POp(dist.isend, h, peer, group=self.group) for h, (_, peer) in zip(keep, sends)]
+        landings = []
+        for t, peer in recvs:
+            buf = torch.empty(t.shape, dtype=t.dtype)
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group))
+            landings.append((t, buf))
+        return _HostStagedXfer(dist.batch_isend_irecv(ops), landings, keep)
 
     class _AllGatherWork:
         """all_gather_into_tensor on equal-size padded pieces; wait() also scatters the valid rows into place"""
@@ -122,53 +253,98 @@ class ShardedPropagator:
         work = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         mine = spans[self.rank]
         spans_remote = [(r0, r1) if q != self.rank else (mine[0], mine[0]) for q, (r0, r1) in enumerate(spans)]
-        return [ShardedPropagator._AllGatherWork(work, out, x_next, spans_remote, max_rows)]
+        return _Works([ShardedPropagator._AllGatherWork(work, out, x_next, spans_remote, max_rows)])
 
-    class _StagedWork:
-        def __init__(self, works, recvs, x_next, keep):
-            self.works, self.recvs, self.x_next, self.keep = works, recvs, x_next, keep
-
-        def wait(self):
-            for w in self.works:
-                w.wait()
-            for buf, r0, r1 in self.recvs:
-                self.x_next[r0:r1].copy_(buf)
-
-    def _exchange_piece_staged(self, p, y_piece, x_next):
-        """Fallback for process groups that cannot move device memory (gloo): device -> host -> send/recv -> device.
-        Slow by construction (PCIe both ways, synchronises the stream); exists so that the sharded path also runs
-        where RCCL is unavailable -- and so that several ranks can be exercised end to end on ONE GPU in the tests."""
-        host = y_piece.detach().cpu()
-        ops, recvs = [], []
-        for k in range(1, self.world):
-            dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
-            if host.numel():
-                ops.append(dist.P2POp(dist.isend, host, dst, group=self.group))
-            r0, r1 = int(self.pb[src, p]), int(self.pb[src, p + 1])
-            if r1 > r0:
-                buf = torch.empty((r1 - r0, x_next.shape[1]), dtype=x_next.dtype)
-                ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
-                recvs.append((buf, r0, r1))
-        works = dist.batch_isend_irecv(ops) if ops else []
-        return [ShardedPropagator._StagedWork(works, recvs, x_next, host)]
-
-    def _exchange_piece(self, p, y_piece, x_next):
-        """post the transfers of my piece p to every peer and of every peer's piece p to me"""
-        if self.transport == "allgather":
-            return self._exchange_piece_allgather(p, y_piece, x_next)
-        if self.transport == "staged":
-            return self._exchange_piece_staged(p, y_piece, x_next)
-        ops = []
+    def _exchange_piece_direct(self, p, y_piece, x_next, staged):
+        """my piece p to every rank of my column group and theirs to me, one link per peer"""
+        sends, recvs = [], []
         # stagger the peer order per rank so that at any moment every link carries one transfer
         for k in range(1, self.world):
-            dst = (self.rank + k) % self.world
-            src = (self.rank - k) % self.world
+            dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
             if y_piece.numel():
-                ops.append(dist.P2POp(dist.isend, y_piece, dst, group=self.group))
+                sends.append((y_piece, self.members[dst]))
             r0, r1 = int(self.pb[src, p]), int(self.pb[src, p + 1])
             if r1 > r0:
-                ops.append(dist.P2POp(dist.irecv, x_next[r0:r1], src, group=self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+                recvs.append((x_next[r0:r1], self.members[src]))
+        return self._xfer(sends, recvs, staged)
+
+    # relay transport: stripe q of row block rg's piece p
+    def _stripe(self, rg, p, q):
+        r0, r1 = int(self.pb[rg, p]), int(self.pb[rg, p + 1])
+        W = self.layout.world
+        return r0 + (r1 - r0) * q // W, r0 + (r1 - r0) * (q + 1) // W
+
+    def _relay_buf(self, p, g, rows, width, like):
+        key = (p, g)
+        buf = self._relay_bufs.get(key)
+        if buf is None or buf.shape != (rows, width) or buf.device != like.device:
+            buf = torch.empty((rows, width), dtype=like.dtype, device=like.device)
+            self._relay_bufs[key] = buf
+        return buf
+
+    def _relay_phase1(self, p, y_piece, x_next):
+        """scatter: stripe q of my piece goes to rank q; I collect stripe `me` of EVERY rank's piece -- straight into
+        my replica when it comes from my own column group, into a relay buffer otherwise"""
+        L, me = self.layout, self.me
+        my_cg = L.coords(me)[1]
+        base = int(self.pb[self.rank, p])
+        sends, recvs = [], []
+        for k in range(1, L.world):
+            q, g = (me + k) % L.world, (me - k) % L.world
+            a, b = self._stripe(self.rank, p, q)
+            if b > a:
+                sends.append((y_piece[a - base:b - base], q))
+            rg_g, cg_g = L.coords(g)
+            a, b = self._stripe(rg_g, p, me)
+            if b > a:
+                dst = x_next[a:b] if cg_g == my_cg else self._relay_buf(p, g, b - a, self.widths[cg_g], x_next)
+                recvs.append((dst, g))
+        return self._xfer(sends, recvs, self.transport == "relay_staged")
+
+    def _relay_phase2(self, p, y_piece, x_next):
+        """forward: every rank `dst` gets, from me, stripe `me` of the pieces of the other ranks of ITS column group"""
+        L, me = self.layout, self.me
+        my_cg = L.coords(me)[1]
+        base = int(self.pb[self.rank, p])
+        sends, recvs = [], []
+        for k in range(1, L.world):
+            dst, src = (me + k) % L.world, (me - k) % L.world
+            cg_d = L.coords(dst)[1]
+            for g in L.members(cg_d):
+                if g == dst:
+                    continue
+                a, b = self._stripe(L.coords(g)[0], p, me)
+                if b <= a:
+                    continue
+                if g == me:
+                    t = y_piece[a - base:b - base]            # my own stripe never left
+                elif cg_d == my_cg:
+                    t = x_next[a:b]                           # I needed it myself: phase 1 put it into my replica
+                else:
+                    t = self._relay_buf(p, g, b - a, self.widths[cg_d], x_next)
+                sends.append((t, dst))
+            for g in self.members:
+                if g == me:
+                    continue
+                a, b = self._stripe(L.coords(g)[0], p, src)
+                if b > a:
+                    recvs.append((x_next[a:b], src))
+        return self._xfer(sends, recvs, self.transport == "relay_staged")
+
+    def _exchange_piece(self, p, y_piece, x_next):
+        """start moving my piece p to the ranks of my column group (and theirs to me).  Returns an object with
+        advance() (cheap; call it after more compute has been queued) and wait()."""
+        if self.transport in ("relay", "relay_staged"):
+            return _RelayExchange(self, p, y_piece, x_next)
+        if self.transport == "allgather":
+            return self._exchange_piece_allgather(p, y_piece, x_next)
+        return self._exchange_piece_direct(p, y_piece, x_next, self.transport == "staged")
+
+    def _exchanging(self):
+        """does a hop need an exchange?  (relay: every rank takes part even when its own column group is one rank)"""
+        if self.transport in ("relay", "relay_staged"):
+            return self.layout.world > 1 and self.layout.row_groups > 1
+        return self.world > 1
 
     def propagate(self, x_full, prop_steps, x_buffers=None):
         """x_full: [N, d] replica of the input features on this rank's device (row-major, contiguous).
@@ -193,10 +369,14 @@ class ShardedPropagator:
                 y_piece = y_local[r0:r1]
                 if r1 > r0:
                     self.spmm_pieces[p](cur, y_piece)
-                if not last and self.world > 1:
-                    works += self._exchange_piece(p, y_piece, x_next)
+                for w in works:                   # two-phase transports: earlier pieces move on while this one computed
+                    w.advance()
+                if not last and self._exchanging():
+                    works.append(self._exchange_piece(p, y_piece, x_next))
             if not last:
                 x_next[self.lo:self.hi].copy_(y_local)
+                for w in works:
+                    w.advance()
                 for w in works:
                     w.wait()
                 cur = x_next
@@ -222,9 +402,11 @@ class ShardedPropagator:
             works = []
             for p in range(self.pieces):
                 r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
-                if self.world > 1:
-                    works += self._exchange_piece(p, y_local[r0:r1], x_next)
+                if self._exchanging():
+                    works.append(self._exchange_piece(p, y_local[r0:r1], x_next))
             x_next[self.lo:self.hi].copy_(y_local)
+            for w in works:
+                w.advance()
             for w in works:
                 w.wait()
 
@@ -395,8 +577,8 @@ class ShardedPropagator:
                     y_piece = y_local[r0:r1]
                     if r1 > r0:
                         self.spmm_pieces[p](cur[c], y_piece)
-                    if not last and self.world > 1:
-                        pending[c] += self._exchange_piece(p, y_piece, x_next)
+                    if not last and self._exchanging():
+                        pending[c].append(self._exchange_piece(p, y_piece, x_next))
                 if not last:
                     x_next[self.lo:self.hi].copy_(y_local)
                     cur[c] = x_next
@@ -407,28 +589,37 @@ class ShardedPropagator:
 
 
 class ShardedGraphOp:
-    """GraphOp.propagate for one rank of a row-sharded job (BASELINE configs 4/5: NAFS / PaSca sweeps with the
-    adjacency row-sharded across the GPUs of a node).
+    """GraphOp.propagate for one rank of a multi-GPU job (BASELINE configs 4/5: NAFS / PaSca sweeps over the GPUs of
+    a node).
 
     Every rank passes the SAME full adjacency (scipy CSR or sgl_amd.io.DeviceAdjacency; it is normalised on the
     rank's own GPU -- identical kernels on identical inputs, so all ranks hold bit-identical A_hat) and the same full
-    feature matrix, and gets back the K+1 hop matrices restricted to ITS rows `[self.lo, self.hi)`.  MessageOps are
-    row-wise, so they apply to the local shards unchanged (e.g. OverSmoothDistanceWeightedOp for NAFS).
+    feature matrix, and gets back the K+1 hop matrices restricted to ITS block: rows `[self.lo, self.hi)` x columns
+    `[self.c0, self.c1)`.  `row_groups` picks the layout (see GridLayout): None = row-sharded over all ranks (the
+    block is full-width; MessageOps are row-wise, so they apply to the local shards unchanged, e.g.
+    OverSmoothDistanceWeightedOp for NAFS), 1 = feature-sharded (all rows, d/G columns, no communication at all;
+    column-wise aggregators -- last/sum/mean/max/min/simple_weighted -- apply unchanged), anything between = grid.
     288 GB per GPU make the replication affordable up to ogbn-papers100M (27 GB of CSR, two 57 GB feature replicas).
 
-    Works without torch.distributed (world size 1); with it, uses the default process group unless `group` is given."""
+    Works without torch.distributed (world size 1); with it, uses the default process group unless `group` is given
+    (row-sharded layout only: grid layouts address ranks of the default group)."""
 
-    def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None, device=None):
+    def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None,
+                 device=None, row_groups=None, transport=None):
         self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
         self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
         self.device = device
-        self.lo = self.hi = None
+        self.row_groups, self.transport = row_groups, transport
+        self.lo = self.hi = self.c0 = self.c1 = None
         self._cache = None
 
     def _ranks(self):
         if dist.is_available() and dist.is_initialized():
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
+
+    def _gloo(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
 
     def propagate(self, adj, feature):
         from . import device as dev
@@ -438,43 +629,86 @@ class ShardedGraphOp:
         if not isinstance(adj, DeviceAdjacency):
             adj = DeviceAdjacency.from_scipy(adj, device=device)
         n = adj.shape[0]
-        key = (id(adj), adj.col.data_ptr(), adj.nnz, world, rank)
+        row_groups = world if self.row_groups is None else int(self.row_groups)
+        layout = GridLayout(world, row_groups)
+        rg, cg = layout.coords(rank)
+        key = (id(adj), adj.col.data_ptr(), adj.nnz, world, rank, row_groups)
         if self._cache is None or self._cache[0] != key:
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, n, self.r, self.alpha)
             rp_host = rowptr.cpu().numpy()
-            pb = all_piece_bounds(rp_host, world, self.pieces)
-            fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rank], rowptr_host=rp_host, strict=self.strict_order)
-            transport = "p2p"
-            if world > 1 and dist.get_backend(self.group) == "gloo":
-                transport = "staged"          # gloo cannot move device memory
-            self._cache = (key, ShardedPropagator(fns, pb, rank, world, n, group=self.group, transport=transport), handles)
-        prop = self._cache[1]
-        self.lo, self.hi = prop.lo, prop.hi
+            pb = all_piece_bounds(rp_host, row_groups, self.pieces)
+            fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rg], rowptr_host=rp_host, strict=self.strict_order)
+            self._cache = (key, fns, pb, handles)
+        _, fns, pb, handles = self._cache
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
-        x = x.to(device=device, dtype=torch.float32).contiguous()
+        x = x.to(device=device, dtype=torch.float32)
         if x.shape[0] != n:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
-        chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
-        if len(chunks) == 1:
-            return prop.propagate(x, self.prop_steps)
-        hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
-        return [torch.cat(h, dim=1) for h in hops]
+        d = x.shape[1]
+        slices = column_slices(d, layout.col_groups)
+        self.c0, self.c1 = slices[cg]
+        if layout.col_groups == 1:
+            transport = self.transport or ("staged" if world > 1 and self._gloo() else "p2p")
+            prop = ShardedPropagator(fns, pb, rank, world, n, group=self.group, transport=transport)
+            self._prop = prop
+            self.lo, self.hi = prop.lo, prop.hi
+            x = x.contiguous()
+            chunks = column_chunks(d, self.col_chunks if world > 1 else 1)
+            if len(chunks) == 1:
+                return prop.propagate(x, self.prop_steps)
+            hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+            return [torch.cat(h, dim=1) for h in hops]
+        # grid / feature-sharded: the slice is stored zero-padded to a line-friendly pitch and multiplied at that width
+        # (the pad columns stay zero and cost no extra cache lines)
+        pitch = [dev.row_pitch(b - a, growth=2.0) if b > a else 0 for a, b in slices]
+        transport = self.transport or (("relay_staged" if self._gloo() else "relay") if row_groups > 1 else "p2p")
+        prop = ShardedPropagator(fns, pb, rg, row_groups, n, group=self.group, transport=transport, layout=layout,
+                                 me=rank, widths=pitch)
+        self._prop = prop
+        self.lo, self.hi = prop.lo, prop.hi
+        w = self.c1 - self.c0
+        xs = torch.zeros((n, pitch[cg]), dtype=torch.float32, device=device)
+        xs[:, :w] = x[:, self.c0:self.c1]
+        hops = prop.propagate(xs, self.prop_steps)
+        return [h[:, :w] for h in hops]
 
-    def gather_rows(self, local):
-        """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (e.g. the final aggregated features)"""
+    def gather_full(self, local):
+        """assemble the full [N, d] matrix on every rank from the ranks' blocks (e.g. the final aggregated features).
+        `local` is this rank's block: rows [lo, hi), any width (the same inside a column group); the column groups'
+        blocks are laid side by side in column-group order."""
         rank, world = self._ranks()
         if world == 1:
             return local
-        prop = self._cache[1]
-        staged = local.is_cuda and dist.get_backend(self.group) == "gloo"
-        send = local.detach().cpu() if staged else local.contiguous()
-        full = torch.empty((prop.n, local.shape[1]), dtype=local.dtype, device=send.device)
-        full[prop.lo:prop.hi].copy_(send)
-        ops = []
+        prop = self._prop
+        layout = prop.layout or GridLayout(world, world)
+        staged = local.is_cuda and self._gloo()
+        send = (local.detach().cpu() if staged else local).contiguous()
+        widths = [None] * world
+        dist.all_gather_object(widths, int(local.shape[1]), group=self.group)
+        col_w = [int(widths[layout.members(cg)[0]]) for cg in range(layout.col_groups)]
+        col_off = np.concatenate([[0], np.cumsum(col_w)])
+        total = int(col_off[-1])
+        full = torch.zeros((prop.n, total), dtype=local.dtype, device=send.device)
+        ops, landings = [], []
         for k in range(1, world):
             dst, src = (rank + k) % world, (rank - k) % world
-            ops.append(dist.P2POp(dist.isend, send, dst, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, full[int(prop.pb[src, 0]):int(prop.pb[src, -1])], src, group=self.group))
-        for w in dist.batch_isend_irecv(ops):
+            if send.numel():
+                ops.append(dist.P2POp(dist.isend, send, dst, group=self.group))
+            rg_s, cg_s = layout.coords(src)
+            r0, r1 = int(prop.pb[rg_s, 0]), int(prop.pb[rg_s, -1])
+            if (r1 - r0) * col_w[cg_s]:
+                buf = torch.empty((r1 - r0, col_w[cg_s]), dtype=local.dtype, device=send.device)
+                ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+                landings.append((r0, r1, int(col_off[cg_s]), buf))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        rg, cg = layout.coords(rank)
+        full[prop.lo:prop.hi, int(col_off[cg]):int(col_off[cg]) + local.shape[1]].copy_(send)
+        for w in works:
             w.wait()
+        for r0, r1, c, buf in landings:
+            full[r0:r1, c:c + buf.shape[1]].copy_(buf)
         return full.to(local.device) if staged else full
+
+    def gather_rows(self, local):
+        """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (row-sharded layout)"""
+        return self.gather_full(local)

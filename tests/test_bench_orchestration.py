@@ -80,14 +80,14 @@ def _make_engine():
     return CpuEngine
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, extra=()):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import bench
     args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_tiny",
-                             "--pieces", "3", "--col-chunks", "2", "--no-cpu-baseline"])
+                             "--pieces", "3", "--col-chunks", "2", "--no-cpu-baseline", *extra])
     lines = []
     out = bench.run(args, engine_cls=_make_engine(), workloads=TINY, emit=lines.append)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
@@ -112,6 +112,25 @@ def test_bench_two_ranks_gloo(tmp_path):
     dg = j["config"]["diagnostics"]
     assert dg["spmm_only_ms_per_hop_max_rank"] > 0 and dg["exchange_only_ms_per_hop_max_rank"] > 0
     assert dg["exchange_inbound_GBps_per_rank"] > 0
+    plan = j["config"]["plan"]
+    assert set(plan["layout_candidates_ms"]) == {"cols", "rows"} and plan["layout"] in ("cols", "rows")
+    assert "layout_rejected" not in plan and plan["layout"] == min(plan["layout_candidates_ms"], key=plan["layout_candidates_ms"].get)
+    assert j["config"]["parallelism"].startswith("feature-sharded" if plan["layout"] == "cols" else "row-sharded")
+
+
+def test_bench_four_ranks_gloo_all_layouts(tmp_path):
+    """N = 4: feature-sharded, row-sharded and the relayed 2 x 2 grid are all built, validated against the single-rank
+    chain and timed; an explicit --layout runs just that one"""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
+    assert j["n_gpus"] == 4 and j["value"] > 0
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "grid", "--grid-pieces", "2")), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    assert j["config"]["plan"]["layout"] == "grid" and j["config"]["parallelism"].startswith("grid 2 row blocks x 2 column slices")
+    assert j["config"]["diagnostics"] is None
 
 
 def test_bench_single_rank_contract(tmp_path, monkeypatch):

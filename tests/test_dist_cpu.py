@@ -85,3 +85,71 @@ def test_sharded_propagation_matches_single_process(tmp_path, world, pieces, K):
     mp.spawn(_worker, args=(world, port, pieces, K, 8, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir):
+    """grid job: rank (rg, cg) multiplies row block rg with column slice cg; exchanges stay inside the column group
+    (direct) or are spread over every rank of the job (relay)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle
+    from inputs import hash_matrix
+    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")))
+        indptr, indices, data = g["pl2000|indptr"], g["pl2000|indices"], g["pl2000|data"]
+        n = len(indptr) - 1
+        ptr, col, val = oracle.sym_norm_csr(indptr, indices, data, n, 0.5)
+        val = val.astype(np.float32)
+        layout = GridLayout(world, row_groups)
+        rg, cg = layout.coords(rank)
+        slices = column_slices(d, layout.col_groups)
+        pb = all_piece_bounds(ptr, row_groups, pieces)
+
+        def make_piece(r0, r1):
+            rp = (ptr[r0:r1 + 1] - ptr[r0]).astype(np.int64)
+            nb, ne = int(ptr[r0]), int(ptr[r1])
+            c, v = col[nb:ne], val[nb:ne]
+
+            def f(x, out):
+                out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c, v, x.numpy(), n_rows=r1 - r0)))
+            return f
+
+        fns = [make_piece(int(pb[rg, p]), int(pb[rg, p + 1])) for p in range(pieces)]
+        widths = [b - a for a, b in slices]
+        prop = ShardedPropagator(fns, pb, rg, row_groups, n, transport=transport, layout=layout, me=rank, widths=widths)
+        x = torch.from_numpy(hash_matrix(n, d, seed=5))
+        a, b = slices[cg]
+        ref = oracle.propagate((ptr, col, val), x.numpy(), K)
+        ok = True
+        for _ in range(2):                                    # second call: relay buffers and replicas are recycled
+            hops = prop.propagate(x[:, a:b].contiguous(), K)
+            ok = ok and len(hops) == K + 1 and all(
+                np.array_equal(hops[h].numpy(), ref[h][prop.lo:prop.hi, a:b]) for h in range(K + 1))
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,row_groups,pieces,K,transport", [
+    (4, 2, 2, 3, "relay"), (4, 2, 2, 3, "p2p"), (6, 3, 2, 3, "relay"), (8, 2, 3, 2, "relay"), (4, 4, 1, 2, "relay"),
+    (3, 1, 2, 2, "p2p"), (6, 2, 1, 2, "relay"), (4, 2, 2, 2, "staged"), (4, 2, 2, 2, "relay_staged")])
+def test_grid_layouts_match_single_process(tmp_path, world, row_groups, pieces, K, transport):
+    port = _free_port()
+    mp.spawn(_grid_worker, args=(world, port, row_groups, pieces, K, 11, transport, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_grid_layout_arithmetic():
+    from sgl_amd.dist import GridLayout, column_slices
+    L = GridLayout(8, 2)
+    assert (L.row_groups, L.col_groups) == (2, 4) and L.members(3) == [6, 7] and L.coords(5) == (1, 2)
+    assert sorted(g for cg in range(4) for g in L.members(cg)) == list(range(8))
+    with pytest.raises(ValueError):
+        GridLayout(8, 3)
+    assert column_slices(100, 8) == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 64), (64, 76), (76, 88), (88, 100)]
+    assert column_slices(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)] and column_slices(100, 1) == [(0, 100)]

@@ -819,6 +819,17 @@ def _two_rank_worker(rank, world, port, out_dir):
         nafs = OverSmoothDistanceWeightedOp().aggregate([h.contiguous() for h in hops])
         full = op.gather_rows(nafs.contiguous())         # config-4 flow: NAFS on the shards, then gather
         ok = ok and orc.parity_ok(full.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        # feature-sharded layout: every rank runs the whole chain on its column slice, no exchange; a column-wise
+        # aggregator (mean) applies to the slices unchanged and gather_full() assembles the full matrix
+        from sgl_amd.operators.message_op import MeanMessageOp
+        opc = ShardedGraphOp(3, r=0.5, strict_order=True, row_groups=1)
+        hc = opc.propagate(adj, x)
+        ok = ok and (opc.lo, opc.hi) == (0, 2000) and opc.c1 - opc.c0 == 50
+        for h in range(4):
+            ok = ok and np.array_equal(hc[h].cpu().numpy(), ref[h][:, opc.c0:opc.c1])
+        mean = MeanMessageOp(0, 4).aggregate([h.contiguous() for h in hc])
+        fullc = opc.gather_full(mean)
+        ok = ok and orc.parity_ok(fullc.cpu().numpy(), orc.agg_mean(ref, 0, 4), 1e-6, rowwise=False)
         open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
@@ -837,7 +848,51 @@ def test_two_ranks_on_one_gpu_end_to_end(cuda, tmp_path):
     assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
 
 
-def _bench_worker(rank, world, port, out_dir):
+def _grid_rank_worker(rank, world, port, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle as orc
+    from inputs import hash_matrix as hm
+    from sgl_amd.dist import ShardedGraphOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(_os.path.join(root, "tests", "golden", "graphs.npz")))
+        adj = sp.csr_matrix((g["pl2000|data"], g["pl2000|indices"], g["pl2000|indptr"]), shape=(2000, 2000))
+        x = hm(2000, 50, seed=23)
+        ref = orc.propagate(orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5), x, 3)
+        ok = True
+        for transport in (None, "staged"):                    # relayed over all 4 ranks / direct inside the pair
+            op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport=transport)
+            hops = op.propagate(adj, x)
+            ok = ok and op.c1 - op.c0 == 25 and 0 < op.hi - op.lo < 2000
+            for h in range(4):
+                ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
+            full = op.gather_full(hops[3])
+            ok = ok and np.array_equal(full.cpu().numpy(), ref[3])
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_ranks_on_one_gpu_grid_layout(cuda, tmp_path):
+    """2 row blocks x 2 column slices with four processes driving cuda:0: the pair exchange relayed through the
+    other pair (two-phase, host-staged here because gloo cannot move device memory) and the direct variant"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_grid_rank_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(4)] == ["ok"] * 4
+
+
+def _bench_worker(rank, world, port, out_dir, extra=()):
     import json as _json
     import os as _os
     import sys as _sys
@@ -850,12 +905,14 @@ def _bench_worker(rank, world, port, out_dir):
         """both ranks on cuda:0; gloo cannot move device memory, so the process-group transport is the host-staged one"""
         backend = "gloo"
         transports = ("staged",)
+        relay_transport = "relay_staged"
 
         def init_kwargs(self):
             return {}
 
     tiny = {"T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3)}
-    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_small", "--no-cpu-baseline"])
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_small", "--no-cpu-baseline",
+                             *extra])
     lines = []
     bench.run(args, engine_cls=OneGpuGlooEngine, workloads=tiny, emit=lines.append)
     with open(_os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
@@ -880,6 +937,24 @@ def test_bench_auto_selects_validated_push_with_two_ranks_on_one_gpu(cuda, tmp_p
     assert "push_rejected" not in plan, plan
     assert set(plan["full_step_candidates_ms"]) == {"staged", "push"}
     assert plan["exchange"] == "push"            # stores over IPC beat a PCIe round trip through the host
+    # both layouts were validated against the single-GPU chain; with no real links between the two processes the
+    # communication-free feature-sharded layout must win
+    assert set(plan["layout_candidates_ms"]) == {"cols", "rows"} and "layout_rejected" not in plan
+    assert plan["layout"] == "cols" and j["config"]["parallelism"].startswith("feature-sharded x2")
+
+
+def test_bench_grid_layout_with_four_ranks_on_one_gpu(cuda, tmp_path):
+    """bench.py --layout grid with real kernels: 2 x 2 grid, relayed exchange, validated against the single-GPU chain"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bench_worker, args=(4, port, str(tmp_path), ("--layout", "grid")), nprocs=4, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
+    assert j["n_gpus"] == 4 and j["value"] > 0 and j["config"]["plan"]["layout"] == "grid"
+    assert "layout_rejected" not in j["config"]["plan"]
 
 
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
