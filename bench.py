@@ -8,10 +8,12 @@ One "step" = one full k-hop propagation (prop_steps SpMM launches, k=3 for the h
 61.86 M undirected edges, d=100; sgl_amd/synthetic.py).  A_hat, X and all hop buffers are resident in HBM when
 the timed region starts.  value = nnz(A_hat) * d * k * steps / time  [edge*featdim/s], whole job.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): A_hat is row-sharded (nnz-balanced), every rank
-keeps a full replica of the current feature block and the per-hop all-gather runs as grouped point-to-point
-RCCL transfers overlapped with the SpMM of the next row piece (sgl_amd/dist.py).  Total work is fixed ->
-"scaling": "strong".
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank holds A_hat; the job is laid out as
+row blocks x column slices (sgl_amd/dist.py): "rows" = A_hat row-sharded (nnz-balanced) + per-hop all-gather over
+RCCL overlapped with the SpMM of the next row piece, "cols" = feature-sharded (each rank runs the whole chain on d/N
+columns, no communication), "grid" = 2 row blocks x N/2 column slices with the pair exchange relayed over all xGMI
+links.  --layout auto (default) validates every candidate against the single-GPU chain and keeps the fastest.
+Total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
   roofline     : dominant kernel (spmm_kernel) algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
