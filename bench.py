@@ -402,7 +402,9 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                     info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
                     # third candidate: the fused push transport -- only if every rank could map its peers, its result
                     # matches the RCCL transport's, and a full propagation is measurably faster
-                    if os.environ.get("SGL_BENCH_TRY_PUSH", "1") != "0" and hasattr(prop, "enable_push") and _handles:
+                    # (opt-in, SGL_BENCH_TRY_PUSH=1: a fault in a peer store would take the whole job down, and at
+                    # every N the layouts below beat what a row-sharded exchange can reach over one link per peer)
+                    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") == "1" and hasattr(prop, "enable_push") and _handles:
                         prop.transport = exchange
                         if setup_push():
                             ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)

@@ -898,7 +898,8 @@ def _bench_worker(rank, world, port, out_dir, extra=()):
     import sys as _sys
     root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
     _sys.path.insert(0, root)
-    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       SGL_BENCH_TRY_PUSH="1")
     import bench
 
     class OneGpuGlooEngine(bench.GpuEngine):
