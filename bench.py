@@ -457,10 +457,18 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             raise SystemExit("--layout grid needs an even number of at least 4 ranks")
         cands, timing, rejected = {}, {}, []
         for name in wanted:
-            c = builders[name]()
-            c["step"]()                                   # warm: plans, communicators, staging buffers
-            sync_all()
-            if not agree(bool(c["check"]())):
+            # a candidate that raises is dropped on EVERY rank (the code path is the same on all of them, so an error
+            # is too; agree() keeps the control flow identical even if it is not)
+            c, good = None, True
+            try:
+                c = builders[name]()
+                c["step"]()                               # warm: plans, communicators, staging buffers
+                sync_all()
+                good = bool(c["check"]())
+            except Exception as e:  # noqa: BLE001
+                good = False
+                sys.stderr.write(f"[bench] layout {name!r} failed on rank {rank}: {e!r}\n")
+            if not agree(good):
                 rejected.append(name)
                 continue
             sync_all()

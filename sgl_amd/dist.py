@@ -155,12 +155,26 @@ class _HostStagedXfer:
 
 
 class _RelayExchange:
-    """two-phase transfer of one row piece: scatter the stripes to all ranks, then forward them"""
+    """two-phase transfer of one row piece: scatter the stripes to all ranks, then forward them.
+
+    On a GPU process group both phases are issued at once from a side stream (which first waits for the piece's SpMM):
+    phase 2 then follows phase 1 on the communicator's stream without ever making the compute stream wait, so the
+    SpMM of the next pieces overlaps both.  Elsewhere (gloo: transfers complete asynchronously on host threads) phase
+    2 is posted by advance() once phase 1 has landed."""
 
     def __init__(self, prop, p, y_piece, x_next):
         self.prop, self.p, self.y_piece, self.x_next = prop, p, y_piece, x_next
-        self.phase1 = prop._relay_phase1(p, y_piece, x_next)
         self.phase2 = None
+        if x_next.is_cuda and prop.transport == "relay":
+            main = torch.cuda.current_stream(x_next.device)
+            side = prop._side_stream(x_next.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.phase1 = prop._relay_phase1(p, y_piece, x_next)
+                self.phase1.wait()                      # the SIDE stream waits; the compute stream runs on
+                self.phase2 = prop._relay_phase2(p, y_piece, x_next)
+        else:
+            self.phase1 = prop._relay_phase1(p, y_piece, x_next)
 
     def advance(self):
         if self.phase2 is None:
@@ -273,6 +287,11 @@ class ShardedPropagator:
         r0, r1 = int(self.pb[rg, p]), int(self.pb[rg, p + 1])
         W = self.layout.world
         return r0 + (r1 - r0) * q // W, r0 + (r1 - r0) * (q + 1) // W
+
+    def _side_stream(self, device):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def _relay_buf(self, p, g, rows, width, like):
         key = (p, g)
