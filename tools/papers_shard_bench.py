@@ -62,6 +62,30 @@ def main():
           f"{nnz / (ms * 1e-3) / 1e9:.2f} G gathers/s, algorithmic-roofline fraction {alg / (ms * 1e-3) / 8e12:.3f}", flush=True)
     inbound = (7 / 8) * n_cols * d * 4
     print(f"PAPERS shard: all-gather in-bound per rank per hop {inbound / 1e9:.1f} GB -> >= {inbound / 537e9 * 1e3:.0f} ms at 7 x 76.8 GB/s", flush=True)
+    # the other layouts of DESIGN.md section 6 on the same row block: column slices of the replica (16 columns = the
+    # feature-sharded layout at 8 ranks, 32 columns = the 2 x 4 grid).  A feature-sharded rank multiplies ALL rows, i.e.
+    # 8 blocks like this one, a grid rank 4 of them.
+    del x, y
+    for w, blocks, what in ((16, 8, "feature-sharded x8: no communication"),
+                            (32, 4, f"grid 2 x 4: {n_cols / 2 * 32 * 4 / 1e9:.1f} GB in-bound per hop, relayed over 7 links")):
+        xs = torch.empty((n_cols, w), device=device)
+        xs.normal_(generator=g)
+        ys = torch.empty((rows, w), device=device)
+        for _ in range(2):
+            csr.spmm(xs, out=ys)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            csr.spmm(xs, out=ys)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms_w = float(np.median(ts))
+        print(f"PAPERS slice: {w} columns ({n_cols * w * 4 / 1e9:.1f} GB slice): {ms_w:.2f} ms for this row block, "
+              f"{nnz / (ms_w * 1e-3) / 1e9:.2f} G gathers/s -> {blocks} blocks = {blocks * ms_w:.0f} ms per hop per rank ({what})", flush=True)
+        del xs, ys
 
 
 if __name__ == "__main__":
