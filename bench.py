@@ -222,9 +222,307 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+class _Job:
+    """What the layout builders and the timing code share: the workload replica of this rank, the ranks' agreement
+    helpers and the knobs.  One instance per bench.run()."""
+
+    def __init__(self, args, engine, rank, world, wl):
+        self.args, self.engine, self.device = args, engine, engine.device
+        self.rank, self.world = rank, world
+        self.n, self.d, self.K = wl["n"], wl["d"], wl["k"]
+        self.nbuf = min(2, max(self.K - 1, 0))           # ping-pong replicas a multi-hop exchange needs
+        self.rowptr = self.col = self.val = self.x0 = self.rp_host = None
+        self.own_group = False
+        self.info = {}                                    # -> config.plan of the JSON line
+        # columns [a, b) of the feature block as the matrix a layout multiplies (engines may pad it to a line pitch)
+        self.engine_pack = getattr(engine, "pack_slice", lambda x, a, b: x[:, a:b].contiguous())
+
+    # ---- agreement between ranks ------------------------------------------------------------------------------------
+    def sync_all(self):
+        import torch.distributed as dist
+        self.engine.sync()
+        if self.world > 1:
+            dist.barrier()
+            self.engine.sync()
+
+    def agree(self, ok):
+        """True iff `ok` holds on every rank: keeps the ranks' control flow identical"""
+        import torch.distributed as dist
+        if self.world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def max_over_ranks(self, v):
+        import torch.distributed as dist
+        if self.world == 1:
+            return float(v)
+        tt = torch.tensor([v], dtype=torch.float64, device=self.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed_s(self, fn, reps=2, warm=1):
+        """seconds per call, MAX over ranks, bracketed by barriers"""
+        for _ in range(warm):
+            fn()
+        self.sync_all()
+        t_a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        self.sync_all()
+        return self.max_over_ranks((time.perf_counter() - t_a) / reps)
+
+    def ensure_group(self):
+        """a process group even for --force-sharded on one GPU (the push transport's setup is collective)"""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group(self.engine.backend, rank=0, world_size=1, **self.engine.init_kwargs())
+            self.own_group = True
+
+    # ---- workload -----------------------------------------------------------------------------------------------
+    def load_workload(self, wl):
+        """rank 0 generates + normalises (untimed), everybody receives a replica"""
+        import torch.distributed as dist
+        n, d, device = self.n, self.d, self.device
+        if self.rank == 0:
+            rowptr, col, val, x0 = self.engine.build_workload(self.args, wl)
+            meta = torch.tensor([col.numel()], dtype=torch.int64, device=device)
+        else:
+            meta = torch.zeros(1, dtype=torch.int64, device=device)
+        if self.world > 1:
+            dist.broadcast(meta, 0)
+            nnz = int(meta.item())
+            if self.rank != 0:
+                rowptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+                col = torch.empty(nnz, dtype=torch.int32, device=device)
+                val = torch.empty(nnz, dtype=torch.float32, device=device)
+                x0 = torch.empty((n, d), dtype=torch.float32, device=device)
+            for t in (rowptr, col, val, x0):
+                dist.broadcast(t, 0)
+        self.rowptr, self.col, self.val, self.x0 = rowptr, col, val, x0
+        self.nnz = int(col.numel())
+        self.engine.sync()
+
+    def piece_spmms(self, bounds):
+        if self.rp_host is None:
+            self.rp_host = self.rowptr.cpu().numpy()
+        return self.engine.piece_spmms(self.args, self.rowptr, self.col, self.val, self.n, bounds, self.rp_host)
+
+
+class _Reference:
+    """The single-GPU k-hop chain computed on this rank's own replica: what every multi-GPU layout must reproduce."""
+
+    def __init__(self, job):
+        self.full_spmm = job.piece_spmms(np.array([0, job.n], dtype=np.int64))[0][0]
+        last = job.x0
+        for _ in range(job.K):
+            nxt = torch.empty_like(job.x0)
+            self.full_spmm(last, nxt)
+            last = nxt
+        self.last = last
+        self.scale = max(float(last.abs().max()), 1e-30)
+
+    def close(self, block, r0, r1, c0, c1):
+        want = self.last[r0:r1, c0:c1]
+        return want.numel() == 0 or float((block - want).abs().max()) <= 1e-5 * self.scale
+
+
+# ---- the layout candidates of an N-rank job (sgl_amd/dist.py).  Each builder returns {"step", "check", "describe"} ------
+
+def _build_cols(job, ref):
+    """feature-sharded: every rank runs the whole chain on d/N columns, no communication"""
+    from sgl_amd.dist import column_slices
+    a, b = column_slices(job.d, job.world)[job.rank]
+    w, K = b - a, job.K
+    xs = job.engine_pack(job.x0, a, b)
+    outs = [torch.empty_like(xs) for _ in range(K)]
+
+    def step():
+        cur = xs
+        for h in range(K if w else 0):
+            ref.full_spmm(cur, outs[h])
+            cur = outs[h]
+    return {"step": step, "check": lambda: K == 0 or ref.close(outs[K - 1][:, :w], 0, job.n, a, b),
+            "describe": f"feature-sharded x{job.world} (each GPU: all rows x {w} of {job.d} columns, no communication)"}
+
+
+def _build_grid(job, ref, row_groups):
+    """row_groups row blocks x N/row_groups column slices, the exchange inside a column group relayed over all ranks"""
+    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices
+    args, K = job.args, job.K
+    layout = GridLayout(job.world, row_groups)
+    rg, cg = layout.coords(job.rank)
+    slices = column_slices(job.d, layout.col_groups)
+    if job.rp_host is None:
+        job.rp_host = job.rowptr.cpu().numpy()
+    pb = all_piece_bounds(job.rp_host, row_groups, args.grid_pieces)
+    fns, _handles = job.piece_spmms(pb[rg])
+    a, b = slices[cg]
+    w = b - a
+    xs = job.engine_pack(job.x0, a, b)
+    widths = [job.engine_pack(job.x0[:1], sa, sb).shape[1] for sa, sb in slices]
+    prop = ShardedPropagator(fns, pb, rg, row_groups, job.n, transport=getattr(job.engine, "relay_transport", "relay"),
+                             layout=layout, me=job.rank, widths=widths)
+    bufs = [torch.empty_like(xs) for _ in range(job.nbuf)]
+
+    def check():
+        hops = prop.propagate(xs, K, x_buffers=bufs)
+        return ref.close(hops[K][:, :w], prop.lo, prop.hi, a, b)
+    return {"step": lambda: prop.propagate(xs, K, x_buffers=bufs), "check": check,
+            "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed over all "
+                        f"{job.world} ranks, {args.grid_pieces} row pieces"}
+
+
+def _select_exchange(job, prop, handles, x_chunks, cbufs):
+    """row-sharded layout: pick the transport of the per-hop all-gather.  auto = time one hop's exchange with each
+    process-group transport (decision on the MAX over ranks, so every rank picks the same); the fused push transport is
+    an opt-in third candidate that must map all peers, reproduce the process-group result and be >= 3 % faster."""
+    args, engine, info, K, device = job.args, job.engine, job.info, job.K, job.device
+
+    def setup_push():
+        """collective; returns True iff every rank mapped every peer's replicas"""
+        job.ensure_group()
+        prop.enable_push([xc.shape[1] for xc in x_chunks], handles, device)
+        ok = prop.agree(prop.push_error is None, device)
+        if ok and getattr(prop, "push_skipped_fraction", None) is not None:
+            info["push_peer_rows_skipped"] = round(prop.push_skipped_fraction, 4)
+        if not ok and prop.push_error is not None:
+            sys.stderr.write(f"[bench] push transport unavailable on rank {job.rank}: {prop.push_error!r}\n")
+        return ok
+
+    exchange = args.exchange
+    if exchange == "push" and not setup_push():
+        exchange = "p2p"
+    if exchange != "auto":
+        return exchange
+    transports = getattr(engine, "transports", ("p2p", "allgather"))
+    exchange = transports[0]
+    if job.world == 1 or job.nbuf == 0:
+        return exchange
+    ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
+    cand = {}
+    for tname in transports:
+        prop.transport = tname
+        cand[tname] = job.timed_s(lambda: prop.exchange_only(ys0, [b[0] for b in cbufs]))
+    exchange = min(cand, key=cand.get)
+    info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
+    # opt-in (SGL_BENCH_TRY_PUSH=1): a fault in a peer store would take the whole job down, and at every N the other
+    # layouts beat what a row-sharded exchange can reach over one link per peer
+    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles:
+        return exchange
+    prop.transport = exchange
+    if not setup_push():
+        info["push_rejected"] = "mapping failed"
+        return exchange
+    ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+    got_hops = prop.propagate_push(x_chunks, K)
+    same = True
+    for a_, b_ in zip(ref_hops[K], got_hops[K]):
+        scale_ = float(a_.abs().max()) if a_.numel() else 0.0
+        same = same and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
+    if not prop.agree(same, device):
+        info["push_rejected"] = "result mismatch"
+        return exchange
+    full = {exchange: job.timed_s(lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
+            "push": job.timed_s(lambda: prop.propagate_push(x_chunks, K))}
+    info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
+    return "push" if full["push"] < 0.97 * full[exchange] else exchange
+
+
+def _build_rows(job, ref):
+    """A_hat row-sharded (nnz-balanced) + per-hop all-gather, row pieces x column chunks software-pipelined"""
+    from sgl_amd.dist import ShardedPropagator, all_piece_bounds, column_chunks
+    args, K, x0 = job.args, job.K, job.x0
+    if job.rp_host is None:
+        job.rp_host = job.rowptr.cpu().numpy()
+    pb = all_piece_bounds(job.rp_host, job.world, args.pieces)
+    pieces, handles = job.piece_spmms(pb[job.rank])
+    prop = ShardedPropagator(pieces, pb, job.rank, job.world, job.n)
+    chunks = column_chunks(job.d, args.col_chunks)
+    job.info.update({"row_pieces": args.pieces, "col_chunks": chunks})
+    # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
+    x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
+    cbufs = [[torch.empty_like(xc) for _ in range(job.nbuf)] for xc in x_chunks]
+    exchange = _select_exchange(job, prop, handles, x_chunks, cbufs)
+    if exchange in ("p2p", "allgather", "staged"):
+        prop.transport = exchange
+    job.info["exchange"] = exchange
+    if exchange == "push":
+        def step():
+            return prop.propagate_push(x_chunks, K)
+    elif len(chunks) == 1:
+        def step():
+            return [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0])]
+    else:
+        def step():
+            return prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+
+    def check():
+        return all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(step()[K], chunks))
+    return {"step": step, "check": check, "rows": (prop, x_chunks, cbufs),
+            "describe": f"row-sharded x{job.world} + per-hop all-gather ({exchange}), {args.pieces} row pieces x "
+                        f"{len(chunks)} column chunks"}
+
+
+def _select_layout(job):
+    """Build every candidate layout, validate it against the single-GPU chain, time a full step, keep the fastest.
+    Returns (step, rows_candidate_or_None)."""
+    args, info, world = job.args, job.info, job.world
+    ref = _Reference(job)
+    builders = {"cols": lambda: _build_cols(job, ref), "rows": lambda: _build_rows(job, ref)}
+    if world >= 4 and world % 2 == 0:
+        builders["grid"] = lambda: _build_grid(job, ref, 2)
+    if args.layout == "grid" and "grid" not in builders:
+        raise SystemExit("--layout grid needs an even number of at least 4 ranks")
+    wanted = list(builders) if args.layout == "auto" else [args.layout]
+    cands, timing, rejected = {}, {}, []
+    for name in wanted:
+        # a candidate that raises is dropped on EVERY rank (the code path is the same on all of them, so an error is
+        # too; agree() keeps the control flow identical even if it is not)
+        c, good = None, True
+        try:
+            c = builders[name]()
+            c["step"]()                                   # warm: plans, communicators, staging buffers
+            job.sync_all()
+            good = bool(c["check"]())
+        except Exception as e:  # noqa: BLE001
+            good = False
+            sys.stderr.write(f"[bench] layout {name!r} failed on rank {job.rank}: {e!r}\n")
+        if not job.agree(good):
+            rejected.append(name)
+            continue
+        timing[name] = job.timed_s(c["step"], reps=2, warm=0)
+        cands[name] = c
+    if not cands:
+        raise SystemExit(f"no multi-GPU layout reproduced the single-GPU result (tried {wanted})")
+    chosen = min(timing, key=timing.get)
+    info["layout"] = chosen
+    info["layout_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in timing.items()}
+    if rejected:
+        info["layout_rejected"] = rejected
+    info["parallelism"] = cands[chosen]["describe"]
+    rows = cands["rows"].get("rows") if "rows" in cands else None
+    return cands[chosen]["step"], rows
+
+
+def _rows_diagnostics(job, rows):
+    """after the timed region, never part of `value`: the two halves of a row-sharded hop in isolation"""
+    prop, x_chunks, cbufs = rows
+    ys = prop.spmm_only(x_chunks)
+    spmm_ms = job.timed_s(lambda: prop.spmm_only(x_chunks), reps=3) * 1e3
+    xnext = [b[0] for b in cbufs]
+    exch_ms = job.timed_s(lambda: prop.exchange_only(ys, xnext), reps=3) * 1e3 if job.world > 1 else 0.0
+    inbound = (job.world - 1) / job.world * job.n * job.d * 4
+    return {"spmm_only_ms_per_hop_max_rank": spmm_ms, "exchange_only_ms_per_hop_max_rank": exch_ms,
+            "inbound_bytes_per_rank_per_hop": inbound,
+            "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
+
+
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     import torch.distributed as dist
-    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_chunks, column_slices
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,302 +536,49 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         quiet.mute()
     engine = engine_cls(local_rank)
     device = engine.device
-    own_group = False
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(engine.backend, rank=rank, world_size=world, **engine.init_kwargs())
-        own_group = True
-
     if workloads is None:
         from sgl_amd import synthetic
         workloads = synthetic.WORKLOADS
     wl = workloads[args.workload]
-    n, d, K = wl["n"], wl["d"], wl["k"]
+    job = _Job(args, engine, rank, world, wl)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(engine.backend, rank=rank, world_size=world, **engine.init_kwargs())
+        job.own_group = True
+    n, d, K = job.n, job.d, job.K
 
-    # ---- build the workload (untimed): rank 0 generates + normalises, everybody receives a replica --------
     t_setup = time.perf_counter()
-    if rank == 0:
-        rowptr, col, val, x0 = engine.build_workload(args, wl)
-        meta = torch.tensor([col.numel()], dtype=torch.int64, device=device)
-    else:
-        meta = torch.zeros(1, dtype=torch.int64, device=device)
-    if world > 1:
-        dist.broadcast(meta, 0)
-        nnz = int(meta.item())
-        if rank != 0:
-            rowptr = torch.empty(n + 1, dtype=torch.int64, device=device)
-            col = torch.empty(nnz, dtype=torch.int32, device=device)
-            val = torch.empty(nnz, dtype=torch.float32, device=device)
-            x0 = torch.empty((n, d), dtype=torch.float32, device=device)
-        for t in (rowptr, col, val, x0):
-            dist.broadcast(t, 0)
-    nnz = int(col.numel())
-    engine.sync()
-
+    job.load_workload(wl)
+    nnz = job.nnz
     sharded = world > 1 or args.force_sharded
-    prop = None
-    nbuf = min(2, max(K - 1, 0))
-
-    def sync_all():
-        engine.sync()
-        if world > 1:
-            dist.barrier()
-            engine.sync()
-
-    def agree(ok):
-        """True iff `ok` holds on every rank: keeps the ranks' control flow identical"""
-        if world == 1:
-            return bool(ok)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item())
-
-    def max_over_ranks(v):
-        if world == 1:
-            return float(v)
-        tt = torch.tensor([v], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-
+    rows = None
     if not sharded:
-        step, info = engine.single_step(args, rowptr, col, val, x0, n, d, K)
+        step, job.info = engine.single_step(args, job.rowptr, job.col, job.val, job.x0, n, d, K)
     else:
-        # Layout candidates for N ranks (sgl_amd/dist.py): "rows" = A_hat row-sharded + per-hop all-gather, "cols" =
-        # feature-sharded (every rank runs the whole chain on d/N columns, no communication), "grid" = 2 row blocks x
-        # N/2 column slices with the pair exchange relayed over all xGMI links.  auto: build each, validate its result
-        # against the single-GPU chain computed on this rank's own replica, time a full step, keep the fastest.
-        rp_host = rowptr.cpu().numpy()
-        info = {}
-        pack = getattr(engine, "pack_slice", lambda x, a, b: x[:, a:b].contiguous())
-        full_spmm = engine.piece_spmms(args, rowptr, col, val, n, np.array([0, n], dtype=np.int64), rp_host)[0][0]
-        ref_last = x0
-        for _ in range(K):
-            nxt = torch.empty_like(x0)
-            full_spmm(ref_last, nxt)
-            ref_last = nxt
-        ref_scale = max(float(ref_last.abs().max()), 1e-30)
-
-        def close(block, r0, r1, c0, c1):
-            want = ref_last[r0:r1, c0:c1]
-            return want.numel() == 0 or float((block - want).abs().max()) <= 1e-5 * ref_scale
-
-        def build_cols():
-            a, b = column_slices(d, world)[rank]
-            w = b - a
-            xs = pack(x0, a, b)
-            outs = [torch.empty_like(xs) for _ in range(K)]
-
-            def step_cols():
-                cur = xs
-                for h in range(K if w else 0):
-                    full_spmm(cur, outs[h])
-                    cur = outs[h]
-            return {"step": step_cols, "check": lambda: K == 0 or close(outs[K - 1][:, :w], 0, n, a, b),
-                    "describe": f"feature-sharded x{world} (each GPU: all rows x {w} of {d} columns, no communication)"}
-
-        def build_grid(row_groups):
-            layout = GridLayout(world, row_groups)
-            rg, cg = layout.coords(rank)
-            slices = column_slices(d, layout.col_groups)
-            pbg = all_piece_bounds(rp_host, row_groups, args.grid_pieces)
-            fns, _h = engine.piece_spmms(args, rowptr, col, val, n, pbg[rg], rp_host)
-            a, b = slices[cg]
-            w = b - a
-            xs = pack(x0, a, b)
-            widths = [pack(x0[:1], sa, sb).shape[1] for sa, sb in slices]
-            gprop = ShardedPropagator(fns, pbg, rg, row_groups, n, transport=getattr(engine, "relay_transport", "relay"),
-                                      layout=layout, me=rank, widths=widths)
-            bufs = [torch.empty_like(xs) for _ in range(nbuf)]
-
-            def check_grid():
-                hops = gprop.propagate(xs, K, x_buffers=bufs)
-                return close(hops[K][:, :w], gprop.lo, gprop.hi, a, b)
-            return {"step": lambda: gprop.propagate(xs, K, x_buffers=bufs), "check": check_grid,
-                    "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed "
-                                f"over all {world} ranks, {args.grid_pieces} row pieces"}
-
-        def build_rows():
-            nonlocal prop, own_group
-            pb = all_piece_bounds(rp_host, world, args.pieces)
-            pieces, _handles = engine.piece_spmms(args, rowptr, col, val, n, pb[rank], rp_host)
-            prop = ShardedPropagator(pieces, pb, rank, world, n)
-            exchange = args.exchange
-            chunks = column_chunks(d, args.col_chunks)
-            info.update({"row_pieces": args.pieces, "col_chunks": chunks})
-            # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
-            x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
-            cbufs = [[torch.empty_like(xc) for _ in range(nbuf)] for xc in x_chunks]
-
-            def setup_push():
-                """collective; returns True iff every rank mapped every peer's replicas"""
-                nonlocal own_group
-                if not dist.is_initialized():   # --force-sharded on one GPU
-                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                    os.environ.setdefault("MASTER_PORT", "29517")
-                    dist.init_process_group(engine.backend, rank=0, world_size=1, **engine.init_kwargs())
-                    own_group = True
-                prop.enable_push([xc.shape[1] for xc in x_chunks], _handles, device)
-                ok = prop.agree(prop.push_error is None, device)
-                if ok and getattr(prop, "push_skipped_fraction", None) is not None:
-                    info["push_peer_rows_skipped"] = round(prop.push_skipped_fraction, 4)
-                if not ok and prop.push_error is not None:
-                    sys.stderr.write(f"[bench] push transport unavailable on rank {rank}: {prop.push_error!r}\n")
-                return ok
-
-            if exchange == "push" and not setup_push():
-                exchange = "p2p"
-            if exchange == "auto":
-                # time one hop's exchange with each RCCL transport (untimed setup) and keep the faster one; the decision
-                # is taken on the MAX over ranks so every rank picks the same
-                exchange = getattr(engine, "transports", ("p2p",))[0]
-                if world > 1 and nbuf > 0:
-                    ys0 = [torch.zeros((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=device) for xc in x_chunks]
-                    cand = {}
-                    for tname in getattr(engine, "transports", ("p2p", "allgather")):
-                        prop.transport = tname
-                        for rep in range(3):
-                            if rep == 1:
-                                sync_all()
-                                t_a = time.perf_counter()
-                            prop.exchange_only(ys0, [b[0] for b in cbufs])
-                        sync_all()
-                        cand[tname] = max_over_ranks((time.perf_counter() - t_a) / 2)
-                    exchange = min(cand, key=cand.get)
-                    info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
-                    # third candidate: the fused push transport -- only if every rank could map its peers, its result
-                    # matches the RCCL transport's, and a full propagation is measurably faster
-                    # (opt-in, SGL_BENCH_TRY_PUSH=1: a fault in a peer store would take the whole job down, and at
-                    # every N the layouts below beat what a row-sharded exchange can reach over one link per peer)
-                    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") == "1" and hasattr(prop, "enable_push") and _handles:
-                        prop.transport = exchange
-                        if setup_push():
-                            ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
-                            got_hops = prop.propagate_push(x_chunks, K)
-                            same = True
-                            for a_, b_ in zip(ref_hops[K], got_hops[K]):
-                                scale_ = float(a_.abs().max()) if a_.numel() else 0.0
-                                same = same and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
-                            if prop.agree(same, device):
-                                full = {}
-                                for tname, fn in ((exchange, lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
-                                                  ("push", lambda: prop.propagate_push(x_chunks, K))):
-                                    fn()
-                                    sync_all()
-                                    t_a = time.perf_counter()
-                                    fn(); fn()
-                                    sync_all()
-                                    full[tname] = max_over_ranks((time.perf_counter() - t_a) / 2)
-                                info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
-                                if full["push"] < 0.97 * full[exchange]:
-                                    exchange = "push"
-                            else:
-                                info["push_rejected"] = "result mismatch"
-                        else:
-                            info["push_rejected"] = "mapping failed"
-            if exchange in ("p2p", "allgather", "staged"):
-                prop.transport = exchange
-            info["exchange"] = exchange
-            if exchange == "push":
-                run_rows = lambda: prop.propagate_push(x_chunks, K)          # noqa: E731
-            elif len(chunks) == 1:
-                run_rows = lambda: [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0])]   # noqa: E731
-            else:
-                run_rows = lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)  # noqa: E731
-
-            def check_rows():
-                last = run_rows()[K]
-                return all(close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(last, chunks))
-            rows_diag.update(x_chunks=x_chunks, cbufs=cbufs)
-            return {"step": run_rows, "check": check_rows,
-                    "describe": f"row-sharded x{world} + per-hop all-gather ({exchange}), {args.pieces} row pieces x "
-                                f"{len(chunks)} column chunks"}
-
-        rows_diag = {}
-        builders = {"cols": build_cols, "rows": build_rows}
-        if world >= 4 and world % 2 == 0:
-            builders["grid"] = lambda: build_grid(2)
-        wanted = list(builders) if args.layout == "auto" else [args.layout]
-        if args.layout == "grid" and "grid" not in builders:
-            raise SystemExit("--layout grid needs an even number of at least 4 ranks")
-        cands, timing, rejected = {}, {}, []
-        for name in wanted:
-            # a candidate that raises is dropped on EVERY rank (the code path is the same on all of them, so an error
-            # is too; agree() keeps the control flow identical even if it is not)
-            c, good = None, True
-            try:
-                c = builders[name]()
-                c["step"]()                               # warm: plans, communicators, staging buffers
-                sync_all()
-                good = bool(c["check"]())
-            except Exception as e:  # noqa: BLE001
-                good = False
-                sys.stderr.write(f"[bench] layout {name!r} failed on rank {rank}: {e!r}\n")
-            if not agree(good):
-                rejected.append(name)
-                continue
-            sync_all()
-            t_a = time.perf_counter()
-            c["step"](); c["step"]()
-            sync_all()
-            timing[name] = max_over_ranks((time.perf_counter() - t_a) / 2)
-            cands[name] = c
-        if not cands:
-            raise SystemExit(f"no multi-GPU layout reproduced the single-GPU result (tried {wanted})")
-        chosen = min(timing, key=timing.get)
-        info["layout"] = chosen
-        info["layout_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in timing.items()}
-        if rejected:
-            info["layout_rejected"] = rejected
-        info["parallelism"] = cands[chosen]["describe"]
-        step = cands[chosen]["step"]
+        step, rows = _select_layout(job)
+    info = job.info
     setup_s = time.perf_counter() - t_setup
 
+    # ---- the timed region: W warm-up steps, then exactly K steps between barrier + device synchronise ------------
     for _ in range(args.warmup):
         step()
-    sync_all()
+    job.sync_all()
     t_start, t_stop, t_elapsed_ms = engine.timer()
     t0 = time.perf_counter()
     t_start()
     for _ in range(args.steps):
         step()
     t_stop()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    job.sync_all()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
-    # ---- diagnostics (after the timed region, never part of `value`): the two halves of a sharded hop in isolation
-    diag = None
-    if sharded and nbuf > 0 and rows_diag:
-        x_chunks, cbufs = rows_diag["x_chunks"], rows_diag["cbufs"]
-
-        def timed_ms(fn, reps=3):
-            fn()
-            sync_all()
-            t_a = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            sync_all()
-            return (time.perf_counter() - t_a) * 1e3 / reps
-        ys = prop.spmm_only(x_chunks)
-        spmm_ms = timed_ms(lambda: prop.spmm_only(x_chunks))
-        xnext = [b[0] for b in cbufs]
-        exch_ms = timed_ms(lambda: prop.exchange_only(ys, xnext)) if world > 1 else 0.0   # the selected RCCL transport
-        vals = torch.tensor([spmm_ms, exch_ms], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-        inbound = (world - 1) / world * n * d * 4
-        diag = {"spmm_only_ms_per_hop_max_rank": float(vals[0]), "exchange_only_ms_per_hop_max_rank": float(vals[1]),
-                "inbound_bytes_per_rank_per_hop": inbound,
-                "exchange_inbound_GBps_per_rank": (inbound / (float(vals[1]) * 1e-3) / 1e9) if float(vals[1]) > 0 else None}
+    diag = _rows_diagnostics(job, rows) if rows is not None and job.nbuf > 0 else None
 
     cpu = None
     if not sharded and not args.no_cpu_baseline and rank == 0:
         try:
-            cpu = cpu_baseline(rowptr, col, val, x0, d)
+            cpu = cpu_baseline(job.rowptr, job.col, job.val, job.x0, d)
         except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
             cpu = {"value": None, "unit": "edge*featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
@@ -578,7 +623,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             quiet.mute()                      # late library chatter (communicator teardown) goes to stderr too
     if world > 1:
         dist.barrier()
-    if own_group and dist.is_initialized():
+    if job.own_group and dist.is_initialized():
         dist.destroy_process_group()
     return out
 
