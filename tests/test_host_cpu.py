@@ -244,3 +244,17 @@ def test_balanced_bounds_properties():
     # degenerate: more parts than rows
     b = balanced_bounds(np.array([0, 2, 4], dtype=np.int64), 8)
     assert b[0] == 0 and b[-1] == 2 and (np.diff(b) >= 0).all()
+
+
+def test_row_pitch_is_line_aware():
+    """leading dimensions: always 16-byte aligned rows, never fewer floats than the row, and rounded up to whole
+    lines / a power of two exactly when that makes a gathered row touch fewer 128-byte lines"""
+    from sgl_amd.device import expected_lines, row_pitch
+    for d in range(1, 700):
+        for growth in (1.25, 2.0):
+            ld = row_pitch(d, growth)
+            assert ld >= d and ld % 4 == 0 and ld <= max(4, growth * (d + 3) // 4 * 4 + 4, 1.34 * ((d + 3) // 4 * 4))
+            assert expected_lines(ld, d) <= expected_lines((d + 3) // 4 * 4, d)
+    assert [row_pitch(d) for d in (100, 128, 147, 500, 12, 13, 16, 50)] == [100, 128, 160, 512, 16, 16, 16, 64]
+    assert row_pitch(25) == 32 and row_pitch(20) == 20 and row_pitch(20, growth=2.0) == 32
+    assert expected_lines(100, 100) == 4 and expected_lines(128, 100) == 4 and expected_lines(160, 147) == 5
