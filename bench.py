@@ -351,14 +351,15 @@ def _build_cols(job, ref):
 
 def _build_grid(job, ref, row_groups):
     """row_groups row blocks x N/row_groups column slices, the exchange inside a column group relayed over all ranks"""
-    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices
+    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices, tapered_weights
     args, K = job.args, job.K
     layout = GridLayout(job.world, row_groups)
     rg, cg = layout.coords(job.rank)
     slices = column_slices(job.d, layout.col_groups)
     if job.rp_host is None:
         job.rp_host = job.rowptr.cpu().numpy()
-    pb = all_piece_bounds(job.rp_host, row_groups, args.grid_pieces)
+    # the last piece's transfer is the one nothing can hide: make it half as large as the others
+    pb = all_piece_bounds(job.rp_host, row_groups, args.grid_pieces, tapered_weights(args.grid_pieces))
     fns, _handles = job.piece_spmms(pb[rg])
     a, b = slices[cg]
     w = b - a

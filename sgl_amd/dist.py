@@ -24,37 +24,53 @@ A_hat with ITS column slice only and exchanges rows only inside its column group
 xGMI is a point-to-point mesh, so an exchange inside a small column group would use only Gr-1 of a GPU's 7 links.  The
 "relay" transport spreads it over all of them: each row piece is cut into G stripes; phase 1 sends stripe q to rank q,
 phase 2 has q forward it to the ranks that need it (two link crossings per byte, but 7 links in parallel)."""
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "device_piece_spmms", "column_chunks",
+__all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "tapered_weights", "device_piece_spmms", "column_chunks",
            "column_slices", "GridLayout", "ShardedPropagator", "ShardedGraphOp"]
 
 
-def balanced_bounds(rowptr, parts):
+def balanced_bounds(rowptr, parts, weights=None):
     """Cut rows [0, n) into `parts` contiguous blocks holding ~equal numbers of non-zeros (+1 per row so
-    empty rows still count).  rowptr: host int64 array [n+1].  Returns int64 array [parts+1]."""
+    empty rows still count), or shares proportional to `weights`.  rowptr: host int64 array [n+1].
+    Returns int64 array [parts+1]."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     n = len(rowptr) - 1
     cost = rowptr + np.arange(n + 1, dtype=np.int64)
-    targets = cost[-1] * np.arange(1, parts, dtype=np.float64) / parts
-    cuts = np.searchsorted(cost, targets, side="left").astype(np.int64)
+    if weights is None:
+        share = np.arange(1, parts, dtype=np.float64) / parts
+    else:
+        w = np.asarray(weights, dtype=np.float64)
+        if len(w) != parts or (w <= 0).any():
+            raise ValueError("one positive weight per part")
+        share = np.cumsum(w)[:-1] / w.sum()
+    cuts = np.searchsorted(cost, cost[-1] * share, side="left").astype(np.int64)
     b = np.concatenate([[0], np.clip(cuts, 0, n), [n]]).astype(np.int64)
     return np.maximum.accumulate(b)
 
 
-def piece_bounds(rowptr, lo, hi, pieces):
+def tapered_weights(pieces):
+    """piece sizes for a hop whose LAST piece's transfer cannot hide behind compute: equal pieces, the last one half
+    as large (4 pieces -> 2:2:2:1, the exposed transfer is 1/7 instead of 1/4 of the hop's traffic)"""
+    return [2.0] * (pieces - 1) + [1.0] if pieces > 1 else [1.0]
+
+
+def piece_bounds(rowptr, lo, hi, pieces, weights=None):
     """split the row block [lo, hi) into `pieces` nnz-balanced sub-blocks -> absolute row boundaries [pieces+1]"""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     local = rowptr[lo:hi + 1] - rowptr[lo]
-    return balanced_bounds(local, pieces) + lo
+    return balanced_bounds(local, pieces, weights) + lo
 
 
-def all_piece_bounds(rowptr_host, world, pieces):
-    """[world, pieces+1] absolute row boundaries: rank blocks balanced by non-zeros, each cut into `pieces`"""
+def all_piece_bounds(rowptr_host, world, pieces, weights=None):
+    """[world, pieces+1] absolute row boundaries: rank blocks balanced by non-zeros, each cut into `pieces`
+    (equal, or in the proportions `weights`)"""
     bounds = balanced_bounds(rowptr_host, world)
-    return np.stack([piece_bounds(rowptr_host, int(bounds[g]), int(bounds[g + 1]), pieces) for g in range(world)])
+    return np.stack([piece_bounds(rowptr_host, int(bounds[g]), int(bounds[g + 1]), pieces, weights) for g in range(world)])
 
 
 def device_piece_spmms(rowptr, col, val, n_cols, my_bounds, rowptr_host=None, strict=False):
@@ -202,6 +218,8 @@ class ShardedPropagator:
         global rank == row block index.  `group` is the process group the transports run on (the whole job's; the
         "allgather" transport needs it to contain exactly the column group)."""
         self.transport = transport            # "p2p" | "allgather" | "staged" | "relay" | "relay_staged"
+        self.piece_streams = True             # propagate(): alternate the row pieces between two streams (GPU only)
+        self.relay_collective = None          # relay phases as one all_to_all each: None = when the backend is RCCL
         self._ag_buf = {}
         self._relay_bufs = {}
         self.spmm_pieces = spmm_pieces
@@ -288,6 +306,11 @@ class ShardedPropagator:
         W = self.layout.world
         return r0 + (r1 - r0) * q // W, r0 + (r1 - r0) * (q + 1) // W
 
+    def _aux_stream(self, device):
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream(device=device)
+        return self._aux
+
     def _side_stream(self, device):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=device)
@@ -304,6 +327,8 @@ class ShardedPropagator:
     def _relay_phase1(self, p, y_piece, x_next):
         """scatter: stripe q of my piece goes to rank q; I collect stripe `me` of EVERY rank's piece -- straight into
         my replica when it comes from my own column group, into a relay buffer otherwise"""
+        if self._relay_collective():
+            return self._relay_phase1_a2a(p, y_piece, x_next)
         L, me = self.layout, self.me
         my_cg = L.coords(me)[1]
         base = int(self.pb[self.rank, p])
@@ -322,6 +347,8 @@ class ShardedPropagator:
 
     def _relay_phase2(self, p, y_piece, x_next):
         """forward: every rank `dst` gets, from me, stripe `me` of the pieces of the other ranks of ITS column group"""
+        if self._relay_collective():
+            return self._relay_phase2_a2a(p, y_piece, x_next)
         L, me = self.layout, self.me
         my_cg = L.coords(me)[1]
         base = int(self.pb[self.rank, p])
@@ -350,6 +377,65 @@ class ShardedPropagator:
                     recvs.append((x_next[a:b], src))
         return self._xfer(sends, recvs, self.transport == "relay_staged")
 
+    # With 2 row blocks every rank exchanges exactly ONE tensor with every other rank in each phase, so a phase is a
+    # single all_to_all (one c10d call instead of a batch of 14 point-to-point ops: the host-side issue cost is what
+    # bounds the number of row pieces a hop can be cut into).  Process groups without all_to_all (gloo) keep the batches.
+    def _relay_collective(self):
+        if getattr(self, "relay_collective", None) is not None:
+            return bool(self.relay_collective)
+        return self.transport == "relay" and self.layout.row_groups == 2 and dist.get_backend(self.group) == "nccl"
+
+    def _dummy(self, like, key):
+        buf = self._relay_bufs.get(key)
+        if buf is None or buf.device != like.device:
+            buf = torch.zeros(1, dtype=like.dtype, device=like.device)
+            self._relay_bufs[key] = buf
+        return buf
+
+    def _relay_phase1_a2a(self, p, y_piece, x_next):
+        L, me = self.layout, self.me
+        my_cg = L.coords(me)[1]
+        base = int(self.pb[self.rank, p])
+        ins, outs = [], []
+        for g in range(L.world):
+            if g == me:                                   # my own stripe stays where it is
+                ins.append(self._dummy(x_next, "in"))
+                outs.append(self._dummy(x_next, "out"))
+                continue
+            a, b = self._stripe(self.rank, p, g)
+            ins.append(y_piece[a - base:b - base] if b > a else self._dummy(x_next, "in"))
+            rg_g, cg_g = L.coords(g)
+            a, b = self._stripe(rg_g, p, me)
+            if b <= a:
+                outs.append(self._dummy(x_next, ("out", g)))
+            else:
+                outs.append(x_next[a:b] if cg_g == my_cg else self._relay_buf(p, g, b - a, self.widths[cg_g], x_next))
+        return _Works([dist.all_to_all(outs, ins, group=self.group, async_op=True)])
+
+    def _relay_phase2_a2a(self, p, y_piece, x_next):
+        L, me = self.layout, self.me
+        partner = [q for q in self.members if q != me][0]
+        base = int(self.pb[self.rank, p])
+        ins, outs = [], []
+        for q in range(L.world):
+            if q == me:
+                ins.append(self._dummy(x_next, "in"))
+                outs.append(self._dummy(x_next, "out"))
+                continue
+            # to q: stripe `me` of the piece of q's partner (my own kept stripe if that partner is me)
+            g = [m for m in L.members(L.coords(q)[1]) if m != q][0]
+            a, b = self._stripe(L.coords(g)[0], p, me)
+            if b <= a:
+                ins.append(self._dummy(x_next, "in"))
+            elif g == me:
+                ins.append(y_piece[a - base:b - base])
+            else:
+                ins.append(self._relay_buf(p, g, b - a, self.widths[L.coords(q)[1]], x_next))
+            # from q: stripe q of my partner's piece
+            a, b = self._stripe(L.coords(partner)[0], p, q)
+            outs.append(x_next[a:b] if b > a else self._dummy(x_next, ("out", q)))
+        return _Works([dist.all_to_all(outs, ins, group=self.group, async_op=True)])
+
     def _exchange_piece(self, p, y_piece, x_next):
         """start moving my piece p to the ranks of my column group (and theirs to me).  Returns an object with
         advance() (cheap; call it after more compute has been queued) and wait()."""
@@ -376,22 +462,36 @@ class ShardedPropagator:
         if x_buffers is None:
             x_buffers = [torch.empty_like(x_full) for _ in range(min(2, max(prop_steps - 1, 0)))]
         cur = x_full
+        # Consecutive row pieces alternate between the caller's stream and an auxiliary one: the tail of one piece's
+        # launch (CUs draining) overlaps the head of the next, so cutting a hop into pieces costs no compute time
+        # (measured: 8 pieces 1.50 -> 1.23 ms = the single-launch time, profiles/r01_layout_shares.log).  Each piece's
+        # exchange is issued from the stream its SpMM ran on.
+        two = x_full.is_cuda and self.pieces > 1 and self.piece_streams
+        if two:
+            main = torch.cuda.current_stream(x_full.device)
+            aux = self._aux_stream(x_full.device)
         for h in range(1, prop_steps + 1):
             last = h == prop_steps
             y_local = torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
             x_next = None if last else x_buffers[(h - 1) % len(x_buffers)]
             if x_next is not None and x_next.data_ptr() == cur.data_ptr():
                 raise RuntimeError("need two distinct full-size buffers to ping-pong between hops")
+            if two:
+                y_local.record_stream(aux)
+                aux.wait_stream(main)             # the previous hop (and its exchange) is complete for both streams
             works = []
             for p in range(self.pieces):
                 r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
                 y_piece = y_local[r0:r1]
-                if r1 > r0:
-                    self.spmm_pieces[p](cur, y_piece)
-                for w in works:                   # two-phase transports: earlier pieces move on while this one computed
-                    w.advance()
-                if not last and self._exchanging():
-                    works.append(self._exchange_piece(p, y_piece, x_next))
+                with torch.cuda.stream(aux if p % 2 else main) if two else contextlib.nullcontext():
+                    if r1 > r0:
+                        self.spmm_pieces[p](cur, y_piece)
+                    for w in works:               # two-phase transports: earlier pieces move on while this one computed
+                        w.advance()
+                    if not last and self._exchanging():
+                        works.append(self._exchange_piece(p, y_piece, x_next))
+            if two:
+                main.wait_stream(aux)
             if not last:
                 x_next[self.lo:self.hi].copy_(y_local)
                 for w in works:

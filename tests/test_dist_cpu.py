@@ -119,7 +119,27 @@ def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir
 
         fns = [make_piece(int(pb[rg, p]), int(pb[rg, p + 1])) for p in range(pieces)]
         widths = [b - a for a, b in slices]
+        collective = transport == "relay_all_to_all"
+        if collective:
+            # the RCCL fast path posts each relay phase as ONE all_to_all; gloo has no all_to_all, so emulate its
+            # contract (tensor q of `ins` arrives as tensor `rank` of rank q's `outs`, sizes must match exactly)
+            def all_to_all(outs, ins, group=None, async_op=False):
+                outs[rank].copy_(ins[rank])
+                ops = []
+                for k in range(1, world):
+                    dst, src = (rank + k) % world, (rank - k) % world
+                    ops += [dist.P2POp(dist.isend, ins[dst], dst), dist.P2POp(dist.irecv, outs[src], src)]
+                works = dist.batch_isend_irecv(ops)
+
+                class Work:
+                    def wait(self):
+                        for w in works:
+                            w.wait()
+                return Work()
+            dist.all_to_all = all_to_all
+            transport = "relay"
         prop = ShardedPropagator(fns, pb, rg, row_groups, n, transport=transport, layout=layout, me=rank, widths=widths)
+        prop.relay_collective = collective
         x = torch.from_numpy(hash_matrix(n, d, seed=5))
         a, b = slices[cg]
         ref = oracle.propagate((ptr, col, val), x.numpy(), K)
@@ -136,7 +156,8 @@ def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir
 
 @pytest.mark.parametrize("world,row_groups,pieces,K,transport", [
     (4, 2, 2, 3, "relay"), (4, 2, 2, 3, "p2p"), (6, 3, 2, 3, "relay"), (8, 2, 3, 2, "relay"), (4, 4, 1, 2, "relay"),
-    (3, 1, 2, 2, "p2p"), (6, 2, 1, 2, "relay"), (4, 2, 2, 2, "staged"), (4, 2, 2, 2, "relay_staged")])
+    (3, 1, 2, 2, "p2p"), (6, 2, 1, 2, "relay"), (4, 2, 2, 2, "staged"), (4, 2, 2, 2, "relay_staged"),
+    (4, 2, 2, 3, "relay_all_to_all"), (8, 2, 3, 2, "relay_all_to_all")])
 def test_grid_layouts_match_single_process(tmp_path, world, row_groups, pieces, K, transport):
     port = _free_port()
     mp.spawn(_grid_worker, args=(world, port, row_groups, pieces, K, 11, transport, str(tmp_path)), nprocs=world, join=True)

@@ -242,6 +242,14 @@ def test_balanced_bounds_properties():
     pb = piece_bounds(rowptr, 1000, 3000, 4)
     assert pb[0] == 1000 and pb[-1] == 3000 and (np.diff(pb) >= 0).all()
     # degenerate: more parts than rows
+    from sgl_amd.dist import all_piece_bounds, tapered_weights
+    rp = np.arange(0, 70001, 7, dtype=np.int64)                      # 10 000 rows of 7 non-zeros
+    pbw = all_piece_bounds(rp, 2, 4, tapered_weights(4))
+    assert pbw.shape == (2, 5) and pbw[0, 0] == 0 and pbw[1, -1] == 10000 and pbw[0, -1] == pbw[1, 0]
+    sizes = np.diff(pbw[0])
+    assert abs(sizes[3] / sizes[0] - 0.5) < 0.01 and abs(sizes[1] / sizes[0] - 1) < 0.01
+    with pytest.raises(ValueError):
+        balanced_bounds(rp, 3, [1, 2])
     b = balanced_bounds(np.array([0, 2, 4], dtype=np.int64), 8)
     assert b[0] == 0 and b[-1] == 2 and (np.diff(b) >= 0).all()
 

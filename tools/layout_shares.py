@@ -62,7 +62,8 @@ def main():
         t = timed(lambda: full.spmm(xs, out=ys))
         print(f"EXP share layout=cols world={world} width={b - a} pitch={xs.shape[1]} ms_per_hop={t:.3f} "
               f"speedup_bound={base / t:.2f}", flush=True)
-        for name, row_groups, pieces in (("rows", world, 2), ("grid2", 2, 4)):
+        extra = [("grid2", 2, int(p)) for p in os.environ.get("SGL_GRID_PIECES", "").split(",") if p]
+        for name, row_groups, pieces in [("rows", world, 2), ("grid2", 2, 4)] + extra:
             if name == "grid2" and world < 4:
                 continue
             col_groups = world // row_groups
@@ -79,6 +80,17 @@ def main():
                     for p in range(pieces):
                         fns[p](xs, outs[p])
                 worst = max(worst, timed(hop))
+                if os.environ.get("SGL_TWO_STREAMS") and rg == 0:
+                    main, aux = torch.cuda.current_stream(), torch.cuda.Stream()
+
+                    def hop2():
+                        aux.wait_stream(main)
+                        for p in range(pieces):
+                            with torch.cuda.stream(aux if p % 2 else main):
+                                fns[p](xs, outs[p])
+                        main.wait_stream(aux)
+                    print(f"EXP share layout={name} world={world} pieces={pieces} two_streams ms_per_hop={timed(hop2):.3f} "
+                          f"one_stream={timed(hop):.3f}", flush=True)
                 del fns, handles, outs
             inbound = (row_groups - 1) / row_groups * n * xs.shape[1] * 4
             print(f"EXP share layout={name} world={world} grid={row_groups}x{col_groups} pieces={pieces} "
