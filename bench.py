@@ -519,7 +519,8 @@ def _rows_diagnostics(job, rows):
     inbound = (job.world - 1) / job.world * job.n * job.d * 4
     return {"spmm_only_ms_per_hop_max_rank": spmm_ms, "exchange_only_ms_per_hop_max_rank": exch_ms,
             "inbound_bytes_per_rank_per_hop": inbound,
-            "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
+            "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None,
+            "exchange_GBps_per_link": (inbound / (job.world - 1) / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
 
 
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
