@@ -831,3 +831,30 @@ class ShardedGraphOp:
     def gather_rows(self, local):
         """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (row-sharded layout)"""
         return self.gather_full(local)
+
+    def over_smooth_aggregate(self, hops):
+        """OverSmoothDistanceWeightedOp (NAFS, message_op/over_smooth_distance_op.py:6-33) on this rank's blocks, for any
+        layout.  The weights need whole rows (cosine of X_0[n] and X_h[n]); a rank that owns only a column slice
+        contributes the partial sums of its columns -- X_0.X_h and |X_h|^2 per row and hop, one all-reduce of
+        [N, 2H] floats for the whole job -- and then combines its own columns with the shared weights.  Row-sharded
+        ranks own whole rows and use the fused single-pass kernel directly."""
+        from . import device as dev
+        prop = self._prop
+        feats = [h.contiguous() for h in hops]
+        if prop.layout is None or prop.layout.col_groups == 1:
+            return dev.nafs_aggregate(feats)
+        H = len(feats)
+        part = torch.zeros((prop.n, 2 * H), dtype=torch.float32, device=feats[0].device)
+        blk = part[prop.lo:prop.hi]
+        for h, xh in enumerate(feats):
+            blk[:, h] = (feats[0] * xh).sum(dim=1)
+            blk[:, H + h] = (xh * xh).sum(dim=1)
+        if self._gloo() and part.is_cuda:
+            host = part.cpu()
+            dist.all_reduce(host, group=self.group)
+            part.copy_(host)
+        else:
+            dist.all_reduce(part, group=self.group)
+        norms = blk[:, H:].sqrt() + 1e-10                    # the reference adds 1e-10 to each norm (:14, :16)
+        w = torch.softmax(blk[:, :H] / norms / norms[:, :1], dim=1).contiguous()
+        return dev.hop_wsum2d(feats, w)

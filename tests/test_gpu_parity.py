@@ -830,6 +830,10 @@ def _two_rank_worker(rank, world, port, out_dir):
         mean = MeanMessageOp(0, 4).aggregate([h.contiguous() for h in hc])
         fullc = opc.gather_full(mean)
         ok = ok and orc.parity_ok(fullc.cpu().numpy(), orc.agg_mean(ref, 0, 4), 1e-6, rowwise=False)
+        # NAFS on column slices: partial dot products all-reduced, weights shared, columns combined locally
+        nafs_c = opc.gather_full(opc.over_smooth_aggregate(hc))
+        ok = ok and orc.parity_ok(nafs_c.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        ok = ok and torch.equal(op.over_smooth_aggregate(hops), nafs)      # row-sharded: the fused kernel itself
         open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
@@ -874,6 +878,8 @@ def _grid_rank_worker(rank, world, port, out_dir):
                 ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
             full = op.gather_full(hops[3])
             ok = ok and np.array_equal(full.cpu().numpy(), ref[3])
+            nafs_g = op.gather_full(op.over_smooth_aggregate(hops))
+            ok = ok and orc.parity_ok(nafs_g.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
         # the RCCL variant issues both relay phases from a side stream; RCCL refuses several ranks on one device, so
         # run that code path with the transfers themselves staged through the host
         from sgl_amd.dist import ShardedPropagator
