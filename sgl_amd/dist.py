@@ -241,6 +241,8 @@ class ShardedPropagator:
     def _xfer(self, sends, recvs, staged=False):
         """post sends [(tensor, global peer)] and receives [(tensor view, global peer)] as one batch.  Per pair of
         ranks the order of the sends equals the order of the matching receives on the other side."""
+        sends = [(t, peer) for t, peer in sends if t.numel()]     # zero-width slices (d < column groups): both sides
+        recvs = [(t, peer) for t, peer in recvs if t.numel()]     # know the size, both skip
         if not sends and not recvs:
             return _Works([])
         if not staged:
@@ -403,10 +405,10 @@ class ShardedPropagator:
                 outs.append(self._dummy(x_next, "out"))
                 continue
             a, b = self._stripe(self.rank, p, g)
-            ins.append(y_piece[a - base:b - base] if b > a else self._dummy(x_next, "in"))
+            ins.append(y_piece[a - base:b - base] if b > a and self.widths[my_cg] else self._dummy(x_next, "in"))
             rg_g, cg_g = L.coords(g)
             a, b = self._stripe(rg_g, p, me)
-            if b <= a:
+            if b <= a or not self.widths[cg_g]:           # nothing to move: a 1-element placeholder on both sides
                 outs.append(self._dummy(x_next, ("out", g)))
             else:
                 outs.append(x_next[a:b] if cg_g == my_cg else self._relay_buf(p, g, b - a, self.widths[cg_g], x_next))
@@ -425,7 +427,7 @@ class ShardedPropagator:
             # to q: stripe `me` of the piece of q's partner (my own kept stripe if that partner is me)
             g = [m for m in L.members(L.coords(q)[1]) if m != q][0]
             a, b = self._stripe(L.coords(g)[0], p, me)
-            if b <= a:
+            if b <= a or not self.widths[L.coords(q)[1]]:
                 ins.append(self._dummy(x_next, "in"))
             elif g == me:
                 ins.append(y_piece[a - base:b - base])
@@ -433,7 +435,7 @@ class ShardedPropagator:
                 ins.append(self._relay_buf(p, g, b - a, self.widths[L.coords(q)[1]], x_next))
             # from q: stripe q of my partner's piece
             a, b = self._stripe(L.coords(partner)[0], p, q)
-            outs.append(x_next[a:b] if b > a else self._dummy(x_next, ("out", q)))
+            outs.append(x_next[a:b] if b > a and x_next.shape[1] else self._dummy(x_next, ("out", q)))
         return _Works([dist.all_to_all(outs, ins, group=self.group, async_op=True)])
 
     def _exchange_piece(self, p, y_piece, x_next):
@@ -474,7 +476,7 @@ class ShardedPropagator:
             last = h == prop_steps
             y_local = torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
             x_next = None if last else x_buffers[(h - 1) % len(x_buffers)]
-            if x_next is not None and x_next.data_ptr() == cur.data_ptr():
+            if x_next is not None and x_next.numel() and x_next.data_ptr() == cur.data_ptr():
                 raise RuntimeError("need two distinct full-size buffers to ping-pong between hops")
             if two:
                 y_local.record_stream(aux)
@@ -689,7 +691,7 @@ class ShardedPropagator:
                 w_c = x_chunks[c].shape[1]
                 y_local = torch.empty((self.hi - self.lo, w_c), dtype=x_chunks[c].dtype, device=x_chunks[c].device)
                 x_next = None if last else buffers[c][(h - 1) % len(buffers[c])]
-                if x_next is not None and x_next.data_ptr() == cur[c].data_ptr():
+                if x_next is not None and x_next.numel() and x_next.data_ptr() == cur[c].data_ptr():
                     raise RuntimeError("need two distinct buffers per chunk to ping-pong between hops")
                 for p in range(self.pieces):
                     r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo

@@ -87,7 +87,7 @@ def test_sharded_propagation_matches_single_process(tmp_path, world, pieces, K):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
-def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir):
+def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir, graph="pl2000"):
     """grid job: rank (rg, cg) multiplies row block rg with column slice cg; exchanges stay inside the column group
     (direct) or are spread over every rank of the job (relay)"""
     sys.path.insert(0, ROOT)
@@ -99,7 +99,7 @@ def _grid_worker(rank, world, port, row_groups, pieces, K, d, transport, out_dir
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         g = dict(np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")))
-        indptr, indices, data = g["pl2000|indptr"], g["pl2000|indices"], g["pl2000|data"]
+        indptr, indices, data = g[graph + "|indptr"], g[graph + "|indices"], g[graph + "|data"]
         n = len(indptr) - 1
         ptr, col, val = oracle.sym_norm_csr(indptr, indices, data, n, 0.5)
         val = val.astype(np.float32)
@@ -162,6 +162,16 @@ def test_grid_layouts_match_single_process(tmp_path, world, row_groups, pieces, 
     port = _free_port()
     mp.spawn(_grid_worker, args=(world, port, row_groups, pieces, K, 11, transport, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@pytest.mark.parametrize("transport", ["relay", "relay_all_to_all", "p2p"])
+def test_grid_with_more_stripes_than_rows(tmp_path, transport):
+    """40 rows, 8 ranks, 3 pieces: most stripes (and some whole pieces) are empty -- both sides must skip the same
+    transfers, d = 3 < column groups leaves a column group without columns"""
+    port = _free_port()
+    mp.spawn(_grid_worker, args=(8, port, 2, 3, 2, 3, transport, str(tmp_path), "dir40"), nprocs=8, join=True)
+    for r in range(8):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
