@@ -37,6 +37,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_BYTES = 8.0e12  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def baseline_metric():
+    """the metric string of BASELINE.json, verbatim (the file travels with the repo snapshot)"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:  # noqa: BLE001
+        return "pre-prop SpMM throughput (edge\u00b7featdim/s), ogbn-products k=3, 1/2/4/8 GPU"
+
+
 def algorithmic_bytes_per_hop(n, nnz, d):
     """SURVEY.md section 8(d) no-reuse gather model: gathered X rows + (col,val) + rowptr + Y write"""
     return nnz * d * 4 + nnz * 8 + (n + 1) * 4 + n * d * 4
@@ -74,7 +83,7 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
             cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
     except Exception:  # noqa: BLE001
         pass
-    out = {"value": nnz_s * d / t, "unit": "edge*featdim/s", "cores": threads, "kind": kind,
+    out = {"value": nnz_s * d / t, "unit": "edge\u00b7featdim/s", "cores": threads, "kind": kind,
            "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}, one hop, median of {len(times)} reps, "
                      f"OpenMP static schedule, {threads} threads on {cpu_model}",
            "ms_per_hop_sample": t * 1e3}
@@ -87,7 +96,7 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
         t0 = time.perf_counter()
         a.dot(xh)
         ts = time.perf_counter() - t0
-        out["scipy_dot"] = {"value": int(rp[r2]) * d / ts, "unit": "edge*featdim/s", "cores": 1,
+        out["scipy_dot"] = {"value": int(rp[r2]) * d / ts, "unit": "edge\u00b7featdim/s", "cores": 1,
                             "sample": f"scipy csr.dot on the first {r2} rows ({int(rp[r2])} nnz)"}
     except Exception as e:  # noqa: BLE001
         out["scipy_dot"] = {"value": None, "sample": f"failed: {e}"}
@@ -582,7 +591,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         try:
             cpu = cpu_baseline(job.rowptr, job.col, job.val, job.x0, d)
         except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
-            cpu = {"value": None, "unit": "edge*featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            cpu = {"value": None, "unit": "edge\u00b7featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
     out = None
     if rank == 0:
@@ -602,8 +611,8 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
-            "metric": "pre-prop SpMM throughput (edge*featdim/s), ogbn-products k=3",
-            "value": value, "unit": "edge*featdim/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": baseline_metric(),
+            "value": value, "unit": "edge\u00b7featdim/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: SGC prop_steps={K} pre-propagation on an ogbn-products-shaped "

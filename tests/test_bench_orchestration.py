@@ -105,7 +105,7 @@ def test_bench_two_ranks_gloo(tmp_path):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j, key
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "strong"
-    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge*featdim/s" and j["vs_baseline"] is None
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge\u00b7featdim/s" and j["metric"].startswith("pre-prop SpMM throughput") and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] and j["cpu_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["config"]["plan"]["exchange"] in ("p2p", "allgather") and len(j["config"]["plan"]["exchange_candidates_ms"]) >= 1
