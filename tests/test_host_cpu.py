@@ -266,3 +266,29 @@ def test_row_pitch_is_line_aware():
     assert [row_pitch(d) for d in (100, 128, 147, 500, 12, 13, 16, 50)] == [100, 128, 160, 512, 16, 16, 16, 64]
     assert row_pitch(25) == 32 and row_pitch(20) == 20 and row_pitch(20, growth=2.0) == 32
     assert expected_lines(100, 100) == 4 and expected_lines(128, 100) == 4 and expected_lines(160, 147) == 5
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/sgl_hip.h is the drop-in boundary: it must compile as C99 and as C++17, and a plain C program built
+    against it must link with libsgl_hip.so and call an entry point (no GPU needed: version / error / tuning calls)"""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "sgl_hip.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    src = tmp_path / "use_abi.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "sgl_hip.h"\n'
+                   'int main(void) {\n'
+                   '  sgl_csr_t *h = NULL;\n'
+                   '  int rc = sgl_csr_create(&h, -1, 1, 0, NULL, NULL, NULL, 0, 0, 0, NULL);\n'
+                   '  printf("%d|%d|%s\\n", sgl_version(), rc != 0, strlen(sgl_last_error()) > 0 ? "msg" : "nomsg");\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "use_abi"
+    libdir = os.path.join(ROOT, "sgl_amd", "csrc")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lsgl_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,--allow-shlib-undefined"])
+    out = subprocess.check_output([str(exe)], text=True).strip().split("|")
+    assert int(out[0]) > 0 and out[1] == "1" and out[2] == "msg"          # bad arguments -> error code + message, no abort
