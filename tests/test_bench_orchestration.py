@@ -133,6 +133,18 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
     assert j["config"]["diagnostics"] is None
 
 
+def test_bench_eight_ranks_gloo(tmp_path):
+    """the driver's largest launch shape: 8 ranks, all three layouts (the grid is 2 row blocks x 4 column slices)"""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
+    assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
+    j = json.loads(lines[0][0])
+    plan = j["config"]["plan"]
+    assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
+    assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0
+
+
 def test_bench_single_rank_contract(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
