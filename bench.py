@@ -381,7 +381,7 @@ def _build_grid(job, ref, row_groups):
     def check():
         hops = prop.propagate(xs, K, x_buffers=bufs)
         return ref.close(hops[K][:, :w], prop.lo, prop.hi, a, b)
-    return {"step": lambda: prop.propagate(xs, K, x_buffers=bufs), "check": check,
+    return {"step": lambda: prop.propagate(xs, K, x_buffers=bufs), "check": check, "halves": (prop, [xs], [bufs]),
             "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed over all "
                         f"{job.world} ranks, {args.grid_pieces} row pieces"}
 
@@ -472,14 +472,14 @@ def _build_rows(job, ref):
 
     def check():
         return all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(step()[K], chunks))
-    return {"step": step, "check": check, "rows": (prop, x_chunks, cbufs),
+    return {"step": step, "check": check, "halves": (prop, x_chunks, cbufs),
             "describe": f"row-sharded x{job.world} + per-hop all-gather ({exchange}), {args.pieces} row pieces x "
                         f"{len(chunks)} column chunks"}
 
 
 def _select_layout(job):
     """Build every candidate layout, validate it against the single-GPU chain, time a full step, keep the fastest.
-    Returns (step, rows_candidate_or_None)."""
+    Returns (step, {layout: (propagator, x_chunks, buffers)} for the layouts that exchange rows)."""
     args, info, world = job.args, job.info, job.world
     ref = _Reference(job)
     builders = {"cols": lambda: _build_cols(job, ref), "rows": lambda: _build_rows(job, ref)}
@@ -514,22 +514,39 @@ def _select_layout(job):
     if rejected:
         info["layout_rejected"] = rejected
     info["parallelism"] = cands[chosen]["describe"]
-    rows = cands["rows"].get("rows") if "rows" in cands else None
-    return cands[chosen]["step"], rows
+    halves = {name: c["halves"] for name, c in cands.items() if "halves" in c}
+    return cands[chosen]["step"], halves
 
 
-def _rows_diagnostics(job, rows):
-    """after the timed region, never part of `value`: the two halves of a row-sharded hop in isolation"""
-    prop, x_chunks, cbufs = rows
+def _hop_halves(job, prop, x_chunks, cbufs, inbound):
+    """the two halves of an exchanging layout's hop in isolation: SpMM only / exchange only (MAX over ranks)"""
     ys = prop.spmm_only(x_chunks)
     spmm_ms = job.timed_s(lambda: prop.spmm_only(x_chunks), reps=3) * 1e3
     xnext = [b[0] for b in cbufs]
-    exch_ms = job.timed_s(lambda: prop.exchange_only(ys, xnext), reps=3) * 1e3 if job.world > 1 else 0.0
-    inbound = (job.world - 1) / job.world * job.n * job.d * 4
+    exch_ms = job.timed_s(lambda: prop.exchange_only(ys, xnext), reps=3) * 1e3 if prop._exchanging() else 0.0
     return {"spmm_only_ms_per_hop_max_rank": spmm_ms, "exchange_only_ms_per_hop_max_rank": exch_ms,
             "inbound_bytes_per_rank_per_hop": inbound,
-            "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None,
-            "exchange_GBps_per_link": (inbound / (job.world - 1) / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
+            "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
+
+
+def _diagnostics(job, halves):
+    """after the timed region, never part of `value`.  Row-sharded layout: its SpMM and all-gather halves and the
+    achieved rate per link; grid layout: the same two halves of the relayed exchange (every byte crosses two links)."""
+    diag = None
+    if "rows" in halves and job.nbuf > 0:
+        inbound = (job.world - 1) / job.world * job.n * job.d * 4
+        diag = _hop_halves(job, *halves["rows"], inbound)
+        ms = diag["exchange_only_ms_per_hop_max_rank"]
+        diag["exchange_GBps_per_link"] = (inbound / (job.world - 1) / (ms * 1e-3) / 1e9) if ms > 0 else None
+    if "grid" in halves and job.nbuf > 0:
+        prop, x_chunks, cbufs = halves["grid"]
+        inbound = (prop.world - 1) / prop.world * job.n * x_chunks[0].shape[1] * 4
+        g = _hop_halves(job, prop, x_chunks, cbufs, inbound)
+        ms = g["exchange_only_ms_per_hop_max_rank"]
+        # two phases, each moving 1/world of the block over every one of the world-1 links
+        g["relay_GBps_per_link"] = (2 * inbound / job.world / (ms * 1e-3) / 1e9) if ms > 0 else None
+        diag = dict(diag or {}, grid=g)
+    return diag
 
 
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
@@ -562,11 +579,11 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     job.load_workload(wl)
     nnz = job.nnz
     sharded = world > 1 or args.force_sharded
-    rows = None
+    halves = {}
     if not sharded:
         step, job.info = engine.single_step(args, job.rowptr, job.col, job.val, job.x0, n, d, K)
     else:
-        step, rows = _select_layout(job)
+        step, halves = _select_layout(job)
     info = job.info
     setup_s = time.perf_counter() - t_setup
 
@@ -584,7 +601,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
 
-    diag = _rows_diagnostics(job, rows) if rows is not None and job.nbuf > 0 else None
+    diag = _diagnostics(job, halves)
 
     cpu = None
     if not sharded and not args.no_cpu_baseline and rank == 0:

@@ -130,7 +130,9 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "grid", "--grid-pieces", "2")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     assert j["config"]["plan"]["layout"] == "grid" and j["config"]["parallelism"].startswith("grid 2 row blocks x 2 column slices")
-    assert j["config"]["diagnostics"] is None
+    g = j["config"]["diagnostics"]["grid"]          # only the grid was built: its two halves, no row-sharded entry
+    assert g["spmm_only_ms_per_hop_max_rank"] > 0 and g["exchange_only_ms_per_hop_max_rank"] > 0 and g["relay_GBps_per_link"] > 0
+    assert "spmm_only_ms_per_hop_max_rank" not in j["config"]["diagnostics"]
 
 
 def test_bench_eight_ranks_gloo(tmp_path):
