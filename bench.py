@@ -601,7 +601,10 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
 
-    diag = _diagnostics(job, halves)
+    try:
+        diag = _diagnostics(job, halves)
+    except Exception as e:  # noqa: BLE001  (reporting only; the measured value is already in hand)
+        diag = {"failed": repr(e)}
 
     cpu = None
     if not sharded and not args.no_cpu_baseline and rank == 0:
