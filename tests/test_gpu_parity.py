@@ -1075,3 +1075,22 @@ def test_products_scale_properties(cuda):
     # (5) k-step propagation through the operator API reproduces repeated SpMM
     hop2 = strict.spmm(ys)
     assert torch.equal(hop2, strict.spmm(strict.spmm(x)))
+
+
+def test_c_abi_from_plain_c_program(cuda, tmp_path):
+    """examples/c_abi_propagate.c: a C99 program with raw hipMalloc'ed buffers (no Python, no PyTorch) normalises a
+    graph and runs the k-hop chain through include/sgl_hip.h, and checks every hop bit for bit against the
+    reference's loop order on the host"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(ROOT, "sgl_amd", "csrc")
+    exe = str(tmp_path / "c_abi_propagate")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "examples", "c_abi_propagate.c"), "-o", exe,
+                           "-L", libdir, "-lsgl_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("C-ABI OK"), (out.returncode, out.stdout, out.stderr)
