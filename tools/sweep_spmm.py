@@ -152,6 +152,15 @@ def main():
         x2 = x0[order].contiguous()
         c = dev.DeviceCSR(p2, c2, v2, (n, n))
         report("relabel", time_hops(chain(c, xin=x2)), K, order="degree_desc")
+        if "narrow" in exps:
+            # column slices of a feature-sharded / grid rank: do hub rows stay L2-resident when rows are 64-128 bytes?
+            for dd in (16, 32):
+                xs = torch.randn((n, dd), device=device)
+                outs = [torch.empty_like(xs) for _ in range(2)]
+                t_base = time_hops(chain(base, xin=xs, outs=outs)) / K
+                t_rel = time_hops(chain(c, xin=xs, outs=outs)) / K
+                print(f"EXP relabel_narrow d={dd} original_order_ms={t_base:.3f} degree_order_ms={t_rel:.3f}", flush=True)
+                del xs, outs
         for B, hot_frac in ((2, 0.1), (2, 0.25), (3, 0.2), (4, 0.25)):
             # first block = the hottest rows (what fits the 256 MiB Infinity Cache), rest equal width
             hot = int(n * hot_frac)
