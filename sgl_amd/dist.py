@@ -733,6 +733,7 @@ class ShardedGraphOp:
         self.row_groups, self.transport = row_groups, transport
         self.lo = self.hi = self.c0 = self.c1 = None
         self._cache = None
+        self._props = {}
 
     def _ranks(self):
         if dist.is_available() and dist.is_initialized():
@@ -760,6 +761,7 @@ class ShardedGraphOp:
             pb = all_piece_bounds(rp_host, row_groups, self.pieces)
             fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rg], rowptr_host=rp_host, strict=self.strict_order)
             self._cache = (key, fns, pb, handles)
+            self._props = {}
         _, fns, pb, handles = self._cache
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
         x = x.to(device=device, dtype=torch.float32)
@@ -770,7 +772,10 @@ class ShardedGraphOp:
         self.c0, self.c1 = slices[cg]
         if layout.col_groups == 1:
             transport = self.transport or ("staged" if world > 1 and self._gloo() else "p2p")
-            prop = ShardedPropagator(fns, pb, rank, world, n, group=self.group, transport=transport)
+            prop = self._props.get(("rows", transport))
+            if prop is None:
+                prop = self._props[("rows", transport)] = ShardedPropagator(fns, pb, rank, world, n, group=self.group,
+                                                                            transport=transport)
             self._prop = prop
             self.lo, self.hi = prop.lo, prop.hi
             x = x.contiguous()
@@ -783,8 +788,10 @@ class ShardedGraphOp:
         # (the pad columns stay zero and cost no extra cache lines)
         pitch = [dev.row_pitch(b - a, growth=2.0) if b > a else 0 for a, b in slices]
         transport = self.transport or (("relay_staged" if self._gloo() else "relay") if row_groups > 1 else "p2p")
-        prop = ShardedPropagator(fns, pb, rg, row_groups, n, group=self.group, transport=transport, layout=layout,
-                                 me=rank, widths=pitch)
+        prop = self._props.get((d, transport))               # keeps its relay buffers / streams across calls
+        if prop is None:
+            prop = self._props[(d, transport)] = ShardedPropagator(fns, pb, rg, row_groups, n, group=self.group,
+                                                                   transport=transport, layout=layout, me=rank, widths=pitch)
         self._prop = prop
         self.lo, self.hi = prop.lo, prop.hi
         w = self.c1 - self.c0
