@@ -1094,3 +1094,26 @@ def test_c_abi_from_plain_c_program(cuda, tmp_path):
                            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("C-ABI OK"), (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.parametrize("launcher", ["python", "torchrun"])
+def test_bench_cli_prints_exactly_one_json_line(cuda, launcher):
+    """the driver's contract: `python bench.py ...` (and the same under torch.distributed.run with one rank) writes ONE
+    line to stdout -- the JSON -- whatever the libraries print; the small workload keeps it to seconds"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29653"]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "S1_small"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and j["cpu_baseline"]["value"] > 0
