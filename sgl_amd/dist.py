@@ -222,6 +222,7 @@ class ShardedPropagator:
         self.relay_collective = None          # relay phases as one all_to_all each: None = when the backend is RCCL
         self._ag_buf = {}
         self._relay_bufs = {}
+        self._a2a_plans = {}
         self.spmm_pieces = spmm_pieces
         self.pb = np.asarray(all_piece_bounds, dtype=np.int64)
         self.rank, self.world, self.n = rank, world, int(n_rows)
@@ -394,49 +395,71 @@ class ShardedPropagator:
             self._relay_bufs[key] = buf
         return buf
 
-    def _relay_phase1_a2a(self, p, y_piece, x_next):
+    def _a2a_plan(self, p):
+        """Static part of the two all_to_all calls of piece p, computed once: per peer what to send and where to
+        receive, as (kind, a, b, aux) with kind 0 = placeholder, 1 = rows [a, b) of my piece (relative), 2 = rows
+        [a, b) of the next-hop replica, 3 = relay buffer of source rank aux = (g, rows, width)."""
+        plan = self._a2a_plans.get(p)
+        if plan is not None:
+            return plan
         L, me = self.layout, self.me
         my_cg = L.coords(me)[1]
-        base = int(self.pb[self.rank, p])
-        ins, outs = [], []
-        for g in range(L.world):
-            if g == me:                                   # my own stripe stays where it is
-                ins.append(self._dummy(x_next, "in"))
-                outs.append(self._dummy(x_next, "out"))
-                continue
-            a, b = self._stripe(self.rank, p, g)
-            ins.append(y_piece[a - base:b - base] if b > a and self.widths[my_cg] else self._dummy(x_next, "in"))
-            rg_g, cg_g = L.coords(g)
-            a, b = self._stripe(rg_g, p, me)
-            if b <= a or not self.widths[cg_g]:           # nothing to move: a 1-element placeholder on both sides
-                outs.append(self._dummy(x_next, ("out", g)))
-            else:
-                outs.append(x_next[a:b] if cg_g == my_cg else self._relay_buf(p, g, b - a, self.widths[cg_g], x_next))
-        return _Works([dist.all_to_all(outs, ins, group=self.group, async_op=True)])
-
-    def _relay_phase2_a2a(self, p, y_piece, x_next):
-        L, me = self.layout, self.me
         partner = [q for q in self.members if q != me][0]
         base = int(self.pb[self.rank, p])
-        ins, outs = [], []
-        for q in range(L.world):
-            if q == me:
-                ins.append(self._dummy(x_next, "in"))
-                outs.append(self._dummy(x_next, "out"))
+        ins1, outs1, ins2, outs2 = [], [], [], []
+        for g in range(L.world):
+            if g == me:                                   # my own stripe stays where it is
+                ins1.append((0, 0, 0, "in")); outs1.append((0, 0, 0, "out"))
+                ins2.append((0, 0, 0, "in")); outs2.append((0, 0, 0, "out"))
                 continue
-            # to q: stripe `me` of the piece of q's partner (my own kept stripe if that partner is me)
-            g = [m for m in L.members(L.coords(q)[1]) if m != q][0]
-            a, b = self._stripe(L.coords(g)[0], p, me)
-            if b <= a or not self.widths[L.coords(q)[1]]:
-                ins.append(self._dummy(x_next, "in"))
-            elif g == me:
-                ins.append(y_piece[a - base:b - base])
+            rg_g, cg_g = L.coords(g)
+            # phase 1, to g: stripe g of my piece; from g: stripe `me` of its piece
+            a, b = self._stripe(self.rank, p, g)
+            ins1.append((1, a - base, b - base, None) if b > a and self.widths[my_cg] else (0, 0, 0, "in"))
+            a, b = self._stripe(rg_g, p, me)
+            if b <= a or not self.widths[cg_g]:           # nothing to move: a 1-element placeholder on both sides
+                outs1.append((0, 0, 0, ("out", g)))
+            elif cg_g == my_cg:
+                outs1.append((2, a, b, None))
             else:
-                ins.append(self._relay_buf(p, g, b - a, self.widths[L.coords(q)[1]], x_next))
-            # from q: stripe q of my partner's piece
-            a, b = self._stripe(L.coords(partner)[0], p, q)
-            outs.append(x_next[a:b] if b > a and x_next.shape[1] else self._dummy(x_next, ("out", q)))
-        return _Works([dist.all_to_all(outs, ins, group=self.group, async_op=True)])
+                outs1.append((3, 0, 0, (g, b - a, self.widths[cg_g])))
+            # phase 2, to g: stripe `me` of the piece of g's partner (my own kept stripe if that partner is me)
+            owner = [m for m in L.members(cg_g) if m != g][0]
+            a, b = self._stripe(L.coords(owner)[0], p, me)
+            if b <= a or not self.widths[cg_g]:
+                ins2.append((0, 0, 0, "in"))
+            elif owner == me:
+                ins2.append((1, a - base, b - base, None))
+            else:
+                ins2.append((3, 0, 0, (owner, b - a, self.widths[cg_g])))
+            # from g: stripe g of my partner's piece
+            a, b = self._stripe(L.coords(partner)[0], p, g)
+            outs2.append((2, a, b, None) if b > a and self.widths[my_cg] else (0, 0, 0, ("out", g)))
+        plan = self._a2a_plans[p] = ((ins1, outs1), (ins2, outs2))
+        return plan
+
+    def _a2a_tensors(self, p, entries, y_piece, x_next):
+        out = []
+        for kind, a, b, aux in entries:
+            if kind == 1:
+                out.append(y_piece[a:b])
+            elif kind == 2:
+                out.append(x_next[a:b])
+            elif kind == 3:
+                out.append(self._relay_buf(p, aux[0], aux[1], aux[2], x_next))
+            else:
+                out.append(self._dummy(x_next, aux))
+        return out
+
+    def _relay_phase1_a2a(self, p, y_piece, x_next):
+        ins, outs = self._a2a_plan(p)[0]
+        return _Works([dist.all_to_all(self._a2a_tensors(p, outs, y_piece, x_next),
+                                       self._a2a_tensors(p, ins, y_piece, x_next), group=self.group, async_op=True)])
+
+    def _relay_phase2_a2a(self, p, y_piece, x_next):
+        ins, outs = self._a2a_plan(p)[1]
+        return _Works([dist.all_to_all(self._a2a_tensors(p, outs, y_piece, x_next),
+                                       self._a2a_tensors(p, ins, y_piece, x_next), group=self.group, async_op=True)])
 
     def _exchange_piece(self, p, y_piece, x_next):
         """start moving my piece p to the ranks of my column group (and theirs to me).  Returns an object with
