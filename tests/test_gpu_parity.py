@@ -513,7 +513,7 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("d", [147, 7, 100, 500, 1])
+@pytest.mark.parametrize("d", [147, 7, 100, 500, 1, 5, 12, 13, 33])
 @pytest.mark.parametrize("padded", [True, False])
 def test_aggregators_any_width_and_layout(cuda, d, padded):
     """every aggregator kernel against the numpy oracle for widths that are / are not multiples of 4, on row-padded
@@ -1117,3 +1117,27 @@ def test_bench_cli_prints_exactly_one_json_line(cuda, launcher):
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and j["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("n,H,d", [(1, 1, 3), (2, 1, 1), (1, 5, 64), (65, 2, 2), (3, 12, 9)])
+def test_aggregators_degenerate_shapes(cuda, n, H, d):
+    """one row, one hop, one column: every aggregator kernel still matches the oracle"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    host = [np.ascontiguousarray(hash_matrix(n, d, seed=90 + h), dtype=np.float32) for h in range(H)]
+    feats = []
+    for x in host:
+        t = dev.alloc_rows(n, d, cuda)
+        t.copy_(torch.from_numpy(x))
+        feats.append(t)
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_SUM, feats).cpu().numpy(), oracle.agg_sum(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MEAN, feats).cpu().numpy(), oracle.agg_mean(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MAX, feats).cpu().numpy(), oracle.agg_max(host, 0, H))
+    assert np.array_equal(dev.hop_concat(feats).cpu().numpy(), oracle.agg_concat(host, 0, H))
+    w2 = oracle.softmax32(hash_matrix(n, H, seed=9), 1)
+    out = dev.hop_wsum2d(feats, torch.from_numpy(w2).to(cuda))
+    assert oracle.parity_ok(out.cpu().numpy(), oracle.two_dim_weighted_add(host, w2), 1e-6, rowwise=False)
+    yn = dev.nafs_aggregate(feats)
+    assert oracle.parity_ok(yn.cpu().numpy(), oracle.agg_over_smooth_distance(host), 1e-5, rowwise=False)
+    idx = torch.arange(n - 1, -1, -1, device=cuda)
+    assert np.array_equal(dev.gather_rows(feats[0], idx).cpu().numpy(), host[0][::-1])
