@@ -377,11 +377,14 @@ def _build_grid(job, ref, row_groups):
     prop = ShardedPropagator(fns, pb, rg, row_groups, job.n, transport=getattr(job.engine, "relay_transport", "relay"),
                              layout=layout, me=job.rank, widths=widths)
     bufs = [torch.empty_like(xs) for _ in range(job.nbuf)]
+    ybufs = [torch.empty((prop.hi - prop.lo, xs.shape[1]), dtype=xs.dtype, device=xs.device) for _ in range(K)]
+
+    def step():
+        return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs)     # every buffer preallocated: no allocator traffic
 
     def check():
-        hops = prop.propagate(xs, K, x_buffers=bufs)
-        return ref.close(hops[K][:, :w], prop.lo, prop.hi, a, b)
-    return {"step": lambda: prop.propagate(xs, K, x_buffers=bufs), "check": check, "halves": (prop, [xs], [bufs]),
+        return ref.close(step()[K][:, :w], prop.lo, prop.hi, a, b)
+    return {"step": step, "check": check, "halves": (prop, [xs], [bufs]),
             "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed over all "
                         f"{job.world} ranks, {args.grid_pieces} row pieces"}
 
@@ -456,6 +459,8 @@ def _build_rows(job, ref):
     # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
     x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
     cbufs = [[torch.empty_like(xc) for _ in range(job.nbuf)] for xc in x_chunks]
+    ybufs = [[torch.empty((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=xc.device) for _ in range(K)]
+             for xc in x_chunks]
     exchange = _select_exchange(job, prop, handles, x_chunks, cbufs)
     if exchange in ("p2p", "allgather", "staged"):
         prop.transport = exchange
@@ -465,10 +470,10 @@ def _build_rows(job, ref):
             return prop.propagate_push(x_chunks, K)
     elif len(chunks) == 1:
         def step():
-            return [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0])]
+            return [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0], y_buffers=ybufs[0])]
     else:
         def step():
-            return prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+            return prop.propagate_chunked(x_chunks, K, buffers=cbufs, y_buffers=ybufs)
 
     def check():
         return all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(step()[K], chunks))

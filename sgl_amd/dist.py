@@ -476,9 +476,12 @@ class ShardedPropagator:
             return self.layout.world > 1 and self.layout.row_groups > 1
         return self.world > 1
 
-    def propagate(self, x_full, prop_steps, x_buffers=None):
+    def propagate(self, x_full, prop_steps, x_buffers=None, y_buffers=None):
         """x_full: [N, d] replica of the input features on this rank's device (row-major, contiguous).
-        Returns the list of K+1 LOCAL hop shards [hi-lo, d] (hop 0 is a view of x_full)."""
+        Returns the list of K+1 LOCAL hop shards [hi-lo, d] (hop 0 is a view of x_full).
+        y_buffers: optional K preallocated [hi-lo, d] outputs (a loop that calls this repeatedly then allocates
+        nothing: with asynchronous transfers holding references, a host running ahead of the GPU would otherwise keep
+        the allocator from recycling the previous calls' outputs)."""
         n, d = x_full.shape
         assert n == self.n
         hops = [x_full[self.lo:self.hi]]
@@ -497,12 +500,14 @@ class ShardedPropagator:
             aux = self._aux_stream(x_full.device)
         for h in range(1, prop_steps + 1):
             last = h == prop_steps
-            y_local = torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
+            y_local = y_buffers[h - 1] if y_buffers is not None else \
+                torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
             x_next = None if last else x_buffers[(h - 1) % len(x_buffers)]
             if x_next is not None and x_next.numel() and x_next.data_ptr() == cur.data_ptr():
                 raise RuntimeError("need two distinct full-size buffers to ping-pong between hops")
             if two:
-                y_local.record_stream(aux)
+                # no record_stream on y_local: the caller's stream waits for `aux` at the end of this hop, before
+                # anything that could recycle the block, so stream order already protects it
                 aux.wait_stream(main)             # the previous hop (and its exchange) is complete for both streams
             works = []
             for p in range(self.pieces):
@@ -683,7 +688,7 @@ class ShardedPropagator:
             hops.append(outs)
         return hops
 
-    def propagate_chunked(self, x_chunks, prop_steps, buffers=None):
+    def propagate_chunked(self, x_chunks, prop_steps, buffers=None, y_buffers=None):
         """Software-pipelined variant: the feature block is held as C column chunks (separate contiguous [N, w_c]
         matrices, see column_chunks()).  SpMM is separable over columns, so while chunk c's new rows are in flight
         to the peers, chunk c+1 is being multiplied, and hop h+1 of chunk c only waits for chunk c's own exchange:
@@ -693,7 +698,8 @@ class ShardedPropagator:
 
         The dependency stall of the plain scheme (next hop cannot start before the whole all-gather landed)
         disappears; in the communication-bound regime the hop time is the transfer time.
-        x_chunks: list of C replicas [N, w_c]; returns hops[h][c] = LOCAL shard [hi-lo, w_c]."""
+        x_chunks: list of C replicas [N, w_c]; returns hops[h][c] = LOCAL shard [hi-lo, w_c].
+        y_buffers[c][h-1]: optional preallocated outputs (see propagate)."""
         C = len(x_chunks)
         n = x_chunks[0].shape[0]
         assert n == self.n and self.pieces >= 1
@@ -712,7 +718,8 @@ class ShardedPropagator:
                     w.wait()
                 pending[c] = []
                 w_c = x_chunks[c].shape[1]
-                y_local = torch.empty((self.hi - self.lo, w_c), dtype=x_chunks[c].dtype, device=x_chunks[c].device)
+                y_local = y_buffers[c][h - 1] if y_buffers is not None else \
+                    torch.empty((self.hi - self.lo, w_c), dtype=x_chunks[c].dtype, device=x_chunks[c].device)
                 x_next = None if last else buffers[c][(h - 1) % len(buffers[c])]
                 if x_next is not None and x_next.numel() and x_next.data_ptr() == cur[c].data_ptr():
                     raise RuntimeError("need two distinct buffers per chunk to ping-pong between hops")
