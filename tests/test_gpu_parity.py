@@ -1141,3 +1141,54 @@ def test_aggregators_degenerate_shapes(cuda, n, H, d):
     assert oracle.parity_ok(yn.cpu().numpy(), oracle.agg_over_smooth_distance(host), 1e-5, rowwise=False)
     idx = torch.arange(n - 1, -1, -1, device=cuda)
     assert np.array_equal(dev.gather_rows(feats[0], idx).cpu().numpy(), host[0][::-1])
+
+
+def _rccl_world1_worker(rank, port, out_dir):
+    import os as _os
+    _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev_ = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev_)
+    try:
+        ok = True
+        # the calls the multi-GPU paths make, with the argument shapes they use, on the real RCCL backend
+        x = torch.arange(12, dtype=torch.float32, device=dev_).view(3, 4)
+        out = torch.empty_like(x)
+        side = torch.cuda.Stream(device=dev_)
+        side.wait_stream(torch.cuda.current_stream(dev_))
+        with torch.cuda.stream(side):
+            w = dist.all_to_all([out[0:3]], [x[0:3]], async_op=True)         # views of row ranges, async, side stream
+            w.wait()
+            w2 = dist.all_to_all([out[1:2]], [x[2:3]], async_op=True)
+        w2.wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(out[0], x[0]) and torch.equal(out[1], x[2])
+        gathered = torch.empty((3, 4), dtype=torch.float32, device=dev_)
+        dist.all_gather_into_tensor(gathered, x, async_op=True).wait()
+        flag = torch.tensor([1], dtype=torch.int32, device=dev_)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev_)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        objs = [None]
+        dist.all_gather_object(objs, {"w": 25})
+        dist.barrier()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(gathered, x) and int(flag) == 1 and float(t) == 1.5 and objs[0] == {"w": 25}
+        open(_os.path.join(out_dir, "ok.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_accepts_the_calls_the_layouts_make(cuda, tmp_path):
+    """one RCCL rank on the one GPU: all_to_all on lists of row-range views issued asynchronously from a side stream,
+    all_gather_into_tensor, the agreement all-reduces, all_gather_object, barrier -- the exact call shapes of
+    sgl_amd/dist.py and bench.py, accepted by the real backend (multi-rank behaviour is covered under gloo)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_world1_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "ok.txt").read() == "ok"
