@@ -649,7 +649,10 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_BYTES, "traffic": traffic,
                          "kernel": "spmm_kernel", "algorithmic_bytes_per_launch": alg,
-                         "avg_launch_ms": hop_s * 1e3},
+                         "avg_launch_ms": hop_s * 1e3,
+                         # measured L2<->memory-side bytes (PMC, profiles/traffic.json) over the same launch time: how
+                         # close the kernel runs to the memory system's peak in bytes actually moved
+                         "traffic_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None},
             "cpu_baseline": cpu,
         }
         quiet.unmute()
