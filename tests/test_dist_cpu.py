@@ -184,3 +184,11 @@ def test_grid_layout_arithmetic():
         GridLayout(8, 3)
     assert column_slices(100, 8) == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 64), (64, 76), (76, 88), (88, 100)]
     assert column_slices(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)] and column_slices(100, 1) == [(0, 100)]
+    # whole 128-byte lines per slice wherever there are at least as many lines as parts
+    assert column_slices(100, 4) == [(0, 32), (32, 64), (64, 96), (96, 100)] and column_slices(100, 2) == [(0, 64), (64, 100)]
+    assert column_slices(128, 4) == [(0, 32), (32, 64), (64, 96), (96, 128)] and column_slices(11, 2) == [(0, 6), (6, 11)]
+    for d in range(1, 300):
+        for parts in range(1, 9):
+            sl = column_slices(d, parts)
+            assert len(sl) == parts and sl[0][0] == 0 and sl[-1][1] == d and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert max(-(-(b - a) // 32) for a, b in sl) == -(-(-(-d // parts)) // 32) or parts > -(-d // 32)

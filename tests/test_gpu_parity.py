@@ -824,7 +824,7 @@ def _two_rank_worker(rank, world, port, out_dir):
         from sgl_amd.operators.message_op import MeanMessageOp
         opc = ShardedGraphOp(3, r=0.5, strict_order=True, row_groups=1)
         hc = opc.propagate(adj, x)
-        ok = ok and (opc.lo, opc.hi) == (0, 2000) and opc.c1 - opc.c0 == 50
+        ok = ok and (opc.lo, opc.hi) == (0, 2000) and (opc.c0, opc.c1) == ((0, 64), (64, 100))[rank]   # whole lines first
         for h in range(4):
             ok = ok and np.array_equal(hc[h].cpu().numpy(), ref[h][:, opc.c0:opc.c1])
         mean = MeanMessageOp(0, 4).aggregate([h.contiguous() for h in hc])
@@ -873,7 +873,7 @@ def _grid_rank_worker(rank, world, port, out_dir):
         for transport in (None, "staged"):                    # relayed over all 4 ranks / direct inside the pair
             op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport=transport)
             hops = op.propagate(adj, x)
-            ok = ok and op.c1 - op.c0 == 25 and 0 < op.hi - op.lo < 2000
+            ok = ok and op.c1 - op.c0 in (32, 18) and 0 < op.hi - op.lo < 2000
             for h in range(4):
                 ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
             full = op.gather_full(hops[3])
