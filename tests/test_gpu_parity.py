@@ -882,12 +882,12 @@ def _grid_rank_worker(rank, world, port, out_dir):
             ok = ok and orc.parity_ok(nafs_g.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
         # the RCCL variant issues both relay phases from a side stream; RCCL refuses several ranks on one device, so
         # run that code path with the transfers themselves staged through the host
-        from sgl_amd.dist import ShardedPropagator
-        orig = ShardedPropagator._xfer
-        ShardedPropagator._xfer = lambda self, sends, recvs, staged=False: orig(self, sends, recvs, True)
+        import sgl_amd.dist as sdist
+        orig = sdist._post
+        sdist._post = lambda group, sends, recvs, staged=False: orig(group, sends, recvs, True)
         op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport="relay")
         hops = op.propagate(adj, x)
-        ok = ok and getattr(op._prop, "_side", None) is not None
+        ok = ok and op._prop._transport._side is not None            # the side-stream branch really ran
         for h in range(4):
             ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
         open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
