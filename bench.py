@@ -9,7 +9,7 @@ One "step" = one full k-hop propagation (prop_steps SpMM launches, k=3 for the h
 the timed region starts.  value = nnz(A_hat) * d * k * steps / time  [edge*featdim/s], whole job.
 
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank holds A_hat; the job is laid out as
-row blocks x column slices (sgl_amd/dist.py): "rows" = A_hat row-sharded (nnz-balanced) + per-hop all-gather over
+row blocks x column slices (sgl_amd/dist/): "rows" = A_hat row-sharded (nnz-balanced) + per-hop all-gather over
 RCCL overlapped with the SpMM of the next row piece, "cols" = feature-sharded (each rank runs the whole chain on d/N
 columns, no communication), "grid" = 2 row blocks x N/2 column slices with the pair exchange relayed over all xGMI
 links.  --layout auto (default) validates every candidate against the single-GPU chain and keeps the fastest.
@@ -339,7 +339,7 @@ class _Reference:
         return want.numel() == 0 or float((block - want).abs().max()) <= 1e-5 * self.scale
 
 
-# ---- the layout candidates of an N-rank job (sgl_amd/dist.py).  Each builder returns {"step", "check", "describe"} ------
+# ---- the layout candidates of an N-rank job (sgl_amd/dist/).  Each builder returns {"step", "check", "describe"} ------
 
 def _build_cols(job, ref):
     """feature-sharded: every rank runs the whole chain on d/N columns, no communication"""

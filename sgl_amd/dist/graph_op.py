@@ -1,0 +1,167 @@
+"""ShardedGraphOp: GraphOp.propagate for one rank of a multi-GPU job, in any layout."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .layout import GridLayout, all_piece_bounds, column_chunks, column_slices, device_piece_spmms
+from .propagator import ShardedPropagator
+
+
+class ShardedGraphOp:
+    """GraphOp.propagate for one rank of a multi-GPU job (BASELINE configs 4/5: NAFS / PaSca sweeps over the GPUs of
+    a node).
+
+    Every rank passes the SAME full adjacency (scipy CSR or sgl_amd.io.DeviceAdjacency; it is normalised on the
+    rank's own GPU -- identical kernels on identical inputs, so all ranks hold bit-identical A_hat) and the same full
+    feature matrix, and gets back the K+1 hop matrices restricted to ITS block: rows `[self.lo, self.hi)` x columns
+    `[self.c0, self.c1)`.  `row_groups` picks the layout (see GridLayout): None = row-sharded over all ranks (the
+    block is full-width; MessageOps are row-wise, so they apply to the local shards unchanged, e.g.
+    OverSmoothDistanceWeightedOp for NAFS), 1 = feature-sharded (all rows, d/G columns, no communication at all;
+    column-wise aggregators -- last/sum/mean/max/min/simple_weighted -- apply unchanged), anything between = grid.
+    288 GB per GPU make the replication affordable up to ogbn-papers100M (27 GB of CSR, two 57 GB feature replicas).
+
+    Works without torch.distributed (world size 1); with it, uses the default process group unless `group` is given
+    (row-sharded layout only: grid layouts address ranks of the default group)."""
+
+    def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None,
+                 device=None, row_groups=None, transport=None):
+        self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
+        self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
+        self.device = device
+        self.row_groups, self.transport = row_groups, transport
+        self.lo = self.hi = self.c0 = self.c1 = None
+        self._cache = None
+        self._props = {}
+
+    def _ranks(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def _gloo(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
+
+    def propagate(self, adj, feature):
+        from .. import device as dev
+        from ..io import DeviceAdjacency
+        rank, world = self._ranks()
+        device = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if not isinstance(adj, DeviceAdjacency):
+            adj = DeviceAdjacency.from_scipy(adj, device=device)
+        n = adj.shape[0]
+        row_groups = world if self.row_groups is None else int(self.row_groups)
+        layout = GridLayout(world, row_groups)
+        rg, cg = layout.coords(rank)
+        key = (id(adj), adj.col.data_ptr(), adj.nnz, world, rank, row_groups)
+        if self._cache is None or self._cache[0] != key:
+            rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, n, self.r, self.alpha)
+            rp_host = rowptr.cpu().numpy()
+            pb = all_piece_bounds(rp_host, row_groups, self.pieces)
+            fns, handles = device_piece_spmms(rowptr, col, val, n, pb[rg], rowptr_host=rp_host, strict=self.strict_order)
+            self._cache = (key, fns, pb, handles)
+            self._props = {}
+        _, fns, pb, handles = self._cache
+        x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
+        x = x.to(device=device, dtype=torch.float32)
+        if x.shape[0] != n:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        d = x.shape[1]
+        slices = column_slices(d, layout.col_groups)
+        self.c0, self.c1 = slices[cg]
+        if layout.col_groups == 1:
+            transport = self.transport or ("staged" if world > 1 and self._gloo() else "p2p")
+            prop = self._props.get(("rows", transport))
+            if prop is None:
+                prop = self._props[("rows", transport)] = ShardedPropagator(fns, pb, rank, world, n, group=self.group,
+                                                                            transport=transport)
+            self._prop = prop
+            self.lo, self.hi = prop.lo, prop.hi
+            x = x.contiguous()
+            chunks = column_chunks(d, self.col_chunks if world > 1 else 1)
+            if len(chunks) == 1:
+                return prop.propagate(x, self.prop_steps)
+            hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+            return [torch.cat(h, dim=1) for h in hops]
+        # grid / feature-sharded: the slice is stored zero-padded to a line-friendly pitch and multiplied at that width
+        # (the pad columns stay zero and cost no extra cache lines)
+        pitch = [dev.row_pitch(b - a, growth=2.0) if b > a else 0 for a, b in slices]
+        transport = self.transport or (("relay_staged" if self._gloo() else "relay") if row_groups > 1 else "p2p")
+        prop = self._props.get((d, transport))               # keeps its relay buffers / streams across calls
+        if prop is None:
+            prop = self._props[(d, transport)] = ShardedPropagator(fns, pb, rg, row_groups, n, group=self.group,
+                                                                   transport=transport, layout=layout, me=rank, widths=pitch)
+        self._prop = prop
+        self.lo, self.hi = prop.lo, prop.hi
+        w = self.c1 - self.c0
+        xs = torch.zeros((n, pitch[cg]), dtype=torch.float32, device=device)
+        xs[:, :w] = x[:, self.c0:self.c1]
+        hops = prop.propagate(xs, self.prop_steps)
+        return [h[:, :w] for h in hops]
+
+    def gather_full(self, local):
+        """assemble the full [N, d] matrix on every rank from the ranks' blocks (e.g. the final aggregated features).
+        `local` is this rank's block: rows [lo, hi), any width (the same inside a column group); the column groups'
+        blocks are laid side by side in column-group order."""
+        rank, world = self._ranks()
+        if world == 1:
+            return local
+        prop = self._prop
+        layout = prop.layout or GridLayout(world, world)
+        staged = local.is_cuda and self._gloo()
+        send = (local.detach().cpu() if staged else local).contiguous()
+        widths = [None] * world
+        dist.all_gather_object(widths, int(local.shape[1]), group=self.group)
+        col_w = [int(widths[layout.members(cg)[0]]) for cg in range(layout.col_groups)]
+        col_off = np.concatenate([[0], np.cumsum(col_w)])
+        total = int(col_off[-1])
+        full = torch.zeros((prop.n, total), dtype=local.dtype, device=send.device)
+        ops, landings = [], []
+        for k in range(1, world):
+            dst, src = (rank + k) % world, (rank - k) % world
+            if send.numel():
+                ops.append(dist.P2POp(dist.isend, send, dst, group=self.group))
+            rg_s, cg_s = layout.coords(src)
+            r0, r1 = int(prop.pb[rg_s, 0]), int(prop.pb[rg_s, -1])
+            if (r1 - r0) * col_w[cg_s]:
+                buf = torch.empty((r1 - r0, col_w[cg_s]), dtype=local.dtype, device=send.device)
+                ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+                landings.append((r0, r1, int(col_off[cg_s]), buf))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        rg, cg = layout.coords(rank)
+        full[prop.lo:prop.hi, int(col_off[cg]):int(col_off[cg]) + local.shape[1]].copy_(send)
+        for w in works:
+            w.wait()
+        for r0, r1, c, buf in landings:
+            full[r0:r1, c:c + buf.shape[1]].copy_(buf)
+        return full.to(local.device) if staged else full
+
+    def gather_rows(self, local):
+        """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (row-sharded layout)"""
+        return self.gather_full(local)
+
+    def over_smooth_aggregate(self, hops):
+        """OverSmoothDistanceWeightedOp (NAFS, message_op/over_smooth_distance_op.py:6-33) on this rank's blocks, for any
+        layout.  The weights need whole rows (cosine of X_0[n] and X_h[n]); a rank that owns only a column slice
+        contributes the partial sums of its columns -- X_0.X_h and |X_h|^2 per row and hop, one all-reduce of
+        [N, 2H] floats for the whole job -- and then combines its own columns with the shared weights.  Row-sharded
+        ranks own whole rows and use the fused single-pass kernel directly."""
+        from .. import device as dev
+        prop = self._prop
+        feats = [h.contiguous() for h in hops]
+        if prop.layout is None or prop.layout.col_groups == 1:
+            return dev.nafs_aggregate(feats)
+        H = len(feats)
+        part = torch.zeros((prop.n, 2 * H), dtype=torch.float32, device=feats[0].device)
+        blk = part[prop.lo:prop.hi]
+        for h, xh in enumerate(feats):
+            blk[:, h] = (feats[0] * xh).sum(dim=1)
+            blk[:, H + h] = (xh * xh).sum(dim=1)
+        if self._gloo() and part.is_cuda:
+            host = part.cpu()
+            dist.all_reduce(host, group=self.group)
+            part.copy_(host)
+        else:
+            dist.all_reduce(part, group=self.group)
+        norms = blk[:, H:].sqrt() + 1e-10                    # the reference adds 1e-10 to each norm (:14, :16)
+        w = torch.softmax(blk[:, :H] / norms / norms[:, :1], dim=1).contiguous()
+        return dev.hop_wsum2d(feats, w)

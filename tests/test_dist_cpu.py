@@ -1,4 +1,4 @@
-"""world_size-2/3 gloo tests (CPU) of the row-sharded propagation orchestration in sgl_amd/dist.py:
+"""world_size-2/3 gloo tests (CPU) of the row-sharded propagation orchestration in sgl_amd/dist/:
 shard arithmetic, piece-wise point-to-point all-gather, buffer ping-pong.  The local SpMM is injected (the CPU
 oracle stands in for the HIP kernel here ONLY because this is a test of the exchange logic, which is
 device-agnostic); the GPU kernels themselves are covered by tests/test_gpu_parity.py."""

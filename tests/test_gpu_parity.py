@@ -882,7 +882,7 @@ def _grid_rank_worker(rank, world, port, out_dir):
             ok = ok and orc.parity_ok(nafs_g.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
         # the RCCL variant issues both relay phases from a side stream; RCCL refuses several ranks on one device, so
         # run that code path with the transfers themselves staged through the host
-        import sgl_amd.dist as sdist
+        import sgl_amd.dist.transports as sdist
         orig = sdist._post
         sdist._post = lambda group, sends, recvs, staged=False: orig(group, sends, recvs, True)
         op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport="relay")
@@ -1183,7 +1183,7 @@ def _rccl_world1_worker(rank, port, out_dir):
 def test_rccl_backend_accepts_the_calls_the_layouts_make(cuda, tmp_path):
     """one RCCL rank on the one GPU: all_to_all on lists of row-range views issued asynchronously from a side stream,
     all_gather_into_tensor, the agreement all-reduces, all_gather_object, barrier -- the exact call shapes of
-    sgl_amd/dist.py and bench.py, accepted by the real backend (multi-rank behaviour is covered under gloo)"""
+    sgl_amd/dist/ and bench.py, accepted by the real backend (multi-rank behaviour is covered under gloo)"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
