@@ -145,6 +145,8 @@ def test_bench_eight_ranks_gloo(tmp_path):
     plan = j["config"]["plan"]
     assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
     assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0
+    links = j["config"]["diagnostics"]["links"]     # gloo: the pairwise exchange works, all_to_all may not exist
+    assert links["pair_exchange_64MB_GBps_per_direction"] > 0 and "all_to_all_1MB_per_peer_GBps_per_link" in links
 
 
 def test_bench_single_rank_contract(tmp_path, monkeypatch):

@@ -923,6 +923,7 @@ def _bench_worker(rank, world, port, out_dir, extra=()):
         backend = "gloo"
         transports = ("staged",)
         relay_transport = "relay_staged"
+        probe_links = False                   # the link micro-benchmark moves device tensors through the process group
 
         def init_kwargs(self):
             return {}
