@@ -221,7 +221,8 @@ def parse_args(argv=None):
                     help="N>1: rows = A_hat row-sharded + per-hop all-gather; cols = feature-sharded (each GPU runs the "
                          "whole chain on d/N columns, no communication); grid = 2 row blocks x N/2 column slices with "
                          "the pair exchange relayed over all links; auto = validate and time each, keep the fastest")
-    ap.add_argument("--grid-pieces", type=int, default=4, help="row pieces per rank of the grid layout")
+    ap.add_argument("--grid-pieces", default="2,4,8",
+                    help="row pieces per rank of the grid layout; a comma list is tried and the fastest count kept")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dup2", action="store_true",
                     help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "
@@ -359,34 +360,58 @@ def _build_cols(job, ref):
 
 
 def _build_grid(job, ref, row_groups):
-    """row_groups row blocks x N/row_groups column slices, the exchange inside a column group relayed over all ranks"""
+    """row_groups row blocks x N/row_groups column slices, the exchange inside a column group relayed over all ranks.
+    How many row pieces a hop is cut into trades exposed transfer time (the last piece's) against per-piece launch and
+    issue cost, and the optimum depends on what the links deliver -- so every count in --grid-pieces is built,
+    validated and timed (untimed setup), and the fastest one is this layout's candidate."""
     from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices, tapered_weights
-    args, K = job.args, job.K
+    K = job.K
     layout = GridLayout(job.world, row_groups)
     rg, cg = layout.coords(job.rank)
     slices = column_slices(job.d, layout.col_groups)
     if job.rp_host is None:
         job.rp_host = job.rowptr.cpu().numpy()
-    # the last piece's transfer is the one nothing can hide: make it half as large as the others
-    pb = all_piece_bounds(job.rp_host, row_groups, args.grid_pieces, tapered_weights(args.grid_pieces))
-    fns, _handles = job.piece_spmms(pb[rg])
     a, b = slices[cg]
     w = b - a
     xs = job.engine_pack(job.x0, a, b)
     widths = [job.engine_pack(job.x0[:1], sa, sb).shape[1] for sa, sb in slices]
-    prop = ShardedPropagator(fns, pb, rg, row_groups, job.n, transport=getattr(job.engine, "relay_transport", "relay"),
-                             layout=layout, me=job.rank, widths=widths)
     bufs = [torch.empty_like(xs) for _ in range(job.nbuf)]
-    ybufs = [torch.empty((prop.hi - prop.lo, xs.shape[1]), dtype=xs.dtype, device=xs.device) for _ in range(K)]
 
-    def step():
-        return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs)     # every buffer preallocated: no allocator traffic
+    def variant(pieces):
+        # the last piece's transfer is the one nothing can hide: make it half as large as the others
+        pb = all_piece_bounds(job.rp_host, row_groups, pieces, tapered_weights(pieces))
+        fns, _handles = job.piece_spmms(pb[rg])
+        prop = ShardedPropagator(fns, pb, rg, row_groups, job.n, transport=getattr(job.engine, "relay_transport", "relay"),
+                                 layout=layout, me=job.rank, widths=widths)
+        ybufs = [torch.empty((prop.hi - prop.lo, xs.shape[1]), dtype=xs.dtype, device=xs.device) for _ in range(K)]
 
-    def check():
-        return ref.close(step()[K][:, :w], prop.lo, prop.hi, a, b)
-    return {"step": step, "check": check, "halves": (prop, [xs], [bufs]),
+        def step():
+            return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs)   # every buffer preallocated: no allocator traffic
+        return prop, step
+
+    counts = [int(t) for t in str(job.args.grid_pieces).split(",") if t.strip()]
+    best, timing = None, {}
+    for pieces in counts:
+        good, made = True, None
+        try:
+            made = variant(pieces)
+            good = bool(ref.close(made[1]()[K][:, :w], made[0].lo, made[0].hi, a, b))
+        except Exception as e:  # noqa: BLE001  (same code on every rank, so an error is too; agree() settles it)
+            good = False
+            sys.stderr.write(f"[bench] grid with {pieces} pieces failed on rank {job.rank}: {e!r}\n")
+        if not job.agree(good):
+            continue
+        timing[pieces] = job.timed_s(made[1], reps=2, warm=0)
+        if best is None or timing[pieces] < timing[best[0]]:
+            best = (pieces,) + made
+    if best is None:
+        raise RuntimeError("no grid variant reproduced the single-GPU result")
+    pieces, prop, step = best
+    job.info["grid_pieces"] = pieces
+    job.info["grid_pieces_candidates_ms"] = {str(k): round(v * 1e3, 3) for k, v in timing.items()}
+    return {"step": step, "check": lambda: ref.close(step()[K][:, :w], prop.lo, prop.hi, a, b), "halves": (prop, [xs], [bufs]),
             "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed over all "
-                        f"{job.world} ranks, {args.grid_pieces} row pieces"}
+                        f"{job.world} ranks, {pieces} row pieces"}
 
 
 def _select_exchange(job, prop, handles, x_chunks, cbufs):

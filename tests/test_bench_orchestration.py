@@ -127,9 +127,11 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
     plan = j["config"]["plan"]
     assert set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
     assert j["n_gpus"] == 4 and j["value"] > 0
+    assert set(plan["grid_pieces_candidates_ms"]) == {"2", "4", "8"} and plan["grid_pieces"] in (2, 4, 8)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "grid", "--grid-pieces", "2")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     assert j["config"]["plan"]["layout"] == "grid" and j["config"]["parallelism"].startswith("grid 2 row blocks x 2 column slices")
+    assert j["config"]["plan"]["grid_pieces"] == 2 and list(j["config"]["plan"]["grid_pieces_candidates_ms"]) == ["2"]
     g = j["config"]["diagnostics"]["grid"]          # only the grid was built: its two halves, no row-sharded entry
     assert g["spmm_only_ms_per_hop_max_rank"] > 0 and g["exchange_only_ms_per_hop_max_rank"] > 0 and g["relay_GBps_per_link"] > 0
     assert "spmm_only_ms_per_hop_max_rank" not in j["config"]["diagnostics"]
