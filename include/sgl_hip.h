@@ -106,6 +106,16 @@ int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
 int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                  int accumulate, void *stream);
 
+/* Split feature layout for widths just above a multiple of 32 floats (d = 100: 96 + 4).  The gather is bound by the
+ * number of 128-byte lines per row; columns [0, d_main) are read from the main matrix (rows 128-byte aligned, d_main a
+ * multiple of 32 floats: exactly d_main/32 lines), the remaining <= 8 columns from a packed side table d_xt
+ * [n_cols, ldxt] (ldxt = 4 or 8 floats: 8 or 4 rows per line).  Y is produced in the same layout: main columns in d_y,
+ * tail columns in d_yt (may be NULL) and, if tail_full != 0, also in columns [d_main, d) of d_y.  Same arithmetic as
+ * sgl_spmm_f32 (one fmaf chain per (row, column) in CSR order).  Pad columns of the tail tables must be zero. */
+int sgl_spmm_tail_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, const float *d_xt, int64_t ldxt, float *d_y,
+                      int64_t ldy, float *d_yt, int64_t ldyt, int64_t d, int64_t d_main, int tail_full, int accumulate,
+                      void *stream);
+
 /* Y_0 = Y_1 = ... = A . X stored into n_out (1..8) matrices with a common leading dimension.  h_y: HOST array of
  * device pointers; entries beyond the first may point into peer GPUs' memory (IPC / symmetric memory): the kernel
  * then pushes each finished row to every replica over xGMI (row-sharded multi-GPU propagation). */
@@ -204,6 +214,14 @@ int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, floa
 /* out[i, :] = X[idx[i], :]   (idx: int64 on device; negative indices are NOT wrapped) */
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);
+
+/* ---- memory-system probes (measurement only: the ceilings bench.py / tools/mem_ceilings.py quote next to the SpMM) ---- */
+/* sequential read of n_floats floats (16 B per lane); nothing is written (d_sink: one float, untouched in practice) */
+int sgl_probe_stream_f32(const float *d_x, int64_t n_floats, float *d_sink, void *stream);
+/* random row gather: every wavefront reads table[idx[i], 0:row_floats] (row_floats % 4 == 0, <= 256) for its share of
+ * the n_idx row ids with `in_flight` (8 / 16 / 32) independent rows per lane; nothing is written */
+int sgl_probe_gather_f32(const float *d_table, int64_t ld, const int32_t *d_idx, int64_t n_idx, int row_floats,
+                         int in_flight, float *d_sink, void *stream);
 
 #ifdef __cplusplus
 }

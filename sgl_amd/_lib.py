@@ -36,6 +36,8 @@ PROTOTYPES = {
     "sgl_csr_destroy": (c_int, [c_void_p]),
     "sgl_csr_info": (c_int, [c_void_p, POINTER(c_int64)]),
     "sgl_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "sgl_spmm_tail_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                  c_int64, c_int64, c_int, c_int, c_void_p]),
     "sgl_spmm_multi_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "sgl_spmm_chain_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_chain_graph_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
@@ -65,6 +67,8 @@ PROTOTYPES = {
                              c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
+    "sgl_probe_stream_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "sgl_probe_gather_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

@@ -28,6 +28,7 @@ static std::map<std::string, int64_t> &tune_map() {
         {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
         {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)
         {"spmm_xcd_remap", 1},   // contiguous row ranges per XCD
+        {"spmm_tail_nt", 0},     // split layout: main-row gathers as separate non-temporal loads
         {"agg_blocks", 0},       // 0 = default cap (2048 blocks) on the grid of the streaming aggregators
         {"nafs_fused", 1},       // 0 = force the two-pass NAFS path
     };

@@ -46,14 +46,17 @@ class ShardedGraphOp:
         from ..io import DeviceAdjacency
         rank, world = self._ranks()
         device = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
-        if not isinstance(adj, DeviceAdjacency):
-            adj = DeviceAdjacency.from_scipy(adj, device=device)
+        from ..operators.base_op import AdjIdentity
+        caller_adj = adj                     # the cache is keyed on the CALLER's object, never on a temporary of ours
         n = adj.shape[0]
         row_groups = world if self.row_groups is None else int(self.row_groups)
         layout = GridLayout(world, row_groups)
         rg, cg = layout.coords(rank)
-        key = (id(adj), adj.col.data_ptr(), adj.nnz, world, rank, row_groups)
-        if self._cache is None or self._cache[0] != key:
+        key = (world, rank, row_groups)
+        if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(caller_adj):
+            if not isinstance(adj, DeviceAdjacency):
+                adj = DeviceAdjacency.from_scipy(adj, device=device)
+            self._cache_ident = AdjIdentity(caller_adj)
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, n, self.r, self.alpha)
             rp_host = rowptr.cpu().numpy()
             pb = all_piece_bounds(rp_host, row_groups, self.pieces)

@@ -13,12 +13,40 @@ from .. import config
 from .. import device as dev
 
 
-def _fingerprint(adj):
-    """cheap identity of a scipy matrix for the normalised-adjacency cache (object, buffers, size, data sample)"""
-    data = adj.data
-    step = max(1, data.size // 1024)
-    return (id(adj), adj.shape, adj.nnz, data.ctypes.data, adj.indices.ctypes.data if hasattr(adj, "indices") else 0,
-            float(np.asarray(data[::step], dtype=np.float64).sum()))
+class AdjIdentity:
+    """Identity of an adjacency for the normalised-adjacency caches: the cache hits only for the SAME object (held by
+    weak reference and compared with `is`, so a recycled id() of a freed temporary can never match) whose contents
+    still look the same -- full hash of the row pointers, strided samples of indices and values, buffer addresses --
+    so in-place edits of a cached matrix are noticed too (up to the sampling of indices / values)."""
+
+    _SAMPLE = 1 << 16
+
+    def __init__(self, adj):
+        import weakref
+        try:
+            self._ref = weakref.ref(adj)
+        except TypeError:
+            self._ref = None
+        self._strong = adj if self._ref is None else None
+        self._print = self.fingerprint(adj)
+
+    @classmethod
+    def fingerprint(cls, adj):
+        import xxhash
+        if hasattr(adj, "indptr"):          # scipy CSR
+            def sample(a):
+                step = max(1, a.size // cls._SAMPLE)
+                return xxhash.xxh64_intdigest(np.ascontiguousarray(a[::step]).tobytes())
+            return ("scipy", adj.shape, int(adj.nnz), adj.indptr.ctypes.data, adj.indices.ctypes.data, adj.data.ctypes.data,
+                    str(adj.data.dtype), xxhash.xxh64_intdigest(np.ascontiguousarray(adj.indptr).tobytes()),
+                    sample(adj.indices), sample(adj.data))
+        # sgl_amd.io.DeviceAdjacency: device buffers; torch bumps _version on every in-place write
+        return ("device", tuple(adj.shape), int(adj.nnz), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr(),
+                adj.rowptr._version, adj.col._version, adj.val._version)
+
+    def matches(self, adj):
+        held = self._ref() if self._ref is not None else self._strong
+        return held is adj and self._print == self.fingerprint(adj)
 
 
 class GraphOp:
@@ -49,21 +77,17 @@ class GraphOp:
         from ..io import DeviceAdjacency
         from .utils import adj_to_symmetric_norm_device
         r, alpha = self._norm_params()
+        params = (r, alpha, bool(self._opt("strict_order")), str(self._opt("device")))
+        if self._opt("cache_adj") and self._adj is not None and self._adj_key is not None:
+            ident, cached_params = self._adj_key
+            if cached_params == params and ident.matches(adj):
+                return self._adj
         if isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
-            key = ("dev", id(adj), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.nnz, r, alpha, bool(self._opt("strict_order")))
-            if self._opt("cache_adj") and key == self._adj_key and self._adj is not None:
-                return self._adj
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, adj.shape[0], r, alpha)
-            self._adj_key = key if self._opt("cache_adj") else None
-            return dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
-        key = None
-        if self._opt("cache_adj"):
-            key = (_fingerprint(adj), r, alpha, bool(self._opt("strict_order")), str(self._opt("device")))
-            if key == self._adj_key and self._adj is not None:
-                return self._adj
-        rowptr, col, val = adj_to_symmetric_norm_device(adj, r, alpha, device=self._opt("device"))
+        else:
+            rowptr, col, val = adj_to_symmetric_norm_device(adj, r, alpha, device=self._opt("device"))
         csr = dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
-        self._adj_key = key
+        self._adj_key = (AdjIdentity(adj), params) if self._opt("cache_adj") else None
         return csr
 
     def propagate(self, adj, feature):
@@ -111,7 +135,6 @@ class GraphOp:
         return prop_feat_list
 
 
-# Might include training parameters
 class MessageOp(nn.Module):
     def __init__(self, start=None, end=None):
         super(MessageOp, self).__init__()

@@ -60,12 +60,50 @@ def main():
     alg = nnz * d * 4 + nnz * 8 + (rows + 1) * 4 + rows * d * 4
     print(f"PAPERS shard: {ms:.2f} ms per hop per rank  = {nnz * d / (ms * 1e-3) / 1e12:.3f}e12 edge*feat/s per GPU, "
           f"{nnz / (ms * 1e-3) / 1e9:.2f} G gathers/s, algorithmic-roofline fraction {alg / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    if os.environ.get("PAPERS_SWEEP", "0") == "1":
+        from sgl_amd import _lib
+        def timed():
+            for _ in range(2):
+                csr.spmm(x, out=y)
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                csr.spmm(x, out=y)
+                e1.record()
+                torch.cuda.synchronize()
+                tt.append(e0.elapsed_time(e1))
+            return float(np.median(tt))
+        for unroll in (1, 3, 2, 4):        # 4 / 8 / 16 / 32 gathers in flight per lane
+            for nt in (0, 1):
+                _lib.set_tuning("spmm_unroll", unroll)
+                _lib.set_tuning("spmm_nt", nt)
+                print(f"PAPERS sweep unroll={unroll} nt={nt} ms={timed():.2f}", flush=True)
+        _lib.set_tuning("spmm_unroll", 0)
+        _lib.set_tuning("spmm_nt", 0)
+        for waves in (1, 2):
+            _lib.set_tuning("spmm_waves", waves)
+            print(f"PAPERS sweep waves={waves} ms={timed():.2f}", flush=True)
+        _lib.set_tuning("spmm_waves", 0)
+        for remap in (0,):
+            _lib.set_tuning("spmm_xcd_remap", remap)
+            print(f"PAPERS sweep xcd_remap={remap} ms={timed():.2f}", flush=True)
+        _lib.set_tuning("spmm_xcd_remap", 1)
+        for item_nnz in (128, 2048):
+            c2 = dev.DeviceCSR(rowptr, col, val, (rows, n_cols), item_nnz=item_nnz)
+            csr_keep, csr = csr, c2
+            print(f"PAPERS sweep item_nnz={item_nnz} ms={timed():.2f}", flush=True)
+            csr = csr_keep
+            del c2
     inbound = (7 / 8) * n_cols * d * 4
     print(f"PAPERS shard: all-gather in-bound per rank per hop {inbound / 1e9:.1f} GB -> >= {inbound / 537e9 * 1e3:.0f} ms at 7 x 76.8 GB/s", flush=True)
     # the other layouts of DESIGN.md section 6 on the same row block: column slices of the replica (16 columns = the
     # feature-sharded layout at 8 ranks, 32 columns = the 2 x 4 grid).  A feature-sharded rank multiplies ALL rows, i.e.
     # 8 blocks like this one, a grid rank 4 of them.
     del x, y
+    if os.environ.get("PAPERS_SWEEP", "0") == "1":
+        return
     for w, blocks, what in ((16, 8, "feature-sharded x8: no communication"),
                             (32, 4, f"grid 2 x 4: {n_cols / 2 * 32 * 4 / 1e9:.1f} GB in-bound per hop, relayed over 7 links")):
         xs = torch.empty((n_cols, w), device=device)
