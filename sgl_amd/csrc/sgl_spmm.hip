@@ -649,8 +649,17 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     if (forced == 8 || forced == 16 || forced == 32 || forced == 64) {
         if (nch == 1 && forced >= lanes) group = (int)forced;
     }
-    // gathers in flight per lane: 16 for the one-row-per-step layout, 8 for the packed ones (0 = this default)
+    // gathers in flight per lane: 16 for the one-row-per-step layout, 8 for the packed ones (0 = this default).  A row's
+    // remainder (nnz mod U) is gathered one dependent load at a time, so short rows want smaller batches: measured
+    // (profiles/r02_flat_*.log) 51 nnz/row: U=16 8.73 ms vs U=8 8.79; 30 nnz/row (papers100M-shaped shard): U=8 37.2 ms
+    // vs U=16 38.1; 6 nnz/row: U=4 11.27 vs U=8 11.36 vs U=16 13.9.  (A walk that batches across row ends was measured
+    // too: within 1 % of this one with the right U, 2-4 % slower for d = 147 and in strict order -- not kept.)
     int ulevel = (group == 64 && nch == 1) ? 2 : 1;
+    if (group == 64 && nch == 1 && h->n_rows > 0) {
+        const double avg = (double)h->nnz / (double)h->n_rows;
+        if (avg < 12.0) ulevel = 0;
+        else if (avg < 40.0) ulevel = 1;
+    }
     const int64_t un = sgl::tuning("spmm_unroll", 0);
     if (un == 1) ulevel = 0;
     if (un == 2) ulevel = 2;

@@ -33,13 +33,15 @@ class AdjIdentity:
     @classmethod
     def fingerprint(cls, adj):
         import xxhash
-        if hasattr(adj, "indptr"):          # scipy CSR
-            def sample(a):
+        if sp.issparse(adj):                # any scipy format (the reference normalises coo / csc input too before it
+            def sample(a):                  # rejects it, base_op.py:20-23)
+                a = np.asarray(a)
                 step = max(1, a.size // cls._SAMPLE)
-                return xxhash.xxh64_intdigest(np.ascontiguousarray(a[::step]).tobytes())
-            return ("scipy", adj.shape, int(adj.nnz), adj.indptr.ctypes.data, adj.indices.ctypes.data, adj.data.ctypes.data,
-                    str(adj.data.dtype), xxhash.xxh64_intdigest(np.ascontiguousarray(adj.indptr).tobytes()),
-                    sample(adj.indices), sample(adj.data))
+                return (a.ctypes.data, a.size, str(a.dtype), xxhash.xxh64_intdigest(np.ascontiguousarray(a[::step]).tobytes()))
+            parts = [sample(getattr(adj, nm)) for nm in ("indices", "data", "row", "col", "offsets") if hasattr(adj, nm)]
+            if hasattr(adj, "indptr"):
+                parts.append(xxhash.xxh64_intdigest(np.ascontiguousarray(adj.indptr).tobytes()))
+            return ("scipy", adj.format, adj.shape, int(adj.nnz), tuple(parts))
         # sgl_amd.io.DeviceAdjacency: device buffers; torch bumps _version on every in-place write
         return ("device", tuple(adj.shape), int(adj.nnz), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr(),
                 adj.rowptr._version, adj.col._version, adj.val._version)

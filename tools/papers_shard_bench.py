@@ -75,13 +75,13 @@ def main():
                 torch.cuda.synchronize()
                 tt.append(e0.elapsed_time(e1))
             return float(np.median(tt))
-        for unroll in (1, 3, 2, 4):        # 4 / 8 / 16 / 32 gathers in flight per lane
-            for nt in (0, 1):
+        for remap in (1, 0):
+            for unroll in (1, 3, 2):        # 4 / 8 / 16 gathers in flight per lane
+                _lib.set_tuning("spmm_xcd_remap", remap)
                 _lib.set_tuning("spmm_unroll", unroll)
-                _lib.set_tuning("spmm_nt", nt)
-                print(f"PAPERS sweep unroll={unroll} nt={nt} ms={timed():.2f}", flush=True)
+                print(f"PAPERS sweep xcd_remap={remap} unroll={unroll} ms={timed():.2f}", flush=True)
         _lib.set_tuning("spmm_unroll", 0)
-        _lib.set_tuning("spmm_nt", 0)
+        _lib.set_tuning("spmm_xcd_remap", 1)
         for waves in (1, 2):
             _lib.set_tuning("spmm_waves", waves)
             print(f"PAPERS sweep waves={waves} ms={timed():.2f}", flush=True)
