@@ -167,6 +167,36 @@ int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int3
                      double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
                      int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream);
 
+/* The two degree powers can be supplied by the caller: sgl_norm_degrees returns the fp64 weighted degrees of A + I
+ * (rows [row0, row0 + n) of a row block; row0 = 0 for a whole matrix), the host evaluates deg^(r-1), deg^(-r) with the
+ * libm the reference's numpy calls (utils.py:79-84, inf -> 0) and sgl_norm_execute_lr uses them: A_hat then rounds to
+ * fp32 bit-identically to the reference (device pow() differs from glibc's in the last bit of a few entries). */
+int sgl_norm_degrees(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                     double *d_deg, void *stream);
+int sgl_norm_execute_lr(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                        const double *d_left, const double *d_right, int use_alpha, double alpha, int64_t nnz_out,
+                        int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream);
+
+/* Row-block normalisation for the row-sharded multi-GPU layout (every GPU holds only ITS rows of A_hat).
+ * Input: rows [row0, row0 + n) of T = A^T (for a symmetric A: of A itself) as CSR with GLOBAL, sorted column ids.
+ *   1. sgl_norm_block_prepare -> *nnz_out = nnz + number of local rows without a diagonal entry (synchronises)
+ *   2. sgl_norm_block_build   -> T' = T + I for the block (CSR, fp64 values) and its fp64 row sums
+ *   3. deg = rowsum(A + I): for a symmetric A the blocks' row sums (all-gather); otherwise the column sums of T'
+ *      (sgl_norm_block_colsum accumulates a block's share into a zeroed [n_cols] vector; all-reduce over the ranks)
+ *   4. sgl_norm_block_scale   -> A_hat[j, i] = (T'[j, i] * L[j]) * R[i]  [then (1-alpha) A_hat + alpha I], rounded to fp32;
+ *      d_left_local = deg^(r-1) of the block's rows, d_right_global = deg^(-r) of ALL n_cols nodes.
+ * Same arithmetic and rounding as sgl_norm_execute; none of it needs the other ranks' rows. */
+int sgl_norm_block_prepare(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                           int64_t *nnz_out, void *stream);
+int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                         const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
+                         double *d_out_val64, double *d_rowsum, void *stream);
+int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, const double *d_val64, double *d_colsum,
+                          void *stream);
+int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_val64,
+                         const double *d_left_local, const double *d_right_global, int use_alpha, double alpha,
+                         float *d_out_val, double *d_out_val64, void *stream);
+
 /* ---- ingest: COO edge list -> canonical CSR on device (sgl/data/base_data.py:29, dataset/custom_dataset.py:52-54) ---- */
 /* d_row / d_col: int64 [nnz] (the reference keeps them as torch.LongTensor), d_val float32 [nnz].  Duplicate (row,col)
  * pairs are summed in input order (fp32), columns come out sorted inside each row -- what scipy's

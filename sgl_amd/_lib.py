@@ -50,6 +50,15 @@ PROTOTYPES = {
     "sgl_norm_prepare": (c_int, [c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
     "sgl_norm_execute": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_degrees": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_execute_lr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_block_prepare": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
+    "sgl_norm_block_build": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_block_colsum": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_block_scale": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
+                                     c_void_p, c_void_p, c_void_p]),
     "sgl_coo_to_csr": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(c_int64), c_void_p]),
     "sgl_hop_reduce_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,

@@ -133,6 +133,130 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t *__restric
     if (out_val64) out_val64[q] = v;
 }
 
+// weighted degrees of A + I only (same summation order as build_aprime_kernel): lets the host evaluate the two degree
+// powers with the very libm the reference's numpy calls, so the rounded A_hat is bit-identical to scipy's
+__global__ __launch_bounds__(256) void degrees_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const float *__restrict__ val, int64_t n, int64_t row0,
+                                                      double *__restrict__ deg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t me = (int32_t)(row0 + i);
+    double s = 0.0;
+    bool placed = false;
+    for (int64_t p = rowptr[i], e = rowptr[i + 1]; p < e; ++p) {
+        const int32_t c = col[p];
+        double v = (double)val[p];
+        if (!placed && c >= me) {
+            placed = true;
+            if (c == me) v += 1.0;
+            else s += 1.0;
+        }
+        s += v;
+    }
+    if (!placed) s += 1.0;
+    deg[i] = s;
+}
+
+// ---- row-block normalisation (multi-GPU: every rank owns rows [row0, row0 + n) of A_hat) ---------------------------------
+// rows of T' = T + I for a block of rows of T (global column ids), as CSR with the diagonal merged / inserted in sorted
+// position; fp64 values; row sums
+__global__ __launch_bounds__(256) void block_build_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const float *__restrict__ val, const int64_t *__restrict__ shift,
+                                                          int64_t n, int64_t row0, int64_t *__restrict__ o_rowptr,
+                                                          int32_t *__restrict__ o_col, double *__restrict__ o_val,
+                                                          double *__restrict__ rowsum) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        o_rowptr[n] = rowptr[n] + shift[n];
+        return;
+    }
+    const int32_t me = (int32_t)(row0 + i);
+    const int64_t b = rowptr[i], e = rowptr[i + 1];
+    int64_t o = b + shift[i];
+    o_rowptr[i] = o;
+    double s = 0.0;
+    bool placed = false;
+    for (int64_t p = b; p < e; ++p) {
+        const int32_t c = col[p];
+        double v = (double)val[p];
+        if (!placed && c >= me) {
+            placed = true;
+            if (c == me) {
+                v += 1.0;
+            } else {
+                o_col[o] = me;
+                o_val[o] = 1.0;
+                s += 1.0;
+                ++o;
+            }
+        }
+        o_col[o] = c;
+        o_val[o] = v;
+        s += v;
+        ++o;
+    }
+    if (!placed) {
+        o_col[o] = me;
+        o_val[o] = 1.0;
+        s += 1.0;
+    }
+    rowsum[i] = s;
+}
+
+__global__ __launch_bounds__(256) void block_diag_missing_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                 int64_t n, int64_t row0, int64_t *__restrict__ miss,
+                                                                 unsigned long long *total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int m = 0;
+    if (i < n) {
+        const int32_t me = (int32_t)(row0 + i);
+        int64_t lo = rowptr[i], hi = rowptr[i + 1];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < me) lo = mid + 1; else hi = mid;
+        }
+        m = !(lo < rowptr[i + 1] && col[lo] == me);
+        miss[i] = m;
+    } else if (i == n) {
+        miss[i] = 0;
+    }
+    if (total) {
+        const unsigned long long b = __ballot(m != 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(total, (unsigned long long)__popcll(b));
+    }
+}
+
+// column sums of a CSR block (fp64 atomics: exact, hence order-independent, for integer weights; otherwise equal up to
+// the last bit of the fp64 sums)
+__global__ __launch_bounds__(256) void block_colsum_kernel(const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                           int64_t m, double *__restrict__ colsum) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < m) atomicAdd(colsum + col[p], val[p]);
+}
+
+// A_hat[j, i] = (T'[j, i] * L[j]) * R[i]  (+ PPR mix), rounded to fp32 where the reference rounds
+__global__ __launch_bounds__(256) void block_scale_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const double *__restrict__ val, const double *__restrict__ left_local,
+                                                          const double *__restrict__ right_global, int64_t n, int64_t row0,
+                                                          int use_alpha, double one_minus_alpha, double alpha,
+                                                          float *__restrict__ o_val, double *__restrict__ o_val64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double l = left_local[i];
+    const int32_t me = (int32_t)(row0 + i);
+    for (int64_t p = rowptr[i], e = rowptr[i + 1]; p < e; ++p) {
+        const int32_t c = col[p];
+        double v = __dmul_rn(__dmul_rn(val[p], l), right_global[c]);
+        if (use_alpha) {
+            v = __dmul_rn(one_minus_alpha, v);
+            if (c == me) v = __dadd_rn(v, alpha);
+        }
+        o_val[p] = (float)v;
+        if (o_val64) o_val64[p] = v;
+    }
+}
+
 struct Tmp {
     std::vector<void *> ptrs;
     ~Tmp() {
@@ -179,9 +303,10 @@ SGL_EXPORT int sgl_norm_prepare(int64_t n, int64_t nnz, const int64_t *d_rowptr,
     return SGL_OK;
 }
 
-SGL_EXPORT int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
-                                double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
-                                int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream) {
+static int norm_execute_impl(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                             double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
+                             int32_t *d_out_col, float *d_out_val, double *d_out_val64, const double *d_left_in,
+                             const double *d_right_in, void *stream) {
     SGL_REQUIRE(n >= 0 && nnz >= 0 && n < INT32_MAX, "sgl_norm_execute: bad sizes");
     SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_execute: nnz_out inconsistent (call sgl_norm_prepare)");
     SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX, "sgl_norm_execute: nnz_out >= 2^32 not supported on one device");
@@ -226,9 +351,14 @@ SGL_EXPORT int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr,
     hipLaunchKernelGGL(build_aprime_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d_rowptr, d_col, d_val, shift, n, t_key,
                        t_row, a64, deg);
     SGL_HIP_CHECK(hipGetLastError());
-    // 3. deg^(r-1), deg^(-r)
-    hipLaunchKernelGGL(degree_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, st, deg, n, r, left, right);
-    SGL_HIP_CHECK(hipGetLastError());
+    // 3. deg^(r-1), deg^(-r): on device, or supplied by the caller (host libm: bit-identical to the reference's numpy)
+    if (d_left_in && d_right_in) {
+        left = const_cast<double *>(d_left_in);
+        right = const_cast<double *>(d_right_in);
+    } else {
+        hipLaunchKernelGGL(degree_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, st, deg, n, r, left, right);
+        SGL_HIP_CHECK(hipGetLastError());
+    }
     // 4. values of the transposed, scaled matrix (still in A' order) + identity permutation
     hipLaunchKernelGGL(scale_values_kernel, dim3(blocks_for(m)), dim3(256), 0, st, t_key, t_row, left, right, m, a64, iota);
     SGL_HIP_CHECK(hipGetLastError());
@@ -249,5 +379,113 @@ SGL_EXPORT int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr,
                        1.0 - alpha, alpha, d_out_col, d_out_val, d_out_val64);
     SGL_HIP_CHECK(hipGetLastError());
     SGL_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are freed on return
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_execute(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                                double r, int use_alpha, double alpha, int64_t nnz_out, int64_t *d_out_rowptr,
+                                int32_t *d_out_col, float *d_out_val, double *d_out_val64, void *stream) {
+    return norm_execute_impl(n, nnz, d_rowptr, d_col, d_val, r, use_alpha, alpha, nnz_out, d_out_rowptr, d_out_col, d_out_val,
+                             d_out_val64, nullptr, nullptr, stream);
+}
+
+SGL_EXPORT int sgl_norm_execute_lr(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                                   const double *d_left, const double *d_right, int use_alpha, double alpha, int64_t nnz_out,
+                                   int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val, double *d_out_val64,
+                                   void *stream) {
+    SGL_REQUIRE(d_left && d_right, "sgl_norm_execute_lr: NULL degree powers");
+    return norm_execute_impl(n, nnz, d_rowptr, d_col, d_val, 0.0, use_alpha, alpha, nnz_out, d_out_rowptr, d_out_col, d_out_val,
+                             d_out_val64, d_left, d_right, stream);
+}
+
+SGL_EXPORT int sgl_norm_degrees(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                                double *d_deg, void *stream) {
+    SGL_REQUIRE(n >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_degrees: bad sizes");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_rowptr && d_deg, "sgl_norm_degrees: NULL arrays");
+    hipLaunchKernelGGL(degrees_kernel, dim3(blocks_for(n)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_val, n, row0,
+                       d_deg);
+    SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+// ---- row-block normalisation ---------------------------------------------------------------------------------------------
+SGL_EXPORT int sgl_norm_block_prepare(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                                      int64_t *nnz_out, void *stream) {
+    SGL_REQUIRE(nnz_out != nullptr, "sgl_norm_block_prepare: NULL nnz_out");
+    SGL_REQUIRE(n >= 0 && nnz >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_prepare: bad sizes");
+    if (n == 0) {
+        *nnz_out = 0;
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_rowptr && (nnz == 0 || d_col), "sgl_norm_block_prepare: NULL arrays");
+    hipStream_t st = sgl::as_stream(stream);
+    Tmp tmp;
+    int64_t *miss = nullptr;
+    unsigned long long *total = nullptr;
+    int rc;
+    if ((rc = tmp.alloc(&miss, (size_t)n + 1)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&total, 1)) != SGL_OK) return rc;
+    SGL_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(block_diag_missing_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, n, row0, miss, total);
+    SGL_HIP_CHECK(hipGetLastError());
+    unsigned long long h_total = 0;
+    SGL_HIP_CHECK(hipMemcpyAsync(&h_total, total, sizeof(h_total), hipMemcpyDeviceToHost, st));
+    SGL_HIP_CHECK(hipStreamSynchronize(st));
+    *nnz_out = nnz + (int64_t)h_total;
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                                    const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
+                                    double *d_out_val64, double *d_rowsum, void *stream) {
+    SGL_REQUIRE(n >= 0 && nnz >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_build: bad sizes");
+    SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_block_build: nnz_out inconsistent (call sgl_norm_block_prepare)");
+    SGL_REQUIRE(d_out_rowptr != nullptr, "sgl_norm_block_build: NULL output row pointers");
+    hipStream_t st = sgl::as_stream(stream);
+    if (n == 0) {
+        SGL_HIP_CHECK(hipMemsetAsync(d_out_rowptr, 0, sizeof(int64_t), st));
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_rowptr && (nnz == 0 || (d_col && d_val)) && d_out_col && d_out_val64 && d_rowsum, "sgl_norm_block_build: NULL arrays");
+    Tmp tmp;
+    int rc;
+    int64_t *miss = nullptr, *shift = nullptr;
+    if ((rc = tmp.alloc(&miss, (size_t)n + 1)) != SGL_OK) return rc;
+    if ((rc = tmp.alloc(&shift, (size_t)n + 1)) != SGL_OK) return rc;
+    hipLaunchKernelGGL(block_diag_missing_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, n, row0, miss,
+                       (unsigned long long *)nullptr);
+    SGL_HIP_CHECK(hipGetLastError());
+    size_t bytes = 0;
+    SGL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, miss, shift, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+    char *scratch = nullptr;
+    if ((rc = tmp.alloc(&scratch, bytes)) != SGL_OK) return rc;
+    SGL_HIP_CHECK(rocprim::exclusive_scan(scratch, bytes, miss, shift, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+    hipLaunchKernelGGL(block_build_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, d_val, shift, n, row0,
+                       d_out_rowptr, d_out_col, d_out_val64, d_rowsum);
+    SGL_HIP_CHECK(hipGetLastError());
+    SGL_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are freed on return
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, const double *d_val64, double *d_colsum,
+                                     void *stream) {
+    SGL_REQUIRE(n_cols >= 0 && nnz >= 0, "sgl_norm_block_colsum: bad sizes");
+    if (nnz == 0) return SGL_OK;
+    SGL_REQUIRE(d_col && d_val64 && d_colsum, "sgl_norm_block_colsum: NULL arrays");
+    hipLaunchKernelGGL(block_colsum_kernel, dim3(blocks_for(nnz)), dim3(256), 0, sgl::as_stream(stream), d_col, d_val64, nnz, d_colsum);
+    SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_val64,
+                                    const double *d_left_local, const double *d_right_global, int use_alpha, double alpha,
+                                    float *d_out_val, double *d_out_val64, void *stream) {
+    SGL_REQUIRE(n >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_scale: bad sizes");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_rowptr && d_col && d_val64 && d_left_local && d_right_global && d_out_val, "sgl_norm_block_scale: NULL arrays");
+    hipLaunchKernelGGL(block_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_val64,
+                       d_left_local, d_right_global, n, row0, use_alpha, 1.0 - alpha, alpha, d_out_val, d_out_val64);
+    SGL_HIP_CHECK(hipGetLastError());
     return SGL_OK;
 }

@@ -645,8 +645,12 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         group = 8;
         while (group < lanes) group <<= 1;
     }
+    if (eh.xt) {   // split layout: always the one-row-per-step lane layout
+        group = 64;
+        nch = 1;
+    }
     const int64_t forced = sgl::tuning("spmm_group", 0);
-    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) {
+    if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && !eh.xt) {
         if (nch == 1 && forced >= lanes) group = (int)forced;
     }
     // gathers in flight per lane: 16 for the one-row-per-step layout, 8 for the packed ones (0 = this default).  A row's

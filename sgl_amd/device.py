@@ -13,6 +13,7 @@ from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
+    "normalize_block", "degree_powers",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
 ]
 
@@ -288,9 +289,24 @@ class ChainGraph:
             pass
 
 
-def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False):
+def degree_powers(deg, r):
+    """deg^(r-1), deg^(-r) with inf -> 0, evaluated on the HOST by numpy exactly as the reference does
+    (operators/utils.py:79-84): the same libm, hence bit-identical degree factors.  deg: fp64 tensor (any device);
+    returns two fp64 CPU tensors."""
+    d = deg.detach().cpu().numpy().astype(np.float64, copy=False)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        left = np.power(d, r - 1)
+        left[np.isinf(left)] = 0.
+        right = np.power(d, -r)
+        right[np.isinf(right)] = 0.
+    return torch.from_numpy(left), torch.from_numpy(right)
+
+
+def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_pow=True):
     """Device adj_to_symmetric_norm (+ optional PPR mix): canonical CSR of A on device -> CSR of A_hat.
-    rowptr int64 [n+1], col int32, val float32 (CUDA).  Returns (rowptr, col, val[, val64])."""
+    rowptr int64 [n+1], col int32, val float32 (CUDA).  Returns (rowptr, col, val[, val64]).
+    host_pow: the two degree powers (n values) are evaluated by the host's numpy like the reference's, everything per
+    non-zero stays on the GPU; the rounded A_hat is then bit-identical to scipy's."""
     _lib.require_gpu()
     nnz = int(col.numel())
     dev = rowptr.device
@@ -303,9 +319,72 @@ def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False):
         o_col = torch.empty(m, dtype=torch.int32, device=dev)
         o_val = torch.empty(m, dtype=torch.float32, device=dev)
         o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
-        check(lib().sgl_norm_execute(n, nnz, ptr(rowptr), ptr(col), ptr(val), float(r), int(alpha is not None),
-                                     float(alpha if alpha is not None else 0.0), m, ptr(o_ptr), ptr(o_col), ptr(o_val),
-                                     ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_execute")
+        if host_pow:
+            deg = torch.empty(n, dtype=torch.float64, device=dev)
+            check(lib().sgl_norm_degrees(n, 0, ptr(rowptr), ptr(col), ptr(val), ptr(deg), current_stream_ptr()),
+                  "sgl_norm_degrees")
+            left, right = (t.to(dev) for t in degree_powers(deg, r))
+            check(lib().sgl_norm_execute_lr(n, nnz, ptr(rowptr), ptr(col), ptr(val), ptr(left), ptr(right),
+                                            int(alpha is not None), float(alpha if alpha is not None else 0.0), m,
+                                            ptr(o_ptr), ptr(o_col), ptr(o_val), ptr(o_v64) if return_fp64 else None,
+                                            current_stream_ptr()), "sgl_norm_execute_lr")
+        else:
+            check(lib().sgl_norm_execute(n, nnz, ptr(rowptr), ptr(col), ptr(val), float(r), int(alpha is not None),
+                                         float(alpha if alpha is not None else 0.0), m, ptr(o_ptr), ptr(o_col), ptr(o_val),
+                                         ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_execute")
+    return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
+
+
+def normalize_block(rowptr, col, val, row0, n_cols, r, alpha=None, symmetric=True, group=None, return_fp64=False, deg=None):
+    """Rows [row0, row0 + n_local) of A_hat from the same rows of T = A^T (symmetric=True: of A itself), each rank of a
+    row-sharded job on its own block (sgl_norm_block_*).  The only communication is the degree vector: an all-gather of
+    the blocks' row sums when A is symmetric, an all-reduce of the column sums otherwise.  Without an initialised
+    process group (or world size 1) the block must be the whole matrix.  Returns (rowptr, col, val[, val64]) of the block
+    (local row pointers, global column ids).  `deg` (fp64 [n_cols], any device): the global degree vector of A + I if
+    the caller already has it -- then nothing is communicated at all."""
+    import torch.distributed as dist
+    _lib.require_gpu()
+    dev = rowptr.device
+    n_loc = int(rowptr.numel()) - 1
+    nnz = int(col.numel())
+    nnz_out = c_int64(0)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    with torch.cuda.device(dev):
+        check(lib().sgl_norm_block_prepare(n_loc, row0, nnz, ptr(rowptr), ptr(col), ctypes.byref(nnz_out),
+                                           current_stream_ptr()), "sgl_norm_block_prepare")
+        m = nnz_out.value
+        o_ptr = torch.empty(n_loc + 1, dtype=torch.int64, device=dev)
+        o_col = torch.empty(m, dtype=torch.int32, device=dev)
+        t64 = torch.empty(m, dtype=torch.float64, device=dev)
+        rowsum = torch.empty(n_loc, dtype=torch.float64, device=dev)
+        check(lib().sgl_norm_block_build(n_loc, row0, nnz, ptr(rowptr), ptr(col), ptr(val), m, ptr(o_ptr), ptr(o_col),
+                                         ptr(t64), ptr(rowsum), current_stream_ptr()), "sgl_norm_block_build")
+        if deg is not None:
+            if deg.numel() != n_cols:
+                raise ValueError("deg must hold one entry per column")
+        elif symmetric:
+            if multi:
+                deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
+                deg[row0:row0 + n_loc] = rowsum
+                dist.all_reduce(deg, group=group)      # blocks are disjoint: the sum IS the concatenation (exact)
+            else:
+                if n_loc != n_cols or row0 != 0:
+                    raise ValueError("a single process must hold the whole matrix")
+                deg = rowsum
+        else:
+            deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
+            check(lib().sgl_norm_block_colsum(n_cols, m, ptr(o_col), ptr(t64), ptr(deg), current_stream_ptr()),
+                  "sgl_norm_block_colsum")
+            if multi:
+                dist.all_reduce(deg, group=group)
+        left, right = degree_powers(deg, r)
+        left_loc = left[row0:row0 + n_loc].contiguous().to(dev)
+        right = right.to(dev)
+        o_val = torch.empty(m, dtype=torch.float32, device=dev)
+        o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
+        check(lib().sgl_norm_block_scale(n_loc, row0, ptr(o_ptr), ptr(o_col), ptr(t64), ptr(left_loc), ptr(right),
+                                         int(alpha is not None), float(alpha if alpha is not None else 0.0), ptr(o_val),
+                                         ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_scale")
     return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
 
 

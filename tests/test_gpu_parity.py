@@ -13,6 +13,8 @@ import torch
 
 import oracle
 from inputs import hash_matrix
+from sgl_amd import _lib
+from sgl_amd import device as dev
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +125,52 @@ def test_spmm_long_rows_empty_rows_and_splitting(cuda, strict):
             # deterministic: same bits on a second run (no float atomics)
             y2 = csr.spmm(torch.from_numpy(x).to(cuda)).cpu().numpy()
             assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("d", [100, 98, 132, 40, 36, 225])
+def test_spmm_split_layout_is_bit_exact(cuda, d):
+    """sgl_spmm_tail_f32 (main block of whole cache lines + packed tail table) = the same fmaf chains as the plain layout:
+    bit-exact vs the oracle in strict order, incl. empty rows, and equal to the plain kernel when long rows are split."""
+    a = long_row_graph()
+    n = a.shape[0]
+    dm = d // 32 * 32
+    tw = (d - dm + 3) // 4 * 4
+    x = hash_matrix(n, d, seed=d)
+    ref = oracle.oracle_spmm(a.indptr, a.indices, a.data, x)
+    xm = torch.zeros((n, dm), device=cuda)
+    xm.copy_(torch.from_numpy(np.ascontiguousarray(x[:, :dm])))
+    xt = torch.zeros((n, tw), device=cuda)
+    xt[:, :d - dm] = torch.from_numpy(np.ascontiguousarray(x[:, dm:])).to(cuda)
+    # narrow matrices (d <= 64) pack several non-zeros per step in the plain fast layout (another summation order), so
+    # there the comparison with the plain kernel is made in strict order only
+    for strict, long_nnz in (((True, 0), (False, 256), (False, 100)) if d > 64 else ((True, 0),)):
+        csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, item_nnz=64, long_row_nnz=long_nnz)
+        plain = csr.spmm(torch.from_numpy(x).to(cuda))
+        # (a) split output: main [n, dm] + tail [n, tw]
+        ym = torch.full((n, dm), 7.0, device=cuda)
+        yt = torch.full((n, tw), 7.0, device=cuda)
+        csr.spmm_tail(xm, xt, ym, yt, d, dm)
+        got = torch.cat([ym, yt[:, :d - dm]], dim=1)
+        assert torch.equal(got, plain), (d, strict, long_nnz)
+        if strict:
+            assert np.array_equal(got.cpu().numpy(), ref)
+        assert not yt[:, d - dm:].any()                      # pad columns of the tail table stay zero
+        # (b) full rows at a line pitch (ordinary [n, d] view) + tail table, then a second hop from that layout
+        pitch = (dm + tw + 31) // 32 * 32
+        yp = torch.zeros((n, pitch), device=cuda)
+        csr.spmm_tail(xm, xt, yp, yt, d, dm, tail_full=True)
+        assert torch.equal(yp[:, :d], plain)
+        y2 = torch.zeros((n, pitch), device=cuda)
+        yt2 = torch.zeros_like(yt)
+        csr.spmm_tail(yp, yt, y2, yt2, d, dm, tail_full=True)
+        assert torch.equal(y2[:, :d], csr.spmm(plain.contiguous()))
+        # (c) accumulate into the split output
+        csr.spmm_tail(xm, xt, ym, yt, d, dm, accumulate=True)
+        acc = plain.clone()
+        csr.spmm(torch.from_numpy(x).to(cuda), out=acc, accumulate=True)
+        assert torch.equal(torch.cat([ym, yt[:, :d - dm]], dim=1), acc)
+    with pytest.raises(_lib.SglHipError):
+        csr.spmm_tail(xm, xt, ym, yt, d + 32, dm)           # more than 8 tail columns
 
 
 def test_spmm_accumulate_and_overwrite_semantics(goldens, cuda):
@@ -355,7 +403,7 @@ G1_VARIANTS = [("lap", r, None) for r in (0.0, 0.3, 0.5, 1.0)] + \
 
 @pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
 def test_device_normalisation_matches_reference_goldens(goldens, cuda, gname):
-    from sgl_amd.operators.utils import adj_to_symmetric_norm_device
+    from sgl_amd.operators.utils import adj_to_symmetric_norm_device, canonical_csr
     g = goldens.graph(gname)
     g1 = goldens.npz("g1_norm")
     worst, n_diff32, total = 0.0, 0, 0
@@ -373,7 +421,52 @@ def test_device_normalisation_matches_reference_goldens(goldens, cuda, gname):
         n_diff32 += int(d32.sum())
         total += d32.size
         assert np.allclose(v32.cpu().numpy(), ref.astype(np.float32), rtol=1.2e-7, atol=0), key   # <= 1 ulp(fp32)
+        # device pow() for the degree factors (host_pow=False) stays within 1 ulp(fp32) of the reference
+        gc = canonical_csr(g)
+        _, _, v32_dev = dev.normalize_adj(*[t.to(cuda) for t in (torch.from_numpy(gc.indptr.astype(np.int64)),
+                                                                 torch.from_numpy(gc.indices.astype(np.int32)),
+                                                                 torch.from_numpy(gc.data.astype(np.float32)))],
+                                          g.shape[0], r, a, host_pow=False)
+        assert np.allclose(v32_dev.cpu().numpy(), ref.astype(np.float32), rtol=1.2e-7, atol=0), key
     print(f"{gname}: worst fp64 rel err {worst:.2e}; fp32-rounded values differing: {n_diff32}/{total}")
+    # the degree powers come from the host's libm like the reference's: the rounded A_hat is bit-identical to scipy's
+    assert n_diff32 == 0, (gname, n_diff32, total)
+
+
+@pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
+def test_row_block_normalisation_matches_full(goldens, cuda, gname):
+    """sgl_norm_block_*: every rank of a row-sharded job normalises only ITS rows; the blocks laid end to end are
+    bit-identical to the single-GPU normalisation (and hence to the reference goldens)."""
+    from sgl_amd.operators.utils import canonical_csr
+    g = canonical_csr(goldens.graph(gname))
+    n = g.shape[0]
+    symmetric = gname != "dir40"
+    t = g if symmetric else sp.csr_matrix(g.T)            # rows of A^T are what a rank holds for a directed graph
+    t.sort_indices()
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(cuda)  # noqa: E731
+    for kind, r, a in G1_VARIANTS:
+        gp, gc, gv = to(g.indptr, np.int64), to(g.indices, np.int32), to(g.data, np.float32)
+        fptr, fcol, fval, f64 = dev.normalize_adj(gp, gc, gv, n, r, a, return_fp64=True)
+        deg = torch.empty(n, dtype=torch.float64, device=cuda)
+        _lib.check(_lib.lib().sgl_norm_degrees(n, 0, _lib.ptr(gp), _lib.ptr(gc), _lib.ptr(gv), _lib.ptr(deg),
+                                               _lib.current_stream_ptr()))
+        torch.cuda.synchronize()
+        for bounds in ([0, n], [0, n // 3, n // 3, n - 5, n]):     # one block; three blocks incl. an EMPTY one
+            ptrs, cols, vals, v64s = [], [], [], []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                rp = t.indptr[lo:hi + 1].astype(np.int64) - int(t.indptr[lo])
+                cc = t.indices[t.indptr[lo]:t.indptr[hi]]
+                vv = t.data[t.indptr[lo]:t.indptr[hi]]
+                bp, bc, bv, b64 = dev.normalize_block(to(rp, np.int64), to(cc, np.int32), to(vv, np.float32), lo, n, r, a,
+                                                      symmetric=symmetric, return_fp64=True,
+                                                      deg=deg if len(bounds) > 2 else None)
+                ptrs.append(bp.cpu().numpy()); cols.append(bc.cpu().numpy()); vals.append(bv.cpu().numpy()); v64s.append(b64.cpu().numpy())
+            offs = np.concatenate([[0], np.cumsum([p[-1] for p in ptrs])])
+            full_ptr = np.concatenate([p[:-1] + o for p, o in zip(ptrs, offs[:-1])] + [offs[-1:]])
+            assert np.array_equal(full_ptr, fptr.cpu().numpy()), (gname, kind, r, a)
+            assert np.array_equal(np.concatenate(cols), fcol.cpu().numpy())
+            assert np.array_equal(np.concatenate(v64s), f64.cpu().numpy())      # same operations in the same order
+            assert np.array_equal(np.concatenate(vals), fval.cpu().numpy())
 
 
 def test_adj_to_symmetric_norm_scipy_contract(goldens, cuda):
@@ -412,7 +505,7 @@ def test_propagate_matches_reference_goldens(goldens, cuda):
             sums = np.array([f.double().sum().item() for f in hops])
             assert np.allclose(sums, g2[f"{key}|sums"], rtol=1e-4, atol=1e-3), key
     print(f"propagate strict mode: {n_exact}/{n_total} golden hop matrices reproduced bit-for-bit")
-    assert n_exact >= 0.9 * n_total   # device A_hat may differ from scipy's by 1 ulp(fp32) in rare entries
+    assert n_exact == n_total        # A_hat is bit-identical to scipy's (degree powers from the host's libm), the chain too
 
 
 def test_propagate_host_output_and_input_types(goldens, cuda):
