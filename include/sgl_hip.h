@@ -253,6 +253,19 @@ int sgl_probe_stream_f32(const float *d_x, int64_t n_floats, float *d_sink, void
 int sgl_probe_gather_f32(const float *d_table, int64_t ld, const int32_t *d_idx, int64_t n_idx, int row_floats,
                          int in_flight, float *d_sink, void *stream);
 
+/* ---- seeded synthetic inputs generated in HBM, keyed by (seed, row) (measurement / tests: SURVEY 8(d) workloads S3, S4) ---- */
+/* Every rank builds its own row block [row0, row0 + n_rows) of an ogbn-papers100M-shaped directed graph and of the feature
+ * matrix; integer hash arithmetic only, mirrored bit-for-bit on the host by sgl_amd/synthetic.py.
+ *   degrees : d_deg[i] = d_table8192[...]: 4096 quantiles of the degree law + 4096 more refining the top bucket (the extreme
+ *             tail), int32, on device; the index comes from hash(seed, row)
+ *   fill    : non-zero j of row i gets a hub-skewed, permuted column id in [0, n_cols) and a value in [0, 1/32)
+ *             (d_rowptr: LOCAL row pointers of the block, i.e. the exclusive scan of the degrees)
+ *   features: X[i, k] in [-1, 1) for k < d, 0 for d <= k < ld */
+int sgl_synth_degrees(uint64_t seed, int64_t row0, int64_t n_rows, const int32_t *d_table8192, int64_t *d_deg, void *stream);
+int sgl_synth_fill(uint64_t seed, int64_t row0, int64_t n_rows, int64_t n_cols, const int64_t *d_rowptr, int32_t *d_col,
+                   float *d_val, void *stream);
+int sgl_synth_features(uint64_t seed, int64_t row0, int64_t n_rows, int64_t d, int64_t ld, float *d_x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ the library binds to (SONAME libamdhip64.so.7) is the one torch already loaded -
 pointers from torch tensors are then valid inside the library."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must precede the CDLL: shares torch's HIP runtime)
 
@@ -76,6 +76,9 @@ PROTOTYPES = {
                              c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
+    "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sgl_synth_fill": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_synth_features": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sgl_probe_stream_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sgl_probe_gather_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
 }

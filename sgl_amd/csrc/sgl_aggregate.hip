@@ -576,6 +576,7 @@ SGL_EXPORT int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int
     if (rc != SGL_OK) return rc;
     if (n == 0) return SGL_OK;
     SGL_REQUIRE(d_vec && d_out && ldo >= n_hops, "sgl_hop_rowdot_f32: bad arguments");
+    if (!sgl::launch_fits((n + 3) / 4, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_rowdot_f32: too many rows for one launch (shard the matrix)");
     hipStream_t st = sgl::as_stream(stream);
     if (d == 0) {
         SGL_HIP_CHECK(hipMemset2DAsync(d_out, ldo * sizeof(float), 0, n_hops * sizeof(float), n, st));
@@ -648,6 +649,7 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     hipStream_t st = sgl::as_stream(stream);
     const int lpr = pick_lpr(d, vec4 ? 4 : 1);
     const int64_t blocks = (n + (256 / lpr) - 1) / (256 / lpr);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "row-wise kernel: too many rows for one launch (shard the matrix)");
     SGL_REQUIRE(blocks < INT32_MAX, "sgl_nafs_f32: too many rows");
     // single-pass kernel: the H hop rows of a node fit in registers (H <= 16, d <= 512, 16-byte lanes)
     const bool out_vec4 = d_out && (ldo % 4 == 0) && aligned_to(d_out, 16);
@@ -704,6 +706,7 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
     hipStream_t st = sgl::as_stream(stream);
     const int lpr = pick_lpr(d, vec4 ? 4 : 1);
     const int64_t blocks = (n_idx + (256 / lpr) - 1) / (256 / lpr);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_gather_rows_f32: too many indices for one launch");
     SGL_REQUIRE(blocks < INT32_MAX, "sgl_gather_rows_f32: too many rows");
 #define SGL_GR(L, V) \
     hipLaunchKernelGGL((gather_rows_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, n_idx, d_out, ldo, (int)d)

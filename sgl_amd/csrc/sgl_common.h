@@ -70,6 +70,12 @@ int64_t tuning(const char *key, int64_t dflt);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A HIP launch carries at most 2^32 - 1 threads per grid dimension; beyond that the launch is silently truncated on this
+// stack (found the hard way at papers100M size).  One-thread-per-element launchers check this, the rest stride.
+inline bool launch_fits(int64_t blocks, int64_t threads_per_block) {
+    return blocks >= 0 && blocks * threads_per_block < ((int64_t)1 << 32) && blocks < (int64_t)INT32_MAX;
+}
+
 }  // namespace sgl
 
 struct sgl_plan {

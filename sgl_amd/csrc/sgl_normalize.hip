@@ -441,6 +441,7 @@ SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const 
                                     double *d_out_val64, double *d_rowsum, void *stream) {
     SGL_REQUIRE(n >= 0 && nnz >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_build: bad sizes");
     SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_block_build: nnz_out inconsistent (call sgl_norm_block_prepare)");
+    SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX, "sgl_norm_block_build: nnz >= 2^32 per block not supported (use more row blocks)");
     SGL_REQUIRE(d_out_rowptr != nullptr, "sgl_norm_block_build: NULL output row pointers");
     hipStream_t st = sgl::as_stream(stream);
     if (n == 0) {
@@ -470,7 +471,7 @@ SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const 
 
 SGL_EXPORT int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, const double *d_val64, double *d_colsum,
                                      void *stream) {
-    SGL_REQUIRE(n_cols >= 0 && nnz >= 0, "sgl_norm_block_colsum: bad sizes");
+    SGL_REQUIRE(n_cols >= 0 && nnz >= 0 && nnz < (int64_t)UINT32_MAX, "sgl_norm_block_colsum: bad sizes (nnz must be < 2^32 per block)");
     if (nnz == 0) return SGL_OK;
     SGL_REQUIRE(d_col && d_val64 && d_colsum, "sgl_norm_block_colsum: NULL arrays");
     hipLaunchKernelGGL(block_colsum_kernel, dim3(blocks_for(nnz)), dim3(256), 0, sgl::as_stream(stream), d_col, d_val64, nnz, d_colsum);

@@ -5,6 +5,7 @@ import torch.distributed as dist
 
 from .layout import GridLayout, all_piece_bounds, column_chunks, column_slices, device_piece_spmms
 from .propagator import ShardedPropagator
+from .sharded_adj import RowBlock, allgather_rows, block_piece_spmms, gather_piece_bounds
 
 
 class ShardedGraphOp:
@@ -20,15 +21,22 @@ class ShardedGraphOp:
     column-wise aggregators -- last/sum/mean/max/min/simple_weighted -- apply unchanged), anything between = grid.
     288 GB per GPU make the replication affordable up to ogbn-papers100M (27 GB of CSR, two 57 GB feature replicas).
 
+    Row-sharded STORAGE (the contract layout of SURVEY 8(e)): pass a `RowBlock` instead -- this rank's rows
+    [lo, hi) of the raw adjacency (of A^T when A is not symmetric: `symmetric=False`), local row pointers, global column
+    ids.  The block is normalised in place of the whole matrix (sgl_norm_block_*: the only communication is the degree
+    vector) and NO rank ever holds more than its own rows of A or A_hat; the feature argument may be the full matrix or
+    just this rank's rows (then the replica is all-gathered once).  Only the row-sharded layout applies.
+
     Works without torch.distributed (world size 1); with it, uses the default process group unless `group` is given
     (row-sharded layout only: grid layouts address ranks of the default group)."""
 
     def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None,
-                 device=None, row_groups=None, transport=None):
+                 device=None, row_groups=None, transport=None, symmetric=True):
         self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
         self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
         self.device = device
         self.row_groups, self.transport = row_groups, transport
+        self.symmetric = symmetric
         self.lo = self.hi = self.c0 = self.c1 = None
         self._cache = None
         self._props = {}
@@ -41,9 +49,51 @@ class ShardedGraphOp:
     def _gloo(self):
         return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
 
+    def _propagate_block(self, blk, feature):
+        """row-sharded storage: normalise and multiply this rank's rows only"""
+        from .. import device as dev
+        from ..operators.base_op import AdjIdentity
+        rank, world = self._ranks()
+        if self.row_groups not in (None, world):
+            raise ValueError("a RowBlock adjacency implies the row-sharded layout")
+        key = ("block", world, rank, blk.lo, blk.hi)
+        if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(blk):
+            rowptr, col, val = dev.normalize_block(blk.rowptr, blk.col, blk.val, blk.lo, blk.n, self.r, self.alpha,
+                                                   symmetric=self.symmetric, group=self.group)
+            nblk = RowBlock(blk.lo, blk.hi, blk.n, rowptr, col, val)
+            fns, handles, mine = block_piece_spmms(nblk, self.pieces, strict=self.strict_order)
+            pb = gather_piece_bounds(mine, self.group)
+            self._cache = (key, fns, pb, handles)
+            self._cache_ident = AdjIdentity(blk)
+            self._props = {}
+            self.a_hat_block = nblk
+        _, fns, pb, handles = self._cache
+        n = blk.n
+        x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
+        x = x.to(device=blk.device, dtype=torch.float32)
+        if x.shape[0] == blk.n_local and x.shape[0] != n:
+            x = allgather_rows(x.contiguous(), pb[:, 0].tolist() + [int(pb[-1, -1])], n, group=self.group)
+        if x.shape[0] != n:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        transport = self.transport or ("staged" if world > 1 and self._gloo() and x.is_cuda else "p2p")
+        prop = self._props.get(("rows", transport))
+        if prop is None:
+            prop = self._props[("rows", transport)] = ShardedPropagator(fns, pb, rank, world, n, group=self.group,
+                                                                        transport=transport)
+        self._prop = prop
+        self.lo, self.hi, self.c0, self.c1 = prop.lo, prop.hi, 0, x.shape[1]
+        x = x.contiguous()
+        chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
+        if len(chunks) == 1:
+            return prop.propagate(x, self.prop_steps)
+        hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+        return [torch.cat(h, dim=1) for h in hops]
+
     def propagate(self, adj, feature):
         from .. import device as dev
         from ..io import DeviceAdjacency
+        if isinstance(adj, RowBlock):
+            return self._propagate_block(adj, feature)
         rank, world = self._ranks()
         device = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         from ..operators.base_op import AdjIdentity

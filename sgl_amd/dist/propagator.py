@@ -77,9 +77,12 @@ class ShardedPropagator:
             self._aux = torch.cuda.Stream(device=device)
         return self._aux
 
-    def propagate(self, x_full, prop_steps, x_buffers=None, y_buffers=None):
+    def propagate(self, x_full, prop_steps, x_buffers=None, y_buffers=None, in_place=False):
         """x_full: [N, d] replica of the input features on this rank's device (row-major, contiguous).
         Returns the list of K+1 LOCAL hop shards [hi-lo, d] (hop 0 is a view of x_full).
+        in_place: hops 1..K-1 are written straight into this rank's rows of the next replica (no separate shard, no
+        copy) -- their entries in the returned list are views that the hop after next overwrites, i.e. only the LAST hop
+        is retained.  For jobs that need just A^K X, or whose K+1 full-size shards would not fit (papers100M on few GPUs).
         y_buffers: optional K preallocated [hi-lo, d] outputs (a loop that calls this repeatedly then allocates
         nothing: with asynchronous transfers holding references, a host running ahead of the GPU would otherwise keep
         the allocator from recycling the previous calls' outputs)."""
@@ -101,11 +104,15 @@ class ShardedPropagator:
             aux = self._aux_stream(x_full.device)
         for h in range(1, prop_steps + 1):
             last = h == prop_steps
-            y_local = y_buffers[h - 1] if y_buffers is not None else \
-                torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
             x_next = None if last else x_buffers[(h - 1) % len(x_buffers)]
             if x_next is not None and x_next.numel() and x_next.data_ptr() == cur.data_ptr():
                 raise RuntimeError("need two distinct full-size buffers to ping-pong between hops")
+            direct = in_place and not last
+            if direct:
+                y_local = x_next[self.lo:self.hi]
+            else:
+                y_local = y_buffers[h - 1] if y_buffers is not None else \
+                    torch.empty((self.hi - self.lo, d), dtype=x_full.dtype, device=x_full.device)
             if two:
                 # no record_stream on y_local: the caller's stream waits for `aux` at the end of this hop, before
                 # anything that could recycle the block, so stream order already protects it
@@ -124,7 +131,8 @@ class ShardedPropagator:
             if two:
                 main.wait_stream(aux)
             if not last:
-                x_next[self.lo:self.hi].copy_(y_local)
+                if not direct:
+                    x_next[self.lo:self.hi].copy_(y_local)
                 for w in works:
                     w.advance()
                 for w in works:

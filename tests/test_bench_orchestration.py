@@ -41,12 +41,62 @@ def _make_engine():
         def init_kwargs(self):
             return {}
 
-        def build_workload(self, args, wl):
+        def build_raw(self, args, wl):
             ip, ix, dt = chung_lu_numpy(wl["n"], wl["m"], wl["d_max"], seed=args.seed)
+            return torch.from_numpy(ip), torch.from_numpy(ix.astype(np.int32)), torch.from_numpy(dt.astype(np.float32))
+
+        def features(self, args, wl):
+            return torch.from_numpy(np.random.default_rng(0).standard_normal((wl["n"], wl["d"])).astype(np.float32))
+
+        def build_workload(self, args, wl):
+            ip, ix, dt = (t.numpy() for t in self.build_raw(args, wl))
             ptr, col, val = oracle.laplacian_adj(ip, ix, dt, wl["n"], 0.5)
-            x = np.random.default_rng(0).standard_normal((wl["n"], wl["d"])).astype(np.float32)
             return (torch.from_numpy(ptr), torch.from_numpy(col.astype(np.int32)),
-                    torch.from_numpy(val.astype(np.float32)), torch.from_numpy(x))
+                    torch.from_numpy(val.astype(np.float32)), self.features(args, wl))
+
+        def normalize_block(self, blk, r=0.5, alpha=None, symmetric=True):
+            """numpy restatement of sgl_norm_block_* for a symmetric unit-weight block: rows of A + I, degrees by
+            all-reduce, (T'[j,i] * L[j]) * R[i] rounded to fp32"""
+            from sgl_amd.dist import RowBlock
+            rp, cc, vv = blk.rowptr.numpy(), blk.col.numpy(), blk.val.numpy()
+            rows = np.repeat(np.arange(blk.n_local), np.diff(rp))
+            import scipy.sparse as sp
+            t = sp.csr_matrix((vv.astype(np.float64), (rows, cc)), shape=(blk.n_local, blk.n))
+            eye = sp.csr_matrix((np.ones(blk.n_local), (np.arange(blk.n_local), np.arange(blk.lo, blk.hi))), shape=t.shape)
+            t = (t + eye).tocsr()
+            t.sort_indices()
+            deg = torch.zeros(blk.n, dtype=torch.float64)
+            deg[blk.lo:blk.hi] = torch.from_numpy(np.asarray(t.sum(1)).ravel())
+            if dist.is_initialized():
+                dist.all_reduce(deg)
+            dg = deg.numpy()
+            left, right = np.power(dg, r - 1), np.power(dg, -r)
+            vals = (t.data * np.repeat(left[blk.lo:blk.hi], np.diff(t.indptr))) * right[t.indices]
+            return RowBlock(blk.lo, blk.hi, blk.n, torch.from_numpy(t.indptr.astype(np.int64)),
+                            torch.from_numpy(t.indices.astype(np.int32)), torch.from_numpy(vals.astype(np.float32)))
+
+        def block_piece_spmms(self, args, blk, pieces, weights=None):
+            from sgl_amd.dist import local_piece_bounds
+            pb, rp_host = local_piece_bounds(blk, pieces, weights)
+            fns = []
+            for p in range(pieces):
+                r0, r1 = int(pb[p]) - blk.lo, int(pb[p + 1]) - blk.lo
+                rp = (rp_host[r0:r1 + 1] - rp_host[r0]).astype(np.int64)
+                c, v = blk.col[int(rp_host[r0]):int(rp_host[r1])].numpy(), blk.val[int(rp_host[r0]):int(rp_host[r1])].numpy()
+                fns.append(lambda x, out, rp=rp, c=c, v=v, rows=r1 - r0:
+                           out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c, v, x.numpy(), n_rows=rows))))
+            return fns, None, pb
+
+        def sampled_rows_check(self, blk, x_prev, y_local, samples=64, tol=1e-5):
+            rows = np.random.default_rng(blk.lo).integers(0, max(blk.n_local, 1), size=min(samples, blk.n_local))
+            rp, c, v = blk.rowptr.numpy(), blk.col.numpy(), blk.val.numpy()
+            for r in rows:
+                sl = slice(int(rp[r]), int(rp[r + 1]))
+                want = (v[sl, None].astype(np.float64) * x_prev.numpy()[c[sl]].astype(np.float64)).sum(0)
+                mag = (np.abs(v[sl, None].astype(np.float64)) * np.abs(x_prev.numpy()[c[sl]])).sum(0)
+                if not (np.abs(y_local.numpy()[r] - want) <= tol * np.maximum(mag, 1e-30) + 1e-30).all():
+                    return False
+            return True
 
         def single_step(self, args, rowptr, col, val, x0, n, d, K):
             rp, c, v = rowptr.numpy(), col.numpy(), val.numpy()
@@ -116,18 +166,41 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert set(plan["layout_candidates_ms"]) == {"cols", "rows"} and plan["layout"] in ("cols", "rows")
     assert "layout_rejected" not in plan and plan["layout"] == min(plan["layout_candidates_ms"], key=plan["layout_candidates_ms"].get)
     assert j["config"]["parallelism"].startswith("feature-sharded" if plan["layout"] == "cols" else "row-sharded")
+    # the contract layout is always reported, whatever runs; A_hat is stored as one row block per rank
+    assert plan["contract_layout"] == "rows" and plan["rows"]["value"] > 0 and plan["rows"]["ms_per_step"] > 0
+    assert plan["rows"]["parallelism"].startswith("row-sharded x2 (A_hat stored as one row block per GPU)")
+    assert plan["adjacency_storage"].startswith("row block per rank") and j["config"]["setup_s"] < 120
+    assert j["config"]["workload"].startswith("T_tiny: prop_steps=3")
+    assert j["roofline"]["traffic"] is None and j["roofline"]["traffic_source"] is None and "papers100M" not in j
+
+
+def test_bench_rows_only_keeps_no_replica_and_budget_skips(tmp_path):
+    """--layout rows: nothing replica-based is ever built; a zero setup budget skips the alternative and says so"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "rows")), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert list(plan["layout_candidates_ms"]) == ["rows"] and plan["layout"] == "rows" and "adjacency_replicated_for" not in plan
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--setup-budget", "0")), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert plan["layout"] == "rows" and plan["layout_skipped_setup_budget"] == ["cols"] and "adjacency_replicated_for" not in plan
 
 
 def test_bench_four_ranks_gloo_all_layouts(tmp_path):
-    """N = 4: feature-sharded, row-sharded and the relayed 2 x 2 grid are all built, validated against the single-rank
-    chain and timed; an explicit --layout runs just that one"""
+    """N = 4, --layout all: row-sharded (contract), feature-sharded and the relayed 2 x 2 grid are all built, validated and
+    timed; the default tries rows + one alternative only; an explicit --layout runs just that one"""
     world = 4
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "all", "--grid-pieces", "2,4,8")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
-    assert j["n_gpus"] == 4 and j["value"] > 0
+    assert j["n_gpus"] == 4 and j["value"] > 0 and plan["rows"]["value"] > 0
+    assert plan["adjacency_replicated_for"].startswith("alternative layout candidates")
     assert set(plan["grid_pieces_candidates_ms"]) == {"2", "4", "8"} and plan["grid_pieces"] in (2, 4, 8)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    assert set(j["config"]["plan"]["layout_candidates_ms"]) == {"rows", "cols"}
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "grid", "--grid-pieces", "2")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     assert j["config"]["plan"]["layout"] == "grid" and j["config"]["parallelism"].startswith("grid 2 row blocks x 2 column slices")
@@ -138,14 +211,15 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
 
 
 def test_bench_eight_ranks_gloo(tmp_path):
-    """the driver's largest launch shape: 8 ranks, all three layouts (the grid is 2 row blocks x 4 column slices)"""
+    """the driver's largest launch shape: 8 ranks, default flags: the contract layout + the 2 x 4 grid"""
     world = 8
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])
     plan = j["config"]["plan"]
-    assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) == {"cols", "rows", "grid"} and "layout_rejected" not in plan
+    assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) == {"rows", "grid"} and "layout_rejected" not in plan
+    assert plan["rows"]["value"] > 0 and plan["contract_layout"] == "rows" and list(plan["grid_pieces_candidates_ms"]) == ["4"]
     assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0
     links = j["config"]["diagnostics"]["links"]     # gloo: the pairwise exchange works, all_to_all may not exist
     assert links["pair_exchange_64MB_GBps_per_direction"] > 0 and "all_to_all_1MB_per_peer_GBps_per_link" in links

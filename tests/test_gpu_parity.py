@@ -1095,6 +1095,36 @@ def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
     assert empty.nnz == 0 and empty.rowptr.cpu().tolist() == [0] * 6
 
 
+def test_hashed_generator_device_equals_host_mirror(cuda):
+    """sgl_synth_* (rows generated per shard on device, keyed by (seed, row)) against the numpy mirror, bit for bit: small
+    blocks anywhere in a papers100M-sized id range, and a block large enough (> 2^30 threads) that the kernels must
+    stride -- a launch cannot carry 2^32 threads, and a truncated one leaves rows unwritten without any error."""
+    from sgl_amd import synthetic as sy
+    n = 111_059_956
+    table = sy.degree_table(30.07, 20_000)
+    for seed, row0, cnt in ((0, 0, 3000), (7, n - 2500, 2500), (1, 55_000_123, 1500)):
+        rp, c, v = sy.hashed_block_torch(seed, row0, cnt, n, table, device=cuda)
+        hp, hc, hv = sy.hashed_rows_numpy(seed, np.arange(row0, row0 + cnt), n, table)
+        assert np.array_equal(rp.cpu().numpy(), hp) and np.array_equal(c.cpu().numpy(), hc) and np.array_equal(v.cpu().numpy(), hv)
+        x = sy.hashed_features_torch(seed, row0, cnt, 100, device=cuda)
+        assert np.array_equal(x.cpu().numpy(), sy.hashed_features_numpy(seed, np.arange(row0, row0 + cnt), 100))
+        assert x.stride(0) == 100 or not dev.padded_parent(x)[:, 100:].any()
+    big = 20_000_000                                          # 1.28e9 generator threads > the 2^30 the launch carries
+    rp, c, v = sy.hashed_block_torch(3, 1000, big, n, table, device=cuda)
+    rows = np.concatenate([np.arange(0, 64), np.arange(big // 2, big // 2 + 64), np.arange(big - 64, big)])
+    hp, hc, hv = sy.hashed_rows_numpy(3, 1000 + rows, n, table)
+    rph = rp.cpu().numpy()
+    assert np.array_equal(np.diff(hp), (rph[rows + 1] - rph[rows]))
+    sel = np.concatenate([np.arange(rph[r], rph[r + 1]) for r in rows])
+    idx = torch.from_numpy(sel).to(cuda)
+    assert np.array_equal(c[idx].cpu().numpy(), hc) and np.array_equal(v[idx].cpu().numpy(), hv)
+    assert int(c.min()) >= 0 and int(c.max()) < n
+    del rp, c, v
+    xb = sy.hashed_features_torch(3, 0, 12_000_000, 128, device=cuda)          # 1.5e9 elements
+    tail = np.arange(12_000_000 - 100, 12_000_000)
+    assert np.array_equal(xb[tail[0]:].cpu().numpy(), sy.hashed_features_numpy(3, tail, 128))
+
+
 def test_int64_offsets_beyond_2_31_elements(cuda):
     """papers100M-shard shape: the dense operand has more than 2^31 elements (the reference's `int` offsets overflow
     there, matmul.c:29,33) and the gathered rows sit at byte offsets beyond 8 GiB"""
