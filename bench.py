@@ -847,9 +847,9 @@ def _replayed_profile(workload, world):
         tj = json.load(open(tfile))
     except Exception:  # noqa: BLE001
         return None
-    if tj.get("workload") != workload or world != 1:
-        return None
-    return tj
+    if "workload" in tj:                              # round-1 layout: a single entry
+        tj = {tj["workload"]: tj}
+    return tj.get(workload) if world == 1 else None
 
 
 def papers_section(args, engine, rank, world, exchange):

@@ -1150,6 +1150,51 @@ def test_int64_offsets_beyond_2_31_elements(cuda):
     del x
 
 
+def test_papers_shard_million_sampled_rows_vs_oracle(cuda):
+    """BASELINE configs 4/5 at their own shape: one rank's 1/8 row block of the ogbn-papers100M-shaped hashed graph
+    (13.9 M rows, ~418 M non-zeros) against the full 111 M x 128 feature replica (56.9 GB).  2^20 sampled rows are
+    recomputed by the CPU oracle (the gathered X rows travel compacted) and must be bit-equal wherever the row is one
+    fmaf chain (<= 2048 non-zeros), within 1e-5 for the few split rows; the sampled rows' generator output is pinned to
+    the host mirror."""
+    from sgl_amd import synthetic as sy
+    free, _ = torch.cuda.mem_get_info()
+    n = 111_059_956 if free > 120e9 else 111_059_956 // 8
+    d = 128
+    table = sy.degree_table(30.07, 20_000)
+    rows_blk = n // 8
+    rp, c, v = sy.hashed_block_torch(0, 0, rows_blk, n, table, device=cuda)
+    x = sy.hashed_features_torch(0, 0, n, d, device=cuda)
+    csr = dev.DeviceCSR(rp, c, v, (rows_blk, n))
+    y = csr.spmm(x)
+    info = csr.info()
+    assert info["nnz"] == c.numel() and info["n_pieces"] > 0          # the block does contain rows that get split
+    m = 1 << 20
+    rows = torch.randperm(rows_blk, generator=torch.Generator().manual_seed(1))[:m].sort().values.to(cuda)
+    b, e = rp[rows], rp[rows + 1]
+    cnt = e - b
+    srp = torch.zeros(m + 1, dtype=torch.int64, device=cuda)
+    torch.cumsum(cnt, 0, out=srp[1:])
+    pos = torch.arange(int(srp[-1]), device=cuda) - torch.repeat_interleave(srp[:-1], cnt) + torch.repeat_interleave(b, cnt)
+    sc, sv = c[pos], v[pos]
+    # generator pinned to the host mirror on the first 3000 sampled rows
+    k = 3000
+    hp, hc, hv = sy.hashed_rows_numpy(0, rows[:k].cpu().numpy(), n, table)
+    assert np.array_equal(hp, srp[:k + 1].cpu().numpy()) and np.array_equal(hc, sc[:hp[-1]].cpu().numpy())
+    assert np.array_equal(hv, sv[:hp[-1]].cpu().numpy())
+    uniq, inv = torch.unique(sc.long(), return_inverse=True)
+    assert np.array_equal(x[uniq[:500]].cpu().numpy(), sy.hashed_features_numpy(0, uniq[:500].cpu().numpy(), d))
+    xc = x[uniq].cpu().numpy()                                          # only the gathered rows leave the GPU
+    ref = oracle.oracle_spmm(srp.cpu().numpy(), inv.to(torch.int32).cpu().numpy(), sv.cpu().numpy(), xc, n_rows=m)
+    got = y[rows].cpu().numpy()
+    whole = (cnt <= 2048).cpu().numpy()
+    assert whole.sum() >= m - 2000 and np.array_equal(got[whole], ref[whole])   # one fmaf chain per (row, column): bit-exact
+    if (~whole).any():
+        scale = oracle.oracle_spmm(srp.cpu().numpy(), inv.to(torch.int32).cpu().numpy(), np.abs(sv.cpu().numpy()), np.abs(xc), n_rows=m)
+        rep = oracle.parity_report(got[~whole], ref[~whole], TOL, scale=scale[~whole])
+        assert rep["ok"], rep
+    print(f"papers shard: {int(whole.sum())} sampled rows bit-equal, {int((~whole).sum())} split rows within {TOL}")
+
+
 # ---- full-size, size-independent properties ------------------------------------------------------------------
 def test_products_scale_properties(cuda):
     """ogbn-products-shaped graph (N = 2.45 M, nnz ~ 126 M, d = 100): sampled rows against the oracle, linearity,

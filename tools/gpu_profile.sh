@@ -1,17 +1,20 @@
 #!/bin/bash
-# rocprofv3 evidence for the bench command: kernel-trace stats (csv) + separate PMC passes (never combined with sys-trace)
+# rocprofv3 evidence for a bench command: kernel-trace stats (csv) + separate PMC passes (never combined with sys-trace).
+#   tools/gpu_profile.sh <workload> [extra bench flags]      e.g.  tools/gpu_profile.sh S1_products
+# Outputs under gpurun_out/prof_<workload>/ ; tools/summarize_profiles.py copies the summaries into profiles/.
+WL=${1:-S1_products}; shift
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/prof_stats gpurun_out/prof_pmc_*
-timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench exit $?" >> gpurun_out/bench.log
+R="$GRAFT_REPO_ROOT"; O=$R/gpurun_out/prof_$WL
+rm -rf $O; mkdir -p $O
+# the papers100M-shaped section of an S1 run launches the same kernel on another graph: kept out of the profiled command
+BENCH="python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-papers $*"
 cd /tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o r1 -- $BENCH > $R/gpurun_out/rocprof_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r -- $BENCH > $O/rocprof_stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD" "GRBM_GUI_ACTIVE"; do
   T=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/prof_pmc_$T -o pmc -- $BENCH > $R/gpurun_out/rocprof_pmc_$T.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$T -o pmc -- $BENCH > $O/rocprof_pmc_$T.log 2>&1
 done
 cd $R
-find gpurun_out -name "*.db" -delete 2>/dev/null
-find gpurun_out -name "*_kernel_trace.csv" -size +5M -delete 2>/dev/null
-grep -v exit gpurun_out/bench.log | tail -1 | cut -c1-300; ls gpurun_out | head -30
+find $O -name "*.db" -delete 2>/dev/null
+find $O -name "*_kernel_trace.csv" -size +5M -delete 2>/dev/null
+ls $O | head -30

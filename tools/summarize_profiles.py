@@ -23,10 +23,16 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "prof_stats", "*_kernel_stats.csv"))
+src = os.path.join(src, f"prof_{workload}") if os.path.isdir(os.path.join(src, f"prof_{workload}")) else src
+kernel_avg_ms = None
+stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True) or \
+    glob.glob(os.path.join(src, "prof_stats", "*_kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
+    for r in rows:
+        if "spmm_kernel" in r["Name"] and kernel_avg_ms is None:
+            kernel_avg_ms = float(r["AverageNs"]) / 1e6
+    with open(os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
         for r in rows:
@@ -34,7 +40,8 @@ if stats:
             w.writerow(r)
 
 means = collections.OrderedDict()
-for f in sorted(glob.glob(os.path.join(src, "prof_pmc_*", "pmc_counter_collection.csv"))):
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "pmc_counter_collection.csv"), recursive=True) or
+                glob.glob(os.path.join(src, "prof_pmc_*", "pmc_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "spmm_kernel" in r["Kernel_Name"]:
@@ -47,10 +54,11 @@ if means:
     fetch = means.get("FETCH_SIZE", (0, 0))[0]
     write = means.get("WRITE_SIZE", (0, 0))[0]
     hbm = (2 * fetch + write) * 1024
-    with open(os.path.join(dst, f"{tag}_pmc_spmm_kernel.md"), "w") as f:
+    with open(os.path.join(dst, f"{tag}_{workload}_pmc_spmm_kernel.md"), "w") as f:
         f.write(f"# rocprofv3 PMC counters, {kname}, workload {workload}\n\n")
         f.write("Command per pass: `rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python bench.py "
-                "--steps 3 --warmup 1 --no-cpu-baseline` (one pass per counter group; means over the launches)\n\n")
+                f"--workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-papers` (one pass per counter group; means over "
+                "the launches)\n\n")
         f.write(f"VGPR {regs[0]}, SGPR {regs[1]}, grid {regs[2]} threads, workgroup {regs[3]}\n\n")
         f.write("| counter | mean per launch | launches |\n|---|---|---|\n")
         for c, (m, n) in means.items():
@@ -61,9 +69,18 @@ if means:
         if "TCC_HIT_sum" in means:
             h, m_ = means["TCC_HIT_sum"][0], means["TCC_MISS_sum"][0]
             f.write(f"\nL2 hit rate = {h / (h + m_):.3%}\n")
-    json.dump({"workload": workload, "hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write,
-               "source": f"profiles/{tag}_pmc_spmm_kernel.md", "kernel": kname},
-              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    tfile = os.path.join(dst, "traffic.json")
+    try:
+        table = json.load(open(tfile))
+        if "workload" in table:                       # round-1 layout: a single entry
+            table = {table["workload"]: table}
+    except Exception:  # noqa: BLE001
+        table = {}
+    table[workload] = {"workload": workload, "hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write,
+                       "source": f"profiles/{tag}_{workload}_pmc_spmm_kernel.md", "kernel": kname,
+                       "kernel_avg_ms_rocprof": kernel_avg_ms,
+                       "kernel_stats": f"profiles/{tag}_{workload}_kernel_stats.csv"}
+    json.dump(table, open(tfile, "w"), indent=1)
 for name in ("sweep.log", "bench.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
