@@ -144,6 +144,14 @@ int sgl_chain_graph_destroy(sgl_graph_t *graph);
 int sgl_spmm_axpb_clamp_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                             float alpha, const float *d_res, int64_t ldres, float lo, float hi, void *stream);
 
+/* Y = A . X and, in the same pass, the running aggregate  ACC <- ACC + Y  (weighted = 0)  or  ACC <- ACC + w * Y  (weighted != 0:
+ * rounded product, then add), followed by ACC <- ACC / divisor when divisor != 1 (Mean's single true division, on the last
+ * hop).  Same arithmetic and order as sgl_hop_reduce_f32 over the materialised hops (SUM / MEAN / WSUM): the Sum / Mean /
+ * SimpleWeighted MessageOps (message_op/sum_message_op.py:10, mean_message_op.py:10, simple_weighted_message_op.py:41-56)
+ * then cost no pass of their own and no hop matrix has to be kept.  ACC is initialised by the caller (X_s, or w_s * X_s). */
+int sgl_spmm_acc_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
+                     int64_t ldacc, float w, int weighted, float divisor, void *stream);
+
 /* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */
 /* matmul.h:5 -- accumulates into `answer` (caller pre-zeroes it, utils.py:31).  Errors are recorded in
  * sgl_last_error() (the reference symbol is void). */

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "sgl_chain_graph_destroy": (c_int, [c_void_p]),
     "sgl_spmm_axpb_clamp_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_float, c_void_p, c_int64,
                                         c_float, c_float, c_void_p]),
+    "sgl_spmm_acc_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_int,
+                                 c_float, c_void_p]),
     "FloatCSRMulDenseOMP": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "FloatCSRMulDense": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "sgl_norm_prepare": (c_int, [c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),

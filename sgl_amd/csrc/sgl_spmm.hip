@@ -116,6 +116,10 @@ struct SpmmArgs {
     int64_t ldres;
     float epi_alpha, epi_lo, epi_hi;
     int32_t epi;
+    float *acc;                 // optional running aggregate (see Epilogue)
+    int64_t ldacc;
+    float acc_w, acc_div;
+    int32_t acc_mode;
     // optional replicas of Y: every output row is ALSO stored at the same (row, column) offset of these matrices
     // (same leading dimension as y).  Used to push a rank's new rows straight into the peers' feature replicas
     // over xGMI from the producing kernel (sgl_spmm_multi_f32); n_more == 0 otherwise.
@@ -150,7 +154,21 @@ struct Epilogue {
     const float *res;   // row pointer already applied by the caller (may be nullptr)
     float alpha, lo, hi;
     int on;
+    // running aggregate over hops, updated where the row is produced (Sum / Mean / SimpleWeighted MessageOps without a
+    // second pass over the hop matrices): acc_mode 1: ACC += Y, 2: ACC += w * Y (rounded product, then add: the order of
+    // hop_reduce_kernel), +4: ACC /= acc_div afterwards (Mean's one true division, on the last hop).  Y itself is stored
+    // unchanged: it is the next hop's input.
+    float *acc;         // row pointer already applied (nullptr = off)
+    int64_t ldacc;
+    float acc_w, acc_div;
+    int acc_mode;
 };
+
+__device__ __forceinline__ float acc_apply(float a, float y, const Epilogue &e) {
+    a = ((e.acc_mode & 3) == 2) ? __fadd_rn(a, __fmul_rn(y, e.acc_w)) : __fadd_rn(a, y);
+    if (e.acc_mode & 4) a = __fdiv_rn(a, e.acc_div);
+    return a;
+}
 
 __device__ __forceinline__ float epi_apply(float v, float r, const Epilogue &e, bool has_res) {
     float t = __fmul_rn(e.alpha, v);          // alpha * spmm(...)   (rounded product, then rounded add: torch order)
@@ -309,6 +327,17 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                             for (int e = 0; e < VEC; ++e) v[e] = epi_apply(v[e], r[e], epi, has_res);
                         }
                     }
+                    if (epi.acc) {
+                        float *ap = epi.acc + (int64_t)ri * epi.ldacc + colofs[ch];
+                        V a = *reinterpret_cast<const V *>(ap);
+                        if constexpr (VEC == 1) {
+                            a = acc_apply(a, v, epi);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) a[e] = acc_apply(a[e], v[e], epi);
+                        }
+                        *reinterpret_cast<V *>(ap) = a;
+                    }
                     if constexpr (TAIL) {
                         if (!is_tail || ta.full) st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
                         if (is_tail && ta.ot)
@@ -343,6 +372,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         none.alpha = 1.f;
         none.lo = none.hi = 0.f;
         none.on = 0;   // pieces hold partial sums: the epilogue runs in the fix-up kernel
+        none.acc = nullptr;
+        none.ldacc = 0;
+        none.acc_w = none.acc_div = 1.f;
+        none.acc_mode = 0;
         MultiOut solo;
         solo.n = 0;
         solo.mask = nullptr;
@@ -367,6 +400,11 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         epi.lo = a.epi_lo;
         epi.hi = a.epi_hi;
         epi.on = a.epi;
+        epi.acc = a.acc ? a.acc + (int64_t)row_begin * a.ldacc : nullptr;
+        epi.ldacc = a.ldacc;
+        epi.acc_w = a.acc_w;
+        epi.acc_div = a.acc_div;
+        epi.acc_mode = a.acc_mode;
         MultiOut mo;
         mo.n = MULTI ? a.n_more : 0;
         mo.mask = (MULTI && a.row_mask) ? a.row_mask + row_begin : nullptr;
@@ -390,6 +428,10 @@ __global__ __launch_bounds__(256) void spmm_tail_kernel(const SpmmArgs a) {
     none.alpha = 1.f;
     none.lo = none.hi = 0.f;
     none.on = 0;
+    none.acc = nullptr;
+    none.ldacc = 0;
+    none.acc_w = none.acc_div = 1.f;
+    none.acc_mode = 0;
     MultiOut solo;
     solo.n = 0;
     solo.mask = nullptr;
@@ -450,6 +492,10 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     float acc = accumulate ? (tp ? *tp : *yp) : 0.f;
     for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
     if (epi.on) acc = epi_apply(acc, res ? res[(int64_t)row * ldres + k] : 0.f, epi, res != nullptr);
+    if (epi.acc) {   // here epi.acc is the matrix base (rows are absolute in the fix-up)
+        float *ap = epi.acc + (int64_t)row * epi.ldacc + k;
+        *ap = acc_apply(*ap, acc, epi);
+    }
     if (main_too) *yp = acc;
     if (tp) *tp = acc;
     const int need = mo.mask ? (int)mo.mask[row] : 0x7f;
@@ -623,6 +669,11 @@ struct EpiHost {
     int n_more = 0;             // replicas of Y (sgl_spmm_multi_f32)
     float *y_more[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const uint8_t *row_mask = nullptr;
+    // running aggregate (sgl_spmm_acc_f32)
+    float *acc = nullptr;
+    int64_t ldacc = 0;
+    float acc_w = 1.f, acc_div = 1.f;
+    int acc_mode = 0;
     // split layout (sgl_spmm_tail_f32)
     const float *xt = nullptr;
     float *yt = nullptr;
@@ -695,6 +746,11 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.epi_lo = eh.lo;
     a.epi_hi = eh.hi;
     a.epi = eh.on;
+    a.acc = eh.acc;
+    a.ldacc = eh.ldacc;
+    a.acc_w = eh.acc_w;
+    a.acc_div = eh.acc_div;
+    a.acc_mode = eh.acc_mode;
     a.n_more = eh.n_more;
     a.row_mask = eh.row_mask;
     for (int q = 0; q < 7; ++q) a.y_more[q] = eh.y_more[q];
@@ -757,6 +813,11 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         fe.lo = eh.lo;
         fe.hi = eh.hi;
         fe.on = eh.on;
+        fe.acc = eh.acc;
+        fe.ldacc = eh.ldacc;
+        fe.acc_w = eh.acc_w;
+        fe.acc_div = eh.acc_div;
+        fe.acc_mode = eh.acc_mode;
         MultiOut fmo;
         fmo.n = eh.n_more;
         fmo.mask = eh.row_mask;
@@ -795,11 +856,17 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
         if (vec == 4 && !(eh.ldres % 4 == 0 && aligned_to(eh.res, 16))) vec = (eh.ldres % 2 == 0 && aligned_to(eh.res, 8) && d % 2 == 0) ? 2 : 1;
         if (vec == 2 && !(eh.ldres % 2 == 0 && aligned_to(eh.res, 8))) vec = 1;
     }
+    if (eh.acc) {
+        SGL_REQUIRE(eh.ldacc >= d && aligned_to(eh.acc, 4), "%s: bad accumulator matrix", who);
+        if (vec == 4 && !(eh.ldacc % 4 == 0 && aligned_to(eh.acc, 16))) vec = (eh.ldacc % 2 == 0 && aligned_to(eh.acc, 8) && d % 2 == 0) ? 2 : 1;
+        if (vec == 2 && !(eh.ldacc % 2 == 0 && aligned_to(eh.acc, 8))) vec = 1;
+    }
     const int64_t max_cols = 64 * 4 * vec;
     for (int64_t c0 = 0; c0 < d; c0 += max_cols) {
         const int dc = (int)std::min<int64_t>(max_cols, d - c0);
         EpiHost es = eh;
         if (es.res) es.res += c0;
+        if (es.acc) es.acc += c0;
         for (int q = 0; q < es.n_more; ++q) es.y_more[q] += c0;
         int rc = spmm_slice(h, d_x + c0, ldx, d_y + c0, ldy, dc, vec, accumulate, st, es);
         if (rc != SGL_OK) return rc;
@@ -926,6 +993,22 @@ SGL_EXPORT int sgl_chain_graph_destroy(sgl_graph_t *g) {
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
     return SGL_OK;
+}
+
+// Y = A X  and, in the same pass,  ACC <- ACC + w * Y  [ / divisor ]: the running aggregate of the Sum / Mean /
+// SimpleWeighted MessageOps (message_op/{sum,mean,simple_weighted}_message_op.py) kept up to date where each row is
+// produced, so those aggregators need no pass of their own over the hop matrices and no hop needs to be kept.
+SGL_EXPORT int sgl_spmm_acc_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
+                                int64_t ldacc, float w, int weighted, float divisor, void *stream) {
+    SGL_REQUIRE(d_acc != nullptr, "sgl_spmm_acc_f32: NULL accumulator");
+    SGL_REQUIRE(!(divisor == 0.f), "sgl_spmm_acc_f32: zero divisor");
+    EpiHost eh;
+    eh.acc = d_acc;
+    eh.ldacc = ldacc;
+    eh.acc_w = w;
+    eh.acc_div = divisor;
+    eh.acc_mode = (weighted ? 2 : 1) | (divisor != 1.f ? 4 : 0);
+    return spmm_impl(h, d_x, ldx, d_y, ldy, d, 0, stream, eh, "sgl_spmm_acc_f32");
 }
 
 SGL_EXPORT int sgl_spmm_axpb_clamp_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,

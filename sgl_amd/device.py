@@ -156,6 +156,20 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
+    def spmm_acc(self, x, out, acc, w=1.0, weighted=False, divisor=1.0):
+        """out = A @ x and, in the same kernel, acc <- acc + out (weighted: acc + w * out), then acc / divisor if
+        divisor != 1 (sgl_spmm_acc_f32): the running hop aggregate of Sum / Mean / SimpleWeighted"""
+        _check_mat(x, "x")
+        _check_mat(out, "out")
+        _check_mat(acc, "acc")
+        if x.shape[0] != self.shape[1] or out.shape != (self.shape[0], x.shape[1]) or acc.shape != out.shape:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        with torch.cuda.device(self.device):
+            check(lib().sgl_spmm_acc_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), x.shape[1], ptr(acc), _ld(acc),
+                                         float(w), int(bool(weighted)), float(divisor), current_stream_ptr()),
+                  "sgl_spmm_acc_f32")
+        return out
+
     def spmm_tail(self, x_main, x_tail, y_main, y_tail, d, d_main, tail_full=False, accumulate=False):
         """A @ X in the split layout (sgl_spmm_tail_f32): columns [0, d_main) live in the *_main matrices (128-byte
         aligned rows), columns [d_main, d) in the packed *_tail tables [n, 4 or 8]."""

@@ -47,8 +47,20 @@ class BaseSGAPModel(nn.Module):
             self._pre_msg_learnable = False
             self._processed_feature = feature
             return
-        self._processed_feat_list = self._pre_graph_op.propagate(adj, feature)
         self._pre_msg_learnable = self._pre_msg_op.aggr_type in _LEARNABLE
+        gop = self._pre_graph_op
+        if (config.fuse_aggregate and not self._pre_msg_learnable and hasattr(gop, "propagate_reduce")
+                and hasattr(self._pre_msg_op, "fused_spec") and not gop._opt("host_output")):
+            # last / sum / mean / simple_weighted: accumulated in the SpMM epilogue, the K+1 hop matrices never coexist
+            spec = self._pre_msg_op.fused_spec(gop._prop_steps + 1)
+            if spec is not None:
+                with torch.no_grad():
+                    fused = gop.propagate_reduce(adj, feature, **spec)
+                if fused is not None:
+                    self._processed_feat_list = None
+                    self._processed_feature = fused
+                    return
+        self._processed_feat_list = self._pre_graph_op.propagate(adj, feature)
         if not self._pre_msg_learnable:
             with torch.no_grad():
                 self._processed_feature = self._pre_msg_op.aggregate(self._processed_feat_list)

@@ -51,6 +51,11 @@ class AdjIdentity:
         return held is adj and self._print == self.fingerprint(adj)
 
 
+def _lib_reduce(kind):
+    from .. import _lib
+    return {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "wsum": _lib.SGL_REDUCE_WSUM}[kind]
+
+
 class GraphOp:
     def __init__(self, prop_steps, device=None, host_output=None, strict_types=None, strict_order=None, cache_adj=None):
         self._prop_steps = prop_steps
@@ -92,7 +97,8 @@ class GraphOp:
         self._adj_key = (AdjIdentity(adj), params) if self._opt("cache_adj") else None
         return csr
 
-    def propagate(self, adj, feature):
+    def _checked(self, adj, feature):
+        """_construct_adj BEFORE validation (reference order, base_op.py:20-27), then the reference's exceptions"""
         self._adj = self._construct_adj(adj)
 
         from ..io import DeviceAdjacency
@@ -108,12 +114,70 @@ class GraphOp:
         if feature.ndim != 2:
             raise ValueError("The feature matrix must be two-dimensional!")
 
+    def _device_features(self, feature):
+        """the input features as a [n, d] view of a 16-byte aligned, line-aware-pitch device buffer"""
         device = self._adj.device
         x0 = feature if (isinstance(feature, Tensor) and feature.is_cuda and feature.dtype == torch.float32) else None
         cur = dev.upload_rows(feature, device) if x0 is None else x0
         if (cur.shape[1] > 1 and cur.stride(1) != 1) or cur.data_ptr() % 16 != 0 or \
                 (cur.shape[0] > 1 and cur.stride(0) != dev.row_pitch(cur.shape[1])):
             cur = dev.upload_rows(cur, device)  # re-pack into an aligned buffer with the line-aware row pitch
+        return cur
+
+    def propagate_reduce(self, adj, feature, kind, start=0, end=None, weights=None, divisor=None):
+        """The hop aggregate WITHOUT the hops: `last`, `sum`, `mean` or `wsum` (fixed weights) of hops start..end-1 of
+        [X, A_hat X, ..., A_hat^K X], accumulated in the SpMM epilogue where each row is produced
+        (sgl_spmm_acc_f32).  Same arithmetic and order as aggregate(propagate(...)) with the corresponding MessageOp
+        (bit-identical for last / sum / mean; wsum identical to the HIP aggregator), but no pass over the hop matrices
+        and only two hop buffers alive at any time instead of K + 1.  Returns the [n, d] device tensor, or None when the
+        hop range is not one this path handles (the caller then uses propagate + aggregate)."""
+        K = self._prop_steps
+        n_hops = K + 1
+        s = 0 if start is None else start
+        e = n_hops if end is None else min(end, n_hops)
+        if kind == "last":
+            s, e = K, n_hops
+        if not (isinstance(s, int) and isinstance(e, int) and 0 <= s < e):
+            return None
+        if kind == "wsum":
+            w = [float(v) for v in torch.as_tensor(weights, dtype=torch.float32).reshape(-1)]
+            if len(w) != e - s:
+                return None
+        self._checked(adj, feature)
+        cur = self._device_features(feature)
+        d = cur.shape[1]
+        src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
+        n = self._adj.shape[0]
+        bufs = [dev.padded_parent(dev.alloc_rows(n, d, src.device)) for _ in range(min(2, e - 1))]
+
+        def begin(x_s):           # the aggregate's first term, with the aggregator kernel's own arithmetic
+            if kind == "wsum":
+                return dev.padded_parent(dev.hop_reduce(_lib_reduce("wsum"), [x_s[:, :d]], torch.tensor(w[:1])))
+            return dev.padded_parent(dev.hop_reduce(_lib_reduce("sum"), [x_s[:, :d]]))
+
+        acc = begin(src) if (s == 0 and kind != "last") else None
+        x = src
+        for h in range(1, e):
+            y = bufs[(h - 1) % len(bufs)]
+            if acc is not None:
+                last = h == e - 1
+                div = float(divisor if divisor is not None else (e - s)) if (kind == "mean" and last) else 1.0
+                self._adj.spmm_acc(x, y, acc, w=w[h - s] if kind == "wsum" else 1.0, weighted=kind == "wsum", divisor=div)
+            else:
+                self._adj.spmm(x, out=y)
+                if h == s and kind != "last":
+                    acc = begin(y)
+            x = y
+        if kind == "last":
+            return x[:, :d] if x.shape[1] != d else x
+        if kind == "mean" and e - s == 1:      # a single hop in range: the division has no SpMM to ride on
+            acc = acc / torch.tensor(float(divisor if divisor is not None else 1), device=acc.device)   # true division
+        return acc[:, :d] if acc.shape[1] != d else acc
+
+    def propagate(self, adj, feature):
+        self._checked(adj, feature)
+        device = self._adj.device
+        cur = self._device_features(feature)
         # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns
         # are zeros and stay zeros under propagation)
         src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
@@ -149,6 +213,11 @@ class MessageOp(nn.Module):
 
     def _combine(self, feat_list):
         return NotImplementedError
+
+    def fused_spec(self, n_hops):
+        """keyword arguments for GraphOp.propagate_reduce when this aggregator can be folded into the SpMM epilogue
+        (None = it cannot; subclasses override)"""
+        return None
 
     def aggregate(self, feat_list):
         if not isinstance(feat_list, list):

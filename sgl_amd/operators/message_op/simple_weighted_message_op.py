@@ -54,5 +54,13 @@ class SimpleWeightedMessageOp(MessageOp):
             return torch.FloatTensor(_decay_weights(self._alpha, n_hops)[self._start:self._end])
         return self._fixed
 
+    def fused_spec(self, n_hops):
+        if not (isinstance(self._start, int) and isinstance(self._end, int)) or self._start < 0 or self._end <= self._start:
+            return None
+        w = self.weights(n_hops)
+        if w.dim() != 1 or w.numel() != min(self._end, n_hops) - self._start:
+            return None           # a weight list that does not match the slice: let the unfused path raise as usual
+        return {"kind": "wsum", "start": self._start, "end": self._end, "weights": w}
+
     def _combine(self, feat_list):
         return one_dim_weighted_add(feat_list[self._start:self._end], weight_list=self.weights(len(feat_list)))

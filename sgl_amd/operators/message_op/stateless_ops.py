@@ -5,6 +5,8 @@ one torch expression: `feat_list[-1]`, `hstack`, Python `sum()`, `sum()/H`, `sta
 Here the four reductions are ONE streaming HIP kernel (sgl_hop_reduce_f32: a single pass over the H hop matrices,
 no [H, N, d] stack is ever materialised) and concat is a strided copy kernel; results are bit-identical to the
 reference's (same left-to-right order, one true division for mean, NaN-propagating max/min)."""
+import torch
+
 from ... import device as dev
 from ..base_op import MessageOp
 from ._common import back_home, device_hops, no_grad_inputs, reduce_hops
@@ -19,6 +21,9 @@ class LastMessageOp(MessageOp):
 
     def _combine(self, feat_list):
         return feat_list[-1]
+
+    def fused_spec(self, n_hops):
+        return {"kind": "last"}
 
 
 class ConcatMessageOp(MessageOp):
@@ -41,7 +46,24 @@ def _reduction(kind, doc):
             self._aggr_type = kind
 
         def _combine(self, feat_list):
-            return reduce_hops(kind, feat_list[self._start:self._end])
+            hops = feat_list[self._start:self._end]
+            if kind == "mean" and len(hops) != self._end - self._start:
+                # the reference divides by (end - start) whatever the slice held (mean_message_op.py:10)
+                total = reduce_hops("sum", hops)
+                # a 0-dim DEVICE divisor: torch's GPU kernel turns division by a host scalar into a multiplication by
+                # its reciprocal, which is not the reference's (CPU) true division in the last bit
+                return total / torch.tensor(float(self._end - self._start), device=total.device)
+            return reduce_hops(kind, hops)
+
+        def fused_spec(self, n_hops):
+            if kind not in ("sum", "mean") or not (isinstance(self._start, int) and isinstance(self._end, int)):
+                return None
+            if self._start < 0 or self._end <= self._start:
+                return None
+            spec = {"kind": kind, "start": self._start, "end": self._end}
+            if kind == "mean":
+                spec["divisor"] = self._end - self._start
+            return spec
 
     _Op.__name__ = _Op.__qualname__ = kind.capitalize() + "MessageOp"
     _Op.__doc__ = doc

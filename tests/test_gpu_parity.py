@@ -576,6 +576,51 @@ def test_simple_aggregators_bit_exact(goldens, cuda):
     assert not y.is_cuda and np.array_equal(y.numpy(), g3["mean|0_5"])
 
 
+@pytest.mark.parametrize("d", [100, 147, 7, 64])
+def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
+    """GraphOp.propagate_reduce (sgl_spmm_acc_f32: the running aggregate updated where each row is produced) against
+    aggregate(propagate(...)): bit-identical for last / sum / mean / simple_weighted, any hop range, also when long rows
+    are split (fix-up path) and when the range ends before the last hop."""
+    from sgl_amd.operators import message_op as m
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    a = long_row_graph(n=1600, seed=9)
+    a = (a + a.T).tocsr()
+    a.data[:] = 1.0
+    x = hash_matrix(a.shape[0], d, seed=3)
+    K = 4
+    ops = [m.LastMessageOp(), m.SumMessageOp(0, K + 1), m.SumMessageOp(1, 4), m.SumMessageOp(2, 3), m.MeanMessageOp(0, K + 1),
+           m.MeanMessageOp(1, K + 1), m.MeanMessageOp(0, 10), m.MeanMessageOp(K, K + 1),
+           m.SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85), m.SimpleWeightedMessageOp(1, K + 1, "alpha", 0.3),
+           m.SimpleWeightedMessageOp(0, 3, "hand_crafted", [0.5, -0.25, 2.0])]
+    for gop in (LaplacianGraphOp(K, r=0.5), PprGraphOp(K, r=0.3, alpha=0.2), LaplacianGraphOp(K, r=0.5, strict_order=True)):
+        hops = gop.propagate(a, x)
+        for op in ops:
+            spec = op.fused_spec(K + 1)
+            assert spec is not None, op
+            fused = gop.propagate_reduce(a, x, **spec)
+            want = op.aggregate(hops)
+            assert fused.shape == want.shape and torch.equal(fused, want), (type(op).__name__, op._start, op._end, d)
+    # ops that cannot ride on the SpMM say so; weird ranges fall back
+    assert m.MaxMessageOp(0, 3).fused_spec(5) is None and m.ConcatMessageOp(0, 3).fused_spec(5) is None
+    assert gop.propagate_reduce(a, x, kind="sum", start=3, end=2) is None
+    # the reference's exceptions come first, exactly as in propagate()
+    with pytest.raises(TypeError):
+        gop.propagate_reduce(a.tocoo(), x, kind="sum")
+    # end to end through a model: the aggregate is the same tensor, the hop list is simply not kept
+    from sgl_amd import config
+    from sgl_amd.models.homo import SGC, SSGC
+    for cls, args in ((SGC, (3, d, 5)), (SSGC, (3, d, 5))):
+        config.fuse_aggregate = True
+        mf = cls(*args)
+        mf.preprocess(a, x)
+        config.fuse_aggregate = False
+        mu = cls(*args)
+        mu.preprocess(a, x)
+        config.fuse_aggregate = True
+        assert mf._processed_feat_list is None and len(mu._processed_feat_list) == 4
+        assert torch.equal(mf._processed_feature, mu._processed_feature), cls.__name__
+
+
 def test_max_min_propagate_nan_like_torch(cuda):
     from sgl_amd.operators import message_op as m
     a = torch.tensor([[1.0, float("nan"), -2.0, 5.0]] * 3, device=cuda)
