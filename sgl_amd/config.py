@@ -9,6 +9,8 @@ strict_types  True  -> reject torch.Tensor features / non-float32 input with the
 strict_order  True  -> SpMM walks every row as ONE sequential fmaf chain (bit-exact with the reference's
                        matmul.c:23-40 order); False -> fastest lane layout (same result within 1e-5)
 cache_adj     reuse the normalised device adjacency across propagate() calls on the same scipy matrix
+slab_hops     GraphOp.propagate writes hop k into column slice k of ONE [N, (K+1) d] buffer (when d % 4 == 0), so that
+              ConcatMessageOp over consecutive hops is a zero-copy view of it instead of a copy of every hop
 fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / simple_weighted aggregation into the SpMM epilogue
               (GraphOp.propagate_reduce): no pass over the hop matrices, only two hop buffers alive; the K+1 hop list
               (`_processed_feat_list`) is then not kept (the reference's own consumers never read it for these ops)
@@ -29,3 +31,4 @@ strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
 strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
 cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
 fuse_aggregate = _env_bool("SGL_AMD_FUSE_AGGREGATE", True)
+slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)

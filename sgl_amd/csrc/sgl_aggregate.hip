@@ -194,6 +194,47 @@ __global__ __launch_bounds__(256) void hop_rowdot_kernel(const Hops hx, const in
     }
 }
 
+// The same with the H hop vectors of the row in registers: dOut is loaded once (not once per hop), the H x loads are in
+// flight together and the H butterflies interleave.  d <= LPR * 4 * CH, H <= HMAX.
+template <int LPR, int CH, int HMAX>
+__global__ __launch_bounds__(256) void hop_rowdot_reg_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
+                                                             const int64_t ldg, float *__restrict__ dw, const int64_t lddw,
+                                                             const int64_t n, const int d) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    f4 gv[CH], xv[HMAX][CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 4;
+        const bool on = live && col < d;
+        gv[c] = on ? load_masked<4>(g + r * ldg, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            xv[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    float acc[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        acc[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[h] = __builtin_fmaf(gv[c][e], xv[h][c][e], acc[h]);
+    }
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1)
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) acc[h] += __shfl_xor(acc[h], off, 64);
+    if (live && l == 0) {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) dw[r * lddw + h] = acc[h];
+    }
+}
+
 // NAFS weights: W[n,h] = softmax_h( <X0,Xh> / (|Xh|+1e-10) / (|X0|+1e-10) )   (over_smooth_distance_op.py:12-22)
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const int n_hops, float *__restrict__ wout,
@@ -362,6 +403,40 @@ __global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const in
     }
 }
 
+// The same for ANY d (d % 4 != 0: the hops' segments start at arbitrary 4-byte offsets of the output row): one thread per
+// ALIGNED 16-byte vector of the output row; its four floats are consecutive in one source row except where the vector
+// straddles a hop boundary, so they are fetched with one dword-aligned 16-byte load (legal on gfx950: vector memory
+// accesses only need dword alignment) or, at the boundaries, element by element.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+                                                             const int64_t ldo, const int64_t n, const int d) {
+    const int width = d * n_hops;
+    const int vecs = (width + 3) / 4;
+    const int64_t total = n * (int64_t)vecs;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / vecs;
+        const int c = (int)(i - row * vecs) * 4;
+        const int h = c / d;
+        const int k = c - h * d;
+        float *op = out + row * ldo + c;
+        if (k + 4 <= d) {
+            const f4u v = *reinterpret_cast<const f4u *>(hx.p[h] + row * hx.ld[h] + k);
+            *reinterpret_cast<f4 *>(op) = (f4){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ce = c + e;
+                if (ce < width) {
+                    const int he = ce / d;
+                    op[e] = hx.p[he][row * hx.ld[he] + (ce - he * d)];
+                }
+            }
+        }
+    }
+}
+
 // dw[h] = sum_{n,k} dOut[n,k] X_h[n,k]: per-block partials, then a sequential (deterministic) second level
 constexpr int kW1dBlocks = 1024;
 
@@ -505,6 +580,29 @@ template <int VEC>
 static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t st, const Hops &hx, int n_hops,
                           const float *g, int64_t ldg, float *dw, int64_t lddw, int64_t n, int d) {
     (void)grid_rows_per_block_unused;
+    if constexpr (VEC == 4) {
+        // the row's H hop vectors fit in registers: one load of dOut, all loads in flight, interleaved butterflies
+        const int ch = (d > lpr * 4) ? 2 : 1;
+        if (n_hops <= 16 && d <= lpr * 4 * ch) {
+            const unsigned grid = (unsigned)((n + (256 / lpr) - 1) / (256 / lpr));
+#define SGL_RR(L, C, HM) \
+    hipLaunchKernelGGL((hop_rowdot_reg_kernel<L, C, HM>), dim3(grid), dim3(256), 0, st, hx, n_hops, g, ldg, dw, lddw, n, d)
+#define SGL_RR_H(L, C)                                 \
+    do {                                               \
+        if (n_hops <= 4) SGL_RR(L, C, 4);              \
+        else if (n_hops <= 8) SGL_RR(L, C, 8);         \
+        else SGL_RR(L, C, 16);                         \
+    } while (0)
+            if (ch == 2) SGL_RR_H(64, 2);
+            else if (lpr == 8) SGL_RR_H(8, 1);
+            else if (lpr == 16) SGL_RR_H(16, 1);
+            else if (lpr == 32) SGL_RR_H(32, 1);
+            else SGL_RR_H(64, 1);
+#undef SGL_RR_H
+#undef SGL_RR
+            return;
+        }
+    }
 #define SGL_RD(L)                                                                                              \
     hipLaunchKernelGGL((hop_rowdot_kernel<L, VEC>), dim3((unsigned)((n + (256 / L) - 1) / (256 / L))), dim3(256), 0, st, \
                        hx, n_hops, g, ldg, dw, lddw, n, d)
@@ -628,11 +726,17 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
     if (n == 0 || d == 0) return SGL_OK;
     SGL_REQUIRE(d_out && ldo >= d * n_hops, "sgl_hop_concat_f32: bad output");
     hipStream_t st = sgl::as_stream(stream);
-    const int grid = stream_grid(n * (d / (vec4 ? 4 : 1)) * n_hops);
-    if (vec4)
+    const bool out16 = (ldo % 4 == 0) && aligned_to(d_out, 16) && d * n_hops < INT32_MAX;
+    if (vec4) {
+        const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
-    else
+    } else if (out16) {   // any d: aligned 16-byte stores, dword-aligned 16-byte loads
+        const int grid = stream_grid(n * ((d * n_hops + 3) / 4));
+        hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    } else {
+        const int grid = stream_grid(n * d * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    }
     SGL_LAUNCH_CHECK("sgl_hop_concat_f32");
     return SGL_OK;
 }

@@ -57,7 +57,8 @@ def _lib_reduce(kind):
 
 
 class GraphOp:
-    def __init__(self, prop_steps, device=None, host_output=None, strict_types=None, strict_order=None, cache_adj=None):
+    def __init__(self, prop_steps, device=None, host_output=None, strict_types=None, strict_order=None, cache_adj=None,
+                 slab_hops=None):
         self._prop_steps = prop_steps
         self._adj = None
         self._device = device
@@ -65,6 +66,7 @@ class GraphOp:
         self._strict_types = strict_types
         self._strict_order = strict_order
         self._cache_adj = cache_adj
+        self._slab_hops = slab_hops
         self._adj_key = None
 
     # ---- effective settings (ctor kwarg, else sgl_amd.config) ------------------------------------
@@ -180,8 +182,17 @@ class GraphOp:
         cur = self._device_features(feature)
         # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns
         # are zeros and stay zeros under propagation)
-        src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
         d = cur.shape[1]
+        K = self._prop_steps
+        if self._opt("slab_hops") and d % 4 == 0 and K >= 1 and not self._opt("host_output"):
+            # concat-as-layout: hop k is produced directly in column slice k of one [n, (K+1) d] slab (the kernel takes
+            # leading dimensions), so ConcatMessageOp over consecutive hops is a view of it -- no copy of any hop
+            slab = torch.empty((cur.shape[0], (K + 1) * d), dtype=torch.float32, device=device)
+            views = [slab[:, k * d:(k + 1) * d] for k in range(K + 1)]
+            views[0].copy_(cur)
+            self._adj.spmm_chain(views[0], K, outs=views[1:])
+            return views
+        src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
         prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
 
         if self._opt("host_output"):

@@ -33,8 +33,30 @@ class ConcatMessageOp(MessageOp):
         super(ConcatMessageOp, self).__init__(start, end)
         self._aggr_type = "concat"
 
+    @staticmethod
+    def _slab_view(feats):
+        """the hops side by side in one buffer already (GraphOp slab_hops layout)?  Then their concatenation is a view."""
+        f0 = feats[0]
+        if not (torch.is_tensor(f0) and f0.dim() == 2 and f0.shape[0] > 0):
+            return None
+        n, d = f0.shape
+        base = f0.untyped_storage().data_ptr()
+        for k, f in enumerate(feats):
+            if not (torch.is_tensor(f) and f.shape == f0.shape and f.dtype == f0.dtype and f.device == f0.device
+                    and f.untyped_storage().data_ptr() == base and f.stride() == f0.stride() and f.stride(1) == 1
+                    and f.storage_offset() == f0.storage_offset() + k * d):
+                return None
+        if n > 1 and f0.stride(0) < len(feats) * d:
+            return None
+        return torch.as_strided(f0, (n, len(feats) * d), (f0.stride(0), 1), f0.storage_offset())
+
     def _combine(self, feat_list):
-        feats, home = device_hops(feat_list[self._start:self._end])
+        hops = feat_list[self._start:self._end]
+        if len(hops) > 1 and not (torch.is_grad_enabled() and any(f.requires_grad for f in hops)):
+            view = self._slab_view(hops)
+            if view is not None:
+                return view
+        feats, home = device_hops(hops)
         no_grad_inputs(feats, "concat")
         return back_home(dev.hop_concat(feats), home)
 

@@ -621,6 +621,31 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
         assert torch.equal(mf._processed_feature, mu._processed_feature), cls.__name__
 
 
+def test_slab_hops_make_concat_a_view(goldens, cuda):
+    """slab_hops: hop k is produced in column slice k of ONE [n, (K+1) d] buffer; the hops are bit-identical to the
+    separate-buffer propagation and ConcatMessageOp over consecutive hops returns a zero-copy view of the slab"""
+    from sgl_amd.operators import message_op as m
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g = goldens.graph("pl2000")
+    for d in (100, 16, 147):
+        x = hash_matrix(g.shape[0], d, seed=4)
+        K = 3
+        plain = LaplacianGraphOp(K).propagate(g, x)
+        slab = LaplacianGraphOp(K, slab_hops=True).propagate(g, x)
+        assert all(torch.equal(a, b) for a, b in zip(plain, slab))
+        cat = m.ConcatMessageOp(0, K + 1).aggregate(slab)
+        want = torch.hstack(plain)
+        assert torch.equal(cat, want)
+        same_storage = cat.untyped_storage().data_ptr() == slab[0].untyped_storage().data_ptr()
+        assert same_storage == (d % 4 == 0)             # d % 4 != 0: separate padded buffers, concat copies (any-width kernel)
+        part = m.ConcatMessageOp(1, 3).aggregate(slab)
+        assert torch.equal(part, torch.hstack(plain[1:3]))
+        if d % 4 == 0:
+            assert part.untyped_storage().data_ptr() == slab[0].untyped_storage().data_ptr()
+        # hops out of order / from different propagations are copied as before
+        assert torch.equal(m.ConcatMessageOp(0, 2).aggregate([slab[2], slab[0]]), torch.hstack([plain[2], plain[0]]))
+
+
 def test_max_min_propagate_nan_like_torch(cuda):
     from sgl_amd.operators import message_op as m
     a = torch.tensor([[1.0, float("nan"), -2.0, 5.0]] * 3, device=cuda)

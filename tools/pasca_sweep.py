@@ -12,7 +12,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sgl_amd import device as dev, synthetic  # noqa: E402
+from sgl_amd.io import DeviceAdjacency  # noqa: E402
 from sgl_amd.operators import message_op as M  # noqa: E402
+from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp  # noqa: E402
 
 
 def timed(fn, reps=3):
@@ -61,6 +63,24 @@ def main():
                 t, _ = timed(lambda: op.aggregate(feats))
             print(f"SWEEP   msg_op={oname:24s} aggregate_ms={t:8.3f}", flush=True)
         del feats, csr
+        # the same aggregates with the aggregation folded into the propagation (round 2): sum / mean / simple_weighted ride
+        # on the SpMM epilogue (GraphOp.propagate_reduce), concat is the layout the hops are produced in (slab_hops)
+        adj = DeviceAdjacency(a_ptr, a_col, a_val, (n, n))
+        gop = LaplacianGraphOp(K, r=r) if alpha is None else PprGraphOp(K, r=r, alpha=alpha)
+        gop.propagate(adj, x0)                      # normalised adjacency cached on the operator from here on
+        t_plain, _ = timed(lambda: gop.propagate(adj, x0))
+        for oname, op in ops[:1] + ops[2:4] + ops[6:7]:
+            t, _ = timed(lambda: gop.propagate_reduce(adj, x0, **op.fused_spec(K + 1)))
+            print(f"SWEEP   fused  {oname:24s} propagate+aggregate_ms={t:8.2f} (propagate alone {t_plain:8.2f}: aggregate adds "
+                  f"{t - t_plain:+.2f} ms)", flush=True)
+        gslab = LaplacianGraphOp(K, r=r, slab_hops=True) if alpha is None else PprGraphOp(K, r=r, alpha=alpha, slab_hops=True)
+        gslab.propagate(adj, x0)
+        t_slab, hops = timed(lambda: gslab.propagate(adj, x0))
+        with torch.no_grad():
+            t_cat, cat = timed(lambda: ops[1][1].aggregate(hops))
+        print(f"SWEEP   slab   concat: propagate_k10_ms={t_slab:8.2f} (separate hop buffers {t_plain:8.2f}) concat_ms={t_cat:8.3f} "
+              f"view={cat.untyped_storage().data_ptr() == hops[0].untyped_storage().data_ptr()}", flush=True)
+        del hops, cat, gop, gslab
 
 
 if __name__ == "__main__":
