@@ -407,10 +407,12 @@ __global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const in
 // ALIGNED 16-byte vector of the output row; its four floats are consecutive in one source row except where the vector
 // straddles a hop boundary, so they are fetched with one dword-aligned 16-byte load (legal on gfx950: vector memory
 // accesses only need dword alignment) or, at the boundaries, element by element.
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 __global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
                                                              const int64_t ldo, const int64_t n, const int d) {
+    // d >= 4.  One thread per aligned 16-byte vector of the output row.  Its floats sit at a dword-aligned position of
+    // ONE source row, except in the vector that straddles a hop boundary (H per row, i.e. in nearly every wavefront:
+    // that path must stay cheap -- no divisions, no element-wise recomputation of the hop index).
     const int width = d * n_hops;
     const int vecs = (width + 3) / 4;
     const int64_t total = n * (int64_t)vecs;
@@ -420,18 +422,36 @@ __global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, cons
         const int c = (int)(i - row * vecs) * 4;
         const int h = c / d;
         const int k = c - h * d;
+        const int rem = d - k;                      // floats of this vector that belong to hop h (>= 1)
+        // two ALIGNED 16-byte loads around the source position and a funnel select (a misaligned 16-byte access is split
+        // by the hardware: measured 0.35 of peak)
+        const float *src = hx.p[h] + row * hx.ld[h];
+        const int sft = k & 3;
+        const int a = k - sft;
+        const f4 v0 = *reinterpret_cast<const f4 *>(src + a);
+        f4 r = v0;
+        if (sft) {
+            f4 v1 = (f4){0.f, 0.f, 0.f, 0.f};
+            if (a + 8 <= hx.ld[h]) v1 = *reinterpret_cast<const f4 *>(src + a + 4);
+            r[0] = (sft == 1) ? v0[1] : (sft == 2) ? v0[2] : v0[3];
+            r[1] = (sft == 1) ? v0[2] : (sft == 2) ? v0[3] : v1[0];
+            r[2] = (sft == 1) ? v0[3] : (sft == 2) ? v1[0] : v1[1];
+            r[3] = (sft == 1) ? v1[0] : (sft == 2) ? v1[1] : v1[2];
+        }
         float *op = out + row * ldo + c;
-        if (k + 4 <= d) {
-            const f4u v = *reinterpret_cast<const f4u *>(hx.p[h] + row * hx.ld[h] + k);
-            *reinterpret_cast<f4 *>(op) = (f4){v[0], v[1], v[2], v[3]};
+        if (rem >= 4) {
+            *reinterpret_cast<f4 *>(op) = r;
         } else {
+            if (h + 1 < n_hops) {                   // the tail of the vector is the head of the next hop's row
+                const float *nx = hx.p[h + 1] + row * hx.ld[h + 1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ce = c + e;
-                if (ce < width) {
-                    const int he = ce / d;
-                    op[e] = hx.p[he][row * hx.ld[he] + (ce - he * d)];
-                }
+                for (int e = 1; e < 4; ++e)
+                    if (e >= rem) r[e] = nx[e - rem];
+                *reinterpret_cast<f4 *>(op) = r;
+            } else {                                // last vector of the row: only the floats inside the row
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < rem) op[e] = r[e];
             }
         }
     }
@@ -471,6 +491,13 @@ __global__ void hop_dot_final_kernel(const float *__restrict__ scratch, const in
 }
 
 bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename H>
+bool vec4_rows(const H &hx, int n_hops) {   // every hop matrix has 16-byte aligned rows (pitch % 4 == 0)
+    for (int h = 0; h < n_hops; ++h)
+        if (hx.ld[h] % 4 != 0 || !aligned_to(hx.p[h], 16)) return false;
+    return true;
+}
 
 int fill_hops(Hops &hx, int n_hops, const float *const *h_x, const int64_t *h_ldx, int64_t d, bool &vec4) {
     if (n_hops < 1 || n_hops > SGL_MAX_HOPS) return sgl::fail(SGL_ERR_INVALID, "n_hops=%d outside [1,%d]", n_hops, SGL_MAX_HOPS);
@@ -582,7 +609,12 @@ static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t s
     (void)grid_rows_per_block_unused;
     if constexpr (VEC == 4) {
         // the row's H hop vectors fit in registers: one load of dOut, all loads in flight, interleaved butterflies
-        const int ch = (d > lpr * 4) ? 2 : 1;
+        int ch = (d > lpr * 4) ? 2 : 1;
+        const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;   // 2 rows per wavefront
+        if (two_rows) {
+            lpr = 32;
+            ch = 2;
+        }
         if (n_hops <= 16 && d <= lpr * 4 * ch) {
             const unsigned grid = (unsigned)((n + (256 / lpr) - 1) / (256 / lpr));
 #define SGL_RR(L, C, HM) \
@@ -593,7 +625,8 @@ static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t s
         else if (n_hops <= 8) SGL_RR(L, C, 8);         \
         else SGL_RR(L, C, 16);                         \
     } while (0)
-            if (ch == 2) SGL_RR_H(64, 2);
+            if (two_rows) SGL_RR_H(32, 2);
+            else if (ch == 2) SGL_RR_H(64, 2);
             else if (lpr == 8) SGL_RR_H(8, 1);
             else if (lpr == 16) SGL_RR_H(16, 1);
             else if (lpr == 32) SGL_RR_H(32, 1);
@@ -730,7 +763,7 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
     if (vec4) {
         const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
-    } else if (out16) {   // any d: aligned 16-byte stores, dword-aligned 16-byte loads
+    } else if (out16 && d >= 4 && vec4_rows(hx, n_hops)) {   // any d: aligned 16-byte stores, aligned 16-byte loads + select
         const int grid = stream_grid(n * ((d * n_hops + 3) / 4));
         hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
     } else {
@@ -759,15 +792,18 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     const bool out_vec4 = d_out && (ldo % 4 == 0) && aligned_to(d_out, 16);
     if (vec4 && out_vec4 && n_hops <= 16 && d <= 512 && sgl::tuning("nafs_fused", 1) != 0) {
         const int ch = (d > lpr * 4) ? 2 : 1;
+        const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;   // 2 rows per wavefront
+        const int64_t nblocks = two_rows ? (n + 7) / 8 : blocks;
 #define SGL_NF(L, C, HM) \
-    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d)
+    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d)
 #define SGL_NF_H(L, C)                                 \
     do {                                               \
         if (n_hops <= 4) SGL_NF(L, C, 4);              \
         else if (n_hops <= 8) SGL_NF(L, C, 8);         \
         else SGL_NF(L, C, 16);                         \
     } while (0)
-        if (ch == 2) SGL_NF_H(64, 2);
+        if (two_rows) SGL_NF_H(32, 2);
+        else if (ch == 2) SGL_NF_H(64, 2);
         else if (lpr == 8) SGL_NF_H(8, 1);
         else if (lpr == 16) SGL_NF_H(16, 1);
         else if (lpr == 32) SGL_NF_H(32, 1);

@@ -490,6 +490,13 @@ class _WSum2D(torch.autograd.Function):
         g = gout.detach().to(torch.float32)
         if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
             g = g.contiguous()
+        if n > 1 and d > 4 and (g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0):
+            # autograd hands over a dense [n, d] gradient: for d % 4 != 0 its rows are not 16-byte aligned and the row-dot
+            # would fall back to 4-byte lanes (measured 0.36 of peak at d = 147); one copy into a padded buffer restores
+            # the 16-byte path for all H hop reads
+            gp = alloc_rows(n, d, g.device)
+            gp.copy_(g)
+            g = gp
         need_w = ctx.needs_input_grad[0]
         need_x = [ctx.needs_input_grad[1 + h] for h in range(H)]
         dw = torch.empty((n, H), dtype=torch.float32, device=g.device) if need_w else None

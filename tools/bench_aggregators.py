@@ -30,6 +30,8 @@ def timeit(fn, reps=7, warm=2):
 
 def main():
     n = int(os.environ.get("AGG_N", 2_449_029))
+    if os.environ.get("AGG_LPR32X2"):
+        _lib.set_tuning("row_lpr32x2", int(os.environ["AGG_LPR32X2"]))
     if os.environ.get("AGG_BLOCKS"):
         _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)
