@@ -97,6 +97,8 @@ int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz,
                    const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
                    int32_t long_row_nnz, void *stream);
 int sgl_csr_destroy(sgl_csr_t *csr);
+/* swap the value array (same sparsity structure, hence same plan): caller-owned, must outlive the handle */
+int sgl_csr_set_values(sgl_csr_t *csr, const float *d_val);
 /* info[0]=n_rows [1]=n_cols [2]=nnz [3]=n_items [4]=n_pieces [5]=n_long_rows [6]=flags [7]=workspace bytes */
 int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
 

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "sgl_csr_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_uint32,
                                c_int32, c_int32, c_void_p]),
     "sgl_csr_destroy": (c_int, [c_void_p]),
+    "sgl_csr_set_values": (c_int, [c_void_p, c_void_p]),
     "sgl_csr_info": (c_int, [c_void_p, POINTER(c_int64)]),
     "sgl_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sgl_spmm_tail_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

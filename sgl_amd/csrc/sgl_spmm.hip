@@ -639,6 +639,15 @@ SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
     return SGL_OK;
 }
 
+// Same structure, new values: the plan depends on the row pointers only, so re-weighting the matrix (another r of the
+// NAFS ensemble, another alpha of a PPR sweep: sgl/tasks/node_clustering.py:205-217) needs no new plan.
+SGL_EXPORT int sgl_csr_set_values(sgl_csr_t *h, const float *d_val) {
+    if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_set_values: NULL handle");
+    SGL_REQUIRE(h->nnz == 0 || d_val, "sgl_csr_set_values: NULL values");
+    h->d_val = d_val;
+    return SGL_OK;
+}
+
 SGL_EXPORT int sgl_csr_info(const sgl_csr_t *h, int64_t info[8]) {
     if (!h || !info) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_info: NULL");
     info[0] = h->n_rows;

@@ -131,6 +131,14 @@ class DeviceCSR:
         val = torch.from_numpy(adj.data.astype(np.float32)).to(device)
         return cls(rowptr, col, val, adj.shape, **kw)
 
+    def set_values(self, val):
+        """same sparsity structure, new values (another normalisation of the same graph): the execution plan is kept"""
+        if not (val.is_cuda and val.dtype == torch.float32 and val.dim() == 1 and val.is_contiguous() and val.numel() == self.nnz):
+            raise TypeError("val must be a contiguous float32 CUDA tensor with one entry per non-zero")
+        check(lib().sgl_csr_set_values(self._h, ptr(val)), "sgl_csr_set_values")
+        self.val = val
+        return self
+
     def info(self):
         a = (c_int64 * 8)()
         check(lib().sgl_csr_info(self._h, a), "sgl_csr_info")

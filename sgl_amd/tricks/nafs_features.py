@@ -4,14 +4,16 @@ Reference: NodeClusteringNAFS._k_hop_cluster (sgl/tasks/node_clustering.py:205-2
 tasks/link_prediction.py:233-284: for every r in r_list normalise the adjacency (D^{r-1}(A+I)^T D^{-r}), propagate
 `hops` times with torch.spmm, weight the hops per node by softmax(cosine similarity to hop 0) -- an O(N * hops)
 Python loop in the reference -- and finally ensemble the per-r results (mean / max / concat; 'simple' = plain
-hops-step propagation with the first r).  Here: device normalisation + k HIP SpMMs + the fused NAFS kernel per r,
-and one streaming reduction kernel for the ensemble; nothing leaves HBM."""
+hops-step propagation with the first r).  Here the raw adjacency is uploaded ONCE; every r is normalised from that
+device copy (sgl_norm_*), re-using one SpMM plan (the sparsity structure does not depend on r: sgl_csr_set_values) and
+one set of hop buffers; the fused NAFS kernel reads each hop of an r exactly once, and one streaming reduction kernel
+forms the ensemble.  Nothing but the first upload crosses PCIe."""
 import scipy.sparse as sp
 import torch
 
 from .. import _lib
 from .. import device as dev
-from ..operators.utils import adj_to_symmetric_norm_device
+from ..io import DeviceAdjacency
 
 _METHODS = ("mean", "max", "concat", "simple")
 
@@ -24,23 +26,30 @@ def nafs_ensemble_features(adj, x, hops, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), me
     method = method.lower()
     if method not in _METHODS:
         raise ValueError("Method not Suppoted! Choose 'mean', 'max' or 'concat' !")
-    if not sp.issparse(adj):
-        raise TypeError("adj must be a scipy sparse matrix")
+    if not (sp.issparse(adj) or isinstance(adj, DeviceAdjacency)):
+        raise TypeError("adj must be a scipy sparse matrix (or a DeviceAdjacency already on the GPU)")
     _lib.require_gpu()
     device = torch.device(device)
+    dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=device)   # the only H2D
+    n = dadj.shape[0]
     x0 = dev.upload_rows(x, device)
+    d = x0.shape[1]
+    hop_bufs = [dev.alloc_rows(n, d, device) for _ in range(hops)]                  # shared by all r
+    csr = None
     per_r = []
     for r in r_list:
-        rowptr, col, val = adj_to_symmetric_norm_device(adj, r, None, device=device)
-        csr = dev.DeviceCSR(rowptr, col, val, adj.shape, strict=strict_order)
+        rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, r, None)
+        if csr is None:
+            csr = dev.DeviceCSR(rowptr, col, val, dadj.shape, strict=strict_order)  # one plan: the structure is r-independent
+        else:
+            csr.set_values(val)
         feats = [x0]
-        for _ in range(hops):
-            y = csr.spmm(dev.padded_parent(feats[-1]))
-            feats.append(y[:, :x0.shape[1]] if y.shape[1] != x0.shape[1] else y)
+        for h in range(hops):
+            csr.spmm(dev.padded_parent(feats[-1]), out=dev.padded_parent(hop_bufs[h]))
+            feats.append(hop_bufs[h])
         if method == "simple":
             return feats[-1]
         per_r.append(dev.nafs_aggregate(feats))
-        del csr, feats
     if method == "mean":
         return dev.hop_reduce(_lib.SGL_REDUCE_MEAN, per_r)
     if method == "max":

@@ -889,6 +889,19 @@ def test_nafs_task_feature_pipeline_matches_reference(goldens, cuda):
         assert rep["ok"], (method, rep)
     with pytest.raises(ValueError):
         nafs_ensemble_features(g, x, 3, method="median")
+    # the adjacency already on the device: identical result, and nothing of it crosses PCIe again (one upload serves all r;
+    # the per-r normalisations re-use one SpMM plan through sgl_csr_set_values)
+    from sgl_amd.io import DeviceAdjacency
+    dadj = DeviceAdjacency.from_scipy(g, device=cuda)
+    y_host = nafs_ensemble_features(g, x, 3, [0.5, 0.3, 0], "mean")
+    assert torch.equal(nafs_ensemble_features(dadj, torch.from_numpy(x).to(cuda), 3, [0.5, 0.3, 0], "mean"), y_host)
+    n, ptr, col, val = norm_graph(goldens, "pl256", r=0.5)
+    csr = device_csr(ptr, col, val, (n, n), cuda)
+    xd = torch.from_numpy(x).to(cuda)
+    y1 = csr.spmm(xd)
+    _, _, _, val2 = norm_graph(goldens, "pl256", r=0.2)
+    v2 = torch.from_numpy(val2).to(cuda)
+    assert torch.equal(csr.set_values(v2).spmm(xd), device_csr(ptr, col, val2, (n, n), cuda).spmm(xd)) and not torch.equal(y1, csr.spmm(xd))
 
 
 def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
