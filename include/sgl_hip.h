@@ -163,6 +163,11 @@ void FloatCSRMulDenseOMP(float answer[], float data[], int indices[], int indptr
 int FloatCSRMulDense(float answer[], int data_nnz, float data[], int indices[], int indptr[], float mat[],
                      int mat_row, int mat_col);
 
+/* The shims keep the uploaded adjacency, its plan and all device / pinned buffers between calls and re-use them when the
+ * next call passes the bit-identical CSR (the reference calls the symbol K times per propagate() with the same matrix):
+ * counters of calls served from / not served from that cache. */
+int sgl_shim_cache_stats(int64_t *hits, int64_t *misses);
+
 /* ---- normalisation on device (adj_to_symmetric_norm, operators/utils.py:76-88) ----------------------------- */
 /* Input: canonical CSR of A (sorted columns, no duplicates), n x n, values fp32, on device.
  * Output: canonical CSR of  A_hat = D^{r-1} (A+I)^T D^{-r}   [then (1-alpha) A_hat + alpha I when use_alpha != 0]

@@ -50,6 +50,7 @@ PROTOTYPES = {
                                  c_float, c_void_p]),
     "FloatCSRMulDenseOMP": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "FloatCSRMulDense": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "sgl_shim_cache_stats": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "sgl_norm_prepare": (c_int, [c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
     "sgl_norm_execute": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -4,20 +4,179 @@
 // (the reference calls are, too).  The device-resident API (sgl_csr_create / sgl_spmm_f32) is the fast path.
 #include "sgl_common.h"
 
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+// The unmodified reference calls the CPU symbol K times per propagate() with the SAME adjacency (base_op.py:29-35) and fresh
+// `answer` / `mat` arrays (utils.py:31-35).  So: the uploaded CSR, its execution plan and every device / pinned buffer are
+// kept between calls and re-used when the adjacency is bit-for-bit the one of the previous call (pointers for indptr /
+// indices, full multi-threaded checksums for indptr, indices AND data -- utils.py:32 makes a new float32 copy of `data`
+// on every call, so its address never repeats); the dense operands travel through pinned staging buffers filled by a
+// team of host threads, each with its own stream, instead of one pageable hipMemcpy.
+
 namespace {
+
+constexpr size_t kChunk = (size_t)32 << 20;   // staging granularity
+constexpr int kMaxThreads = 16;
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() {
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
         if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
     }
-    int alloc(size_t bytes) {
+    int reserve(size_t bytes) {
         if (bytes == 0) bytes = 4;
+        if (bytes <= cap) return SGL_OK;
+        release();
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return sgl::fail((int)e, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
         return SGL_OK;
     }
 };
+
+int team_size() {
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc == 0) hc = 4;
+    return (int)std::min<unsigned>(kMaxThreads, std::max<unsigned>(1, hc / 2));
+}
+
+template <typename F>
+void run_team(int threads, F fn) {
+    std::vector<std::thread> team;
+    for (int t = 1; t < threads; ++t) team.emplace_back(fn, t);
+    fn(0);
+    for (auto &th : team) th.join();
+}
+
+// order-sensitive 64-bit content hash, computed by a team of threads over fixed 1 MiB blocks (so the result does not
+// depend on the number of threads)
+uint64_t content_hash(const void *p, size_t bytes, int threads) {
+    constexpr size_t kBlock = (size_t)1 << 20;
+    const size_t blocks = (bytes + kBlock - 1) / kBlock;
+    std::vector<uint64_t> part(blocks, 0);
+    std::atomic<size_t> next(0);
+    run_team(threads, [&](int) {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= blocks) break;
+            const unsigned char *q = (const unsigned char *)p + b * kBlock;
+            const size_t len = std::min(kBlock, bytes - b * kBlock);
+            uint64_t h0 = 0x9E3779B97F4A7C15ull ^ b, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
+            size_t i = 0;
+            for (; i + 32 <= len; i += 32) {
+                uint64_t w[4];
+                memcpy(w, q + i, 32);
+                h0 = (h0 ^ w[0]) * 0x100000001B3ull;
+                h1 = (h1 ^ w[1]) * 0x100000001B3ull;
+                h2 = (h2 ^ w[2]) * 0x100000001B3ull;
+                h3 = (h3 ^ w[3]) * 0x100000001B3ull;
+            }
+            for (; i < len; ++i) h0 = (h0 ^ q[i]) * 0x100000001B3ull;
+            uint64_t h = h0 ^ (h1 << 1 | h1 >> 63) ^ (h2 << 2 | h2 >> 62) ^ (h3 << 3 | h3 >> 61);
+            h ^= h >> 29;
+            part[b] = h * 0xBF58476D1CE4E5B9ull;
+        }
+    });
+    uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)bytes;
+    for (size_t b = 0; b < blocks; ++b) h = (h ^ part[b]) * 0x100000001B3ull;
+    return h;
+}
+
+bool all_zero(const void *p, size_t bytes, int threads) {
+    constexpr size_t kBlock = (size_t)4 << 20;
+    const size_t blocks = (bytes + kBlock - 1) / kBlock;
+    std::atomic<size_t> next(0);
+    std::atomic<bool> nonzero(false);
+    run_team(threads, [&](int) {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= blocks || nonzero.load(std::memory_order_relaxed)) break;
+            const unsigned char *q = (const unsigned char *)p + b * kBlock;
+            const size_t len = std::min(kBlock, bytes - b * kBlock);
+            uint64_t acc = 0;
+            size_t i = 0;
+            for (; i + 8 <= len; i += 8) {
+                uint64_t w;
+                memcpy(&w, q + i, 8);
+                acc |= w;                       // -0.0f has a bit set: it is NOT "zero" here, the upload then happens
+            }
+            for (; i < len; ++i) acc |= q[i];
+            if (acc) nonzero.store(true, std::memory_order_relaxed);
+        }
+    });
+    return !nonzero.load();
+}
+
+struct Shim {
+    std::mutex mu;
+    // cached adjacency
+    const void *indptr_p = nullptr, *indices_p = nullptr;
+    int64_t n = -1, nnz = -1;
+    uint64_t h_indptr = 0, h_indices = 0, h_data = 0;
+    sgl_csr_t *handle = nullptr;
+    DevBuf d_rp, d_col, d_val, d_x, d_y;
+    // staging
+    void *pinned[kMaxThreads] = {};
+    hipStream_t streams[kMaxThreads] = {};
+    int staged_threads = 0;
+    int64_t hits = 0, misses = 0;
+
+    void drop_graph() {
+        if (handle) sgl_csr_destroy(handle);
+        handle = nullptr;
+        indptr_p = indices_p = nullptr;
+        n = nnz = -1;
+    }
+    int ensure_staging(int threads) {
+        for (int t = staged_threads; t < threads; ++t) {
+            SGL_HIP_CHECK(hipHostMalloc(&pinned[t], kChunk, hipHostMallocDefault));
+            SGL_HIP_CHECK(hipStreamCreateWithFlags(&streams[t], hipStreamNonBlocking));
+            staged_threads = t + 1;
+        }
+        return SGL_OK;
+    }
+    // host <-> device through the pinned buffers: chunk c is handled end to end by thread c % threads on its own stream
+    int copy(void *dev, void *host, size_t bytes, bool to_device, int threads) {
+        if (bytes == 0) return SGL_OK;
+        int rc = ensure_staging(threads);
+        if (rc != SGL_OK) return rc;
+        const size_t chunks = (bytes + kChunk - 1) / kChunk;
+        std::atomic<int> err((int)hipSuccess);
+        run_team(std::min<size_t>(threads, chunks), [&](int t) {
+            for (size_t c = t; c < chunks; c += threads) {
+                const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+                hipError_t e;
+                if (to_device) {
+                    memcpy(pinned[t], (const char *)host + off, len);
+                    e = hipMemcpyAsync((char *)dev + off, pinned[t], len, hipMemcpyHostToDevice, streams[t]);
+                    if (e == hipSuccess) e = hipStreamSynchronize(streams[t]);     // the buffer is refilled next
+                } else {
+                    e = hipMemcpyAsync(pinned[t], (const char *)dev + off, len, hipMemcpyDeviceToHost, streams[t]);
+                    if (e == hipSuccess) e = hipStreamSynchronize(streams[t]);
+                    if (e == hipSuccess) memcpy((char *)host + off, pinned[t], len);
+                }
+                if (e != hipSuccess) {
+                    err.store((int)e);
+                    return;
+                }
+            }
+        });
+        if (err.load() != (int)hipSuccess)
+            return sgl::fail(err.load(), "staged copy failed: %s", hipGetErrorString((hipError_t)err.load()));
+        return SGL_OK;
+    }
+};
+
+Shim &shim() {
+    static Shim s;   // lives for the process: the cached device memory is released with the context
+    return s;
+}
 
 int host_spmm(float *answer, const float *data, const int *indices, const int *indptr, const float *mat,
               int mat_row, int mat_col, int accumulate) {
@@ -33,36 +192,58 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
     const int64_t nnz = indptr[n];
     SGL_REQUIRE(nnz >= 0 && indptr[0] == 0, "FloatCSRMulDense*: bad indptr");
     SGL_REQUIRE(nnz == 0 || (data && indices), "FloatCSRMulDense*: NULL data/indices");
-    std::vector<int64_t> rp64((size_t)n + 1);
-    for (int64_t i = 0; i <= n; ++i) rp64[i] = indptr[i];
-
-    DevBuf d_rp, d_col, d_val, d_x, d_y;
+    Shim &S = shim();
+    std::lock_guard<std::mutex> lk(S.mu);
+    const int threads = team_size();
     int rc;
-    if ((rc = d_rp.alloc(rp64.size() * sizeof(int64_t))) != SGL_OK) return rc;
-    if ((rc = d_col.alloc((size_t)nnz * sizeof(int32_t))) != SGL_OK) return rc;
-    if ((rc = d_val.alloc((size_t)nnz * sizeof(float))) != SGL_OK) return rc;
-    if ((rc = d_x.alloc((size_t)n * d * sizeof(float))) != SGL_OK) return rc;
-    if ((rc = d_y.alloc((size_t)n * d * sizeof(float))) != SGL_OK) return rc;
-    SGL_HIP_CHECK(hipMemcpy(d_rp.p, rp64.data(), rp64.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    if (nnz) {
-        SGL_HIP_CHECK(hipMemcpy(d_col.p, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-        SGL_HIP_CHECK(hipMemcpy(d_val.p, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
-    }
-    SGL_HIP_CHECK(hipMemcpy(d_x.p, mat, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice));
-    if (accumulate) SGL_HIP_CHECK(hipMemcpy(d_y.p, answer, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice));
 
-    sgl_csr_t *h = nullptr;
-    // strict order: the shim promises the reference's exact per-row fmaf chain
-    rc = sgl_csr_create(&h, n, n, nnz, (const int64_t *)d_rp.p, (const int32_t *)d_col.p, (const float *)d_val.p,
-                        SGL_CSR_STRICT_ORDER, 0, 0, nullptr);
-    if (rc != SGL_OK) return rc;
-    rc = sgl_spmm_f32(h, (const float *)d_x.p, d, (float *)d_y.p, d, d, accumulate, nullptr);
-    if (rc == SGL_OK) {
-        hipError_t e = hipMemcpy(answer, d_y.p, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = sgl::fail((int)e, "download failed: %s", hipGetErrorString(e));
+    // ---- the adjacency: re-used when it is bit-for-bit the previous call's --------------------------------------------
+    const uint64_t hp = content_hash(indptr, ((size_t)n + 1) * sizeof(int), threads);
+    const uint64_t hi = content_hash(indices, (size_t)nnz * sizeof(int), threads);
+    const uint64_t hd = content_hash(data, (size_t)nnz * sizeof(float), threads);
+    const bool hit = S.handle && S.indptr_p == indptr && S.indices_p == indices && S.n == n && S.nnz == nnz &&
+                     S.h_indptr == hp && S.h_indices == hi && S.h_data == hd;
+    if (!hit) {
+        ++S.misses;
+        S.drop_graph();
+        std::vector<int64_t> rp64((size_t)n + 1);
+        for (int64_t i = 0; i <= n; ++i) rp64[i] = indptr[i];
+        if ((rc = S.d_rp.reserve(rp64.size() * sizeof(int64_t))) != SGL_OK) return rc;
+        if ((rc = S.d_col.reserve((size_t)nnz * sizeof(int32_t))) != SGL_OK) return rc;
+        if ((rc = S.d_val.reserve((size_t)nnz * sizeof(float))) != SGL_OK) return rc;
+        if ((rc = S.copy(S.d_rp.p, rp64.data(), rp64.size() * sizeof(int64_t), true, threads)) != SGL_OK) return rc;
+        if ((rc = S.copy(S.d_col.p, const_cast<int *>(indices), (size_t)nnz * sizeof(int32_t), true, threads)) != SGL_OK) return rc;
+        if ((rc = S.copy(S.d_val.p, const_cast<float *>(data), (size_t)nnz * sizeof(float), true, threads)) != SGL_OK) return rc;
+        // strict order: the shim promises the reference's exact per-row fmaf chain
+        rc = sgl_csr_create(&S.handle, n, n, nnz, (const int64_t *)S.d_rp.p, (const int32_t *)S.d_col.p,
+                            (const float *)S.d_val.p, SGL_CSR_STRICT_ORDER, 0, 0, nullptr);
+        if (rc != SGL_OK) {
+            S.handle = nullptr;
+            return rc;
+        }
+        S.indptr_p = indptr;
+        S.indices_p = indices;
+        S.n = n;
+        S.nnz = nnz;
+        S.h_indptr = hp;
+        S.h_indices = hi;
+        S.h_data = hd;
+    } else {
+        ++S.hits;
     }
-    sgl_csr_destroy(h);
-    return rc;
+
+    // ---- the dense operands ---------------------------------------------------------------------------------------------
+    const size_t dense = (size_t)n * d * sizeof(float);
+    if ((rc = S.d_x.reserve(dense)) != SGL_OK) return rc;
+    if ((rc = S.d_y.reserve(dense)) != SGL_OK) return rc;
+    if ((rc = S.copy(S.d_x.p, const_cast<float *>(mat), dense, true, threads)) != SGL_OK) return rc;
+    int acc = accumulate;
+    if (acc && all_zero(answer, dense, threads)) acc = 0;   // the reference pre-zeroes `answer` (utils.py:31): 0 + A.X = A.X
+    if (acc && (rc = S.copy(S.d_y.p, answer, dense, true, threads)) != SGL_OK) return rc;
+    rc = sgl_spmm_f32(S.handle, (const float *)S.d_x.p, d, (float *)S.d_y.p, d, d, acc, nullptr);
+    if (rc != SGL_OK) return rc;
+    SGL_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return S.copy(S.d_y.p, answer, dense, false, threads);
 }
 
 }  // namespace
@@ -83,4 +264,13 @@ SGL_EXPORT int FloatCSRMulDense(float answer[], int data_nnz, float data[], int 
         return 1;
     }
     return host_spmm(answer, data, indices, indptr, mat, mat_row, mat_col, /*accumulate=*/0) == SGL_OK ? 0 : 1;
+}
+
+// number of calls served from / not served from the cached adjacency (tests, INTEGRATION.md figures)
+SGL_EXPORT int sgl_shim_cache_stats(int64_t *hits, int64_t *misses) {
+    Shim &S = shim();
+    std::lock_guard<std::mutex> lk(S.mu);
+    if (hits) *hits = S.hits;
+    if (misses) *misses = S.misses;
+    return SGL_OK;
 }

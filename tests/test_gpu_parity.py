@@ -395,6 +395,32 @@ def test_reference_signature_shims(goldens, cuda):
         assert np.array_equal(cuda_csr_sparse_dense_matmul(adj, x), ref)
     if oracle.load_reference_lib() is not None:
         assert np.array_equal(csr_sparse_dense_matmul(adj, x), oracle.reference_spmm(ptr, col, val, x))
+    # the K calls of one propagate() pass the same adjacency: uploaded CSR, plan and buffers are re-used (keyed on the
+    # index arrays' addresses AND full content hashes -- the reference makes a fresh float32 copy of `data` per call)
+    import ctypes
+
+    def stats():
+        h, m_ = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().sgl_shim_cache_stats(ctypes.byref(h), ctypes.byref(m_)))
+        return h.value, m_.value
+    h0, m0 = stats()
+    y1 = csr_sparse_dense_matmul(adj, x)
+    y2 = csr_sparse_dense_matmul(adj, y1)                    # hop 2 of a propagate: same matrix, new dense operand
+    h1, m1 = stats()
+    assert h1 - h0 >= 2 and m1 == m0
+    assert np.array_equal(y2, oracle.oracle_spmm(ptr, col, val, ref))
+    adj.data[7] *= 3.0                                       # edited in place: same addresses, different content -> no stale hit
+    val2 = adj.data.astype(np.float32)
+    assert np.array_equal(csr_sparse_dense_matmul(adj, x), oracle.oracle_spmm(ptr, col, val2, x))
+    assert stats()[1] == m1 + 1
+    acc = np.ones((n, x.shape[1]), dtype=np.float32)         # accumulate-into-answer semantics of the CPU symbol (matmul.c:37)
+    lib = _lib.lib()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ip32, ix32 = adj.indptr.astype(np.int32), adj.indices.astype(np.int32)
+    lib.FloatCSRMulDenseOMP(p(acc), p(val2), p(ix32), p(ip32), p(x), n, x.shape[1])
+    want = np.ones_like(acc)
+    oracle.oracle_spmm(ptr, col, val2, x, out=want)
+    assert np.array_equal(acc, want)
 
 
 G1_VARIANTS = [("lap", r, None) for r in (0.0, 0.3, 0.5, 1.0)] + \
