@@ -675,8 +675,8 @@ def _build_rows(job, ref=None):
         for c, xc in enumerate(x_chunks):
             # what the last hop read: the replica of hop K-1 (the input itself when K == 1)
             x_prev = xc if K == 1 else (prop._push_local[c][(K - 2) % 2] if exchange == "push" else cbufs[c][(K - 2) % job.nbuf])
-            if K >= 2:       # every rank's rows of hop K-1 arrived intact in my replica
-                ok = ok and exchange_checksums(x_prev, hops[K - 1][c], bounds)
+            if K >= 2 and exchange != "push":     # every rank's rows of hop K-1 arrived intact in my replica (the push
+                ok = ok and exchange_checksums(x_prev, hops[K - 1][c], bounds)   # transport skips rows this rank never gathers)
             if check_fn is not None:
                 ok = ok and check_fn(blk, x_prev, hops[K][c])
         if ref is not None:  # a replica-based reference chain exists anyway (alternative layouts were asked for)

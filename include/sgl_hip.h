@@ -90,7 +90,9 @@ typedef struct sgl_csr sgl_csr_t;
 #define SGL_CSR_STRICT_ORDER 0x1u /* no row splitting, one non-zero per step: bit-exact reference order */
 #define SGL_CSR_NO_XCD_REMAP 0x2u /* keep the hardware's round-robin block->XCD order                  */
 
-/* Wraps caller-owned device arrays (NOT copied; they must outlive the handle) and builds the execution plan
+/* A handle carries one split-row workspace: use a handle from ONE stream at a time (create one handle per stream for
+ * concurrent launches on the same matrix; they can share the caller's CSR arrays).
+ * Wraps caller-owned device arrays (NOT copied; they must outlive the handle) and builds the execution plan
  * (copies the row pointers to the host once: this call synchronises `stream`).
  * item_nnz / long_row_nnz: 0 = library default. */
 int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
@@ -153,6 +155,15 @@ int sgl_spmm_axpb_clamp_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float
  * then cost no pass of their own and no hop matrix has to be kept.  ACC is initialised by the caller (X_s, or w_s * X_s). */
 int sgl_spmm_acc_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
                      int64_t ldacc, float w, int weighted, float divisor, void *stream);
+
+/* ---- multi-GPU exchange (row-sharded layout): the all-gather of the feature block between hops ---------------- */
+/* Rank `rank` of `world` owns rows [h_bounds[rank], h_bounds[rank+1]) of the [n, ldx] replica d_x (row-major, whole padded
+ * rows travel) and has already written them; on completion (stream-ordered) every rank's rows are in place.  One grouped
+ * batch of ncclSend / ncclRecv to / from all peers on the CALLER's communicator (`nccl_comm` = ncclComm_t): direct, unequal
+ * blocks, all xGMI links at once.  RCCL is resolved at run time from the host process (else librccl.so is loaded);
+ * SGL_ERR_UNSUPPORTED if there is none.  world == 1 is a no-op.  sgl_exchange_backend() says which RCCL was found. */
+int sgl_allgather_rows(void *nccl_comm, int rank, int world, const int64_t *h_bounds, float *d_x, int64_t ldx, void *stream);
+const char *sgl_exchange_backend(void);
 
 /* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */
 /* matmul.h:5 -- accumulates into `answer` (caller pre-zeroes it, utils.py:31).  Errors are recorded in

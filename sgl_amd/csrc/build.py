@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libsgl_hip.so")
-SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_probe.hip", "sgl_synth.hip"]
+SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_probe.hip", "sgl_synth.hip", "sgl_exchange.hip"]
 HEADERS = ["sgl_common.h", os.path.join(ROOT, "include", "sgl_hip.h")]
 ARCH = "gfx950"
 FLAGS = [
@@ -63,7 +63,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or stale(LIB, objs):
-        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

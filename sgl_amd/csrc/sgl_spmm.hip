@@ -562,6 +562,7 @@ struct sgl_csr {
     int32_t *d_long_first = nullptr;
     float *d_partial = nullptr;
     size_t partial_cap = 0;  // floats
+    std::vector<float *> retired;   // outgrown workspaces: a captured hipGraph may still replay into them (freed at destroy)
     int device = 0;
 };
 
@@ -635,6 +636,7 @@ SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
     (void)hipFree(h->d_long_row);
     (void)hipFree(h->d_long_first);
     (void)hipFree(h->d_partial);
+    for (float *p : h->retired) (void)hipFree(p);
     delete h;
     return SGL_OK;
 }
@@ -780,8 +782,9 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     if (h->n_pieces > 0) {
         const size_t need = (size_t)h->n_pieces * (size_t)a.ldp;
         if (need > h->partial_cap) {
-            SGL_HIP_CHECK(hipStreamSynchronize(st));
-            (void)hipFree(h->d_partial);
+            // grow-only, and the outgrown buffer is kept until the handle dies: a ChainGraph captured earlier has its
+            // address baked in and may be replayed after a wider eager call on the same handle
+            if (h->d_partial) h->retired.push_back(h->d_partial);
             h->d_partial = nullptr;
             h->partial_cap = 0;
             SGL_HIP_CHECK(hipMalloc((void **)&h->d_partial, need * sizeof(float)));

@@ -18,17 +18,43 @@ def back_home(t, home):
     return t if home is None else t.to(home)
 
 
-def no_grad_inputs(feats, what):
-    if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
-        raise NotImplementedError(
-            f"{what}: the HIP kernel of this non-learnable aggregator is forward-only; detach the hop features "
-            "(SGAP pre-propagation never needs their gradient)")
+def wants_grad(feats):
+    """do gradients have to flow through these hop matrices?  The forward-only HIP kernels of the non-learnable aggregators
+    cannot carry them: the callers then evaluate the reference's own differentiable torch expression instead (e.g. when
+    the outputs of a ProjectedConcat / MLP are fed into Concat or Mean; SGAP pre-propagation itself never needs it)."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(f) and f.requires_grad for f in feats)
+
+
+def torch_combine(kind, feats, divisor=None):
+    """the reference's expressions, differentiable (message_op/{sum,mean,max,min,concat}_message_op.py)"""
+    if kind == "sum":
+        return sum(feats)
+    if kind == "mean":
+        return sum(feats) / (len(feats) if divisor is None else divisor)
+    if kind == "max":
+        return torch.stack(feats, dim=0).max(dim=0)[0]
+    if kind == "min":
+        return torch.stack(feats, dim=0).min(dim=0)[0]
+    if kind == "concat":
+        return torch.hstack(feats)
+    if kind == "nafs":
+        # over_smooth_distance_op.py:11-33 with its per-node Python loop written as one weighted sum (same values)
+        x0 = feats[0]
+        n0 = torch.norm(x0, 2, 1).add(1e-10)
+        scores = [torch.div(torch.div((x0 * f).sum(1), torch.norm(f, 2, 1).add(1e-10)), n0).unsqueeze(-1) for f in feats]
+        w = torch.softmax(torch.cat(scores, dim=1), dim=1)
+        out = 0.
+        for h, f in enumerate(feats):
+            out = out + w[:, h:h + 1] * f
+        return out
+    raise ValueError(kind)
 
 
 REDUCE = {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "max": _lib.SGL_REDUCE_MAX, "min": _lib.SGL_REDUCE_MIN}
 
 
 def reduce_hops(kind, feat_list):
+    if wants_grad(feat_list):
+        return torch_combine(kind, list(feat_list))
     feats, home = device_hops(feat_list)
-    no_grad_inputs(feats, kind)
     return back_home(dev.hop_reduce(REDUCE[kind], feats), home)

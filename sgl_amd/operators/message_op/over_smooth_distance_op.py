@@ -1,6 +1,6 @@
 from ... import device as dev
 from ..base_op import MessageOp
-from ._common import back_home, device_hops, no_grad_inputs
+from ._common import back_home, device_hops, torch_combine, wants_grad
 
 
 class OverSmoothDistanceWeightedOp(MessageOp):
@@ -12,6 +12,7 @@ class OverSmoothDistanceWeightedOp(MessageOp):
         self._aggr_type = 'over_smooth_dis_weighted'
 
     def _combine(self, feat_list):
+        if wants_grad(feat_list):
+            return torch_combine("nafs", list(feat_list))
         feats, home = device_hops(feat_list)
-        no_grad_inputs(feats, "over_smooth_dis_weighted")
         return back_home(dev.nafs_aggregate(feats), home)

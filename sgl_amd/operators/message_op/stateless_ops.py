@@ -9,7 +9,7 @@ import torch
 
 from ... import device as dev
 from ..base_op import MessageOp
-from ._common import back_home, device_hops, no_grad_inputs, reduce_hops
+from ._common import back_home, device_hops, reduce_hops, torch_combine, wants_grad
 
 
 class LastMessageOp(MessageOp):
@@ -52,12 +52,13 @@ class ConcatMessageOp(MessageOp):
 
     def _combine(self, feat_list):
         hops = feat_list[self._start:self._end]
-        if len(hops) > 1 and not (torch.is_grad_enabled() and any(f.requires_grad for f in hops)):
+        if wants_grad(hops):
+            return torch_combine("concat", list(hops))
+        if len(hops) > 1:
             view = self._slab_view(hops)
             if view is not None:
                 return view
         feats, home = device_hops(hops)
-        no_grad_inputs(feats, "concat")
         return back_home(dev.hop_concat(feats), home)
 
 
@@ -69,6 +70,8 @@ def _reduction(kind, doc):
 
         def _combine(self, feat_list):
             hops = feat_list[self._start:self._end]
+            if wants_grad(hops):
+                return torch_combine(kind, list(hops), divisor=(self._end - self._start) if kind == "mean" else None)
             if kind == "mean" and len(hops) != self._end - self._start:
                 # the reference divides by (end - start) whatever the slice held (mean_message_op.py:10)
                 total = reduce_hops("sum", hops)

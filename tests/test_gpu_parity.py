@@ -672,6 +672,45 @@ def test_slab_hops_make_concat_a_view(goldens, cuda):
         assert torch.equal(m.ConcatMessageOp(0, 2).aggregate([slab[2], slab[0]]), torch.hstack([plain[2], plain[0]]))
 
 
+def test_non_learnable_aggregators_backpropagate_when_asked(goldens, cuda):
+    """hop matrices that require grad (outputs of a learnable stage fed into Concat / Mean / ...): the reference's own
+    differentiable expression is evaluated instead of the forward-only HIP kernel; values agree with the kernel path"""
+    from sgl_amd.operators import message_op as m
+    feats, _ = g3_feats(goldens, cuda)
+    ops = [m.SumMessageOp(0, 5), m.MeanMessageOp(1, 4), m.MaxMessageOp(0, 5), m.MinMessageOp(0, 3), m.ConcatMessageOp(0, 5),
+           m.OverSmoothDistanceWeightedOp()]
+    for op in ops:
+        want = op.aggregate(feats)
+        leaf = [f.clone().requires_grad_(True) for f in feats]
+        got = op.aggregate(leaf)
+        assert got.requires_grad and oracle.parity_ok(got.detach().cpu().numpy(), want.cpu().numpy(), 1e-6), type(op).__name__
+        got.sum().backward()
+        used = leaf if op._start is None else leaf[op._start:op._end]
+        assert all(f.grad is not None and torch.isfinite(f.grad).all() for f in used), type(op).__name__
+
+
+def test_hip_graph_survives_a_wider_eager_call(cuda):
+    """the split-row workspace of a handle is grow-only and outgrown buffers are retired, not freed -- a chain
+    captured into a hipGraph keeps replaying correctly after an eager SpMM with a wider matrix re-sized the workspace"""
+    a = long_row_graph()
+    a = sp.csr_matrix((np.abs(a.data) / 50.0, a.indices, a.indptr), shape=a.shape)
+    n = a.shape[0]
+    csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, item_nnz=64, long_row_nnz=128)
+    assert csr.info()["n_pieces"] > 0
+    x = torch.from_numpy(hash_matrix(n, 8, seed=1)).to(cuda)
+    outs = [torch.empty_like(x) for _ in range(2)]
+    g = csr.capture_chain(x, outs)
+    want = [o.clone() for o in g.replay()]
+    torch.cuda.synchronize()
+    wide = torch.from_numpy(hash_matrix(n, 200, seed=2)).to(cuda)
+    csr.spmm(wide)                                   # needs a larger workspace than the captured chain
+    for o in outs:
+        o.zero_()
+    got = g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(got, want))
+
+
 def test_max_min_propagate_nan_like_torch(cuda):
     from sgl_amd.operators import message_op as m
     a = torch.tensor([[1.0, float("nan"), -2.0, 5.0]] * 3, device=cuda)
@@ -1232,6 +1271,35 @@ def test_hashed_generator_device_equals_host_mirror(cuda):
     xb = sy.hashed_features_torch(3, 0, 12_000_000, 128, device=cuda)          # 1.5e9 elements
     tail = np.arange(12_000_000 - 100, 12_000_000)
     assert np.array_equal(xb[tail[0]:].cpu().numpy(), sy.hashed_features_numpy(3, tail, 128))
+
+
+def test_c_abi_allgather_rows_on_a_real_communicator(cuda):
+    """sgl_allgather_rows on an RCCL communicator created by the caller (here: one rank -- RCCL refuses two ranks on one
+    device, so the multi-peer batch itself is covered by the gloo tests of the identical Python transport): the library
+    finds RCCL at run time, accepts the communicator and stream, and leaves the replica intact."""
+    import ctypes
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    try:
+        rccl = ctypes.CDLL("librccl.so.1", mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        pytest.skip("no librccl.so.1 on this box")
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    lib = _lib.lib()
+    assert lib.sgl_exchange_backend() in (b"process", b"librccl.so")
+    x = torch.arange(40 * 16, dtype=torch.float32, device=cuda).view(40, 16)
+    keep = x.clone()
+    bounds = (ctypes.c_int64 * 2)(0, 40)
+    _lib.check(lib.sgl_allgather_rows(comm, 0, 1, bounds, _lib.ptr(x), 16, _lib.current_stream_ptr()), "sgl_allgather_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(x, keep)
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)
 
 
 def test_int64_offsets_beyond_2_31_elements(cuda):
