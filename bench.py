@@ -233,6 +233,36 @@ class GpuEngine:
         from sgl_amd.dist import block_piece_spmms
         return block_piece_spmms(blk, pieces, weights, strict=args.strict)
 
+    def gather_ceiling(self, col, x, d, max_idx=64 << 20):
+        """What the memory system gives the bare access pattern of this workload (sgl_probe_gather_f32: whole-row gathers
+        at the workload's own column ids, row width and pitch; no CSR stream, no arithmetic, no stores): the ceiling the
+        SpMM's gather rate is quoted against, measured in this run.  Returns G gathers/s or None."""
+        from sgl_amd import _lib
+        try:
+            idx = col[: min(int(col.numel()), max_idx)]
+            rf = (d + 3) // 4 * 4
+            ld = x.stride(0) if x.shape[0] > 1 else rf
+            if rf > 256 or ld % 4 or x.data_ptr() % 16 or ld < rf:
+                return None
+            sink = torch.zeros(4, device=self.device)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def go():
+                _lib.check(_lib.lib().sgl_probe_gather_f32(_lib.ptr(x), ld, _lib.ptr(idx), idx.numel(), rf, 16, _lib.ptr(sink),
+                                                           _lib.current_stream_ptr()), "sgl_probe_gather_f32")
+            go()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                ev0.record()
+                go()
+                ev1.record()
+                torch.cuda.synchronize()
+                ts.append(ev0.elapsed_time(ev1))
+            return idx.numel() / (sorted(ts)[1] * 1e-3) / 1e9
+        except Exception:  # noqa: BLE001  (reporting only)
+            return None
+
     def sampled_rows_check(self, blk, x_prev, y_local, samples=512, tol=1e-5):
         """kernel-independent check of this rank's SpMM: `samples` of its rows recomputed in fp64 with plain torch
         indexing from the replica the hop read (x_prev) and compared with what the kernel wrote (y_local)"""
@@ -976,6 +1006,10 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     except Exception as e:  # noqa: BLE001  (reporting only; the measured value is already in hand)
         diag = {"failed": repr(e)}
 
+    ceiling = None
+    if not sharded and rank == 0 and hasattr(engine, "gather_ceiling"):
+        ceiling = engine.gather_ceiling(job.col, job.x0, d)
+
     cpu = None
     if not sharded and not args.no_cpu_baseline and rank == 0:
         try:
@@ -1013,7 +1047,12 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                          "kernel": "spmm_kernel", "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": hop_s * 1e3,
                          "kernel_ms_profile": prof.get("kernel_avg_ms_rocprof") if prof else None,
-                         "traffic_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None},
+                         "traffic_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None,
+                         # the bare-gather ceiling of THIS access pattern measured in this run (probe kernel: the same
+                         # column ids, row width and pitch; no CSR stream, arithmetic or stores) and the kernel's gather rate
+                         "gather_ceiling_Ggathers_per_s": ceiling,
+                         "kernel_Ggathers_per_s": nnz / world / hop_s / 1e9,
+                         "frac_of_gather_ceiling": (nnz / world / hop_s / 1e9 / ceiling) if ceiling else None},
             "cpu_baseline": cpu,
         }
 
