@@ -122,6 +122,29 @@ def scatter_row_blocks(full, bounds, n, device, src=0, group=None):
     return RowBlock(lo, hi, n, rp, cc, vv)
 
 
+def canonicalize_block(block):
+    """Sort the columns inside every row of a block and sum duplicate (row, col) entries -- what the normalisation needs
+    and what a generated / ingested row block does not guarantee (sgl_coo_to_csr: 64-bit keys, stable radix sort,
+    duplicate sums in input order).  Returns a new RowBlock; the input is not modified."""
+    import ctypes
+    from .. import _lib
+    _lib.require_gpu()
+    dev = block.device
+    n_loc, nnz = block.n_local, block.nnz
+    rows = torch.repeat_interleave(torch.arange(n_loc, dtype=torch.int64, device=dev), block.rowptr[1:] - block.rowptr[:-1])
+    cols = block.col.to(torch.int64)
+    out_ptr = torch.empty(n_loc + 1, dtype=torch.int64, device=dev)
+    out_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    out_val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+    n_out = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().sgl_coo_to_csr(n_loc, block.n, nnz, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(block.val), _lib.ptr(out_ptr),
+                                             _lib.ptr(out_col), _lib.ptr(out_val), ctypes.byref(n_out), _lib.current_stream_ptr()),
+                   "sgl_coo_to_csr")
+    m = n_out.value
+    return RowBlock(block.lo, block.hi, block.n, out_ptr, out_col[:m].clone(), out_val[:m].clone())
+
+
 def local_piece_bounds(block, pieces, weights=None):
     """absolute boundaries [pieces+1] of the nnz-balanced row pieces of this rank's block"""
     rp_host = block.rowptr.cpu().numpy()

@@ -495,6 +495,45 @@ def test_row_block_normalisation_matches_full(goldens, cuda, gname):
             assert np.array_equal(np.concatenate(vals), fval.cpu().numpy())
 
 
+def test_hashed_directed_blocks_normalise_like_the_whole_matrix(cuda):
+    """S4 path in small: hashed (directed, unsorted, possibly duplicated) row blocks -> canonicalize_block ->
+    sgl_norm_block_*(symmetric=False) with the degree vector summed over the blocks' column sums == the whole-matrix
+    normalisation of A = T^T, bit for bit"""
+    from sgl_amd import synthetic as sy
+    from sgl_amd.dist import RowBlock, canonicalize_block
+    n = 3000
+    table = sy.degree_table(12.0, 300)
+    bounds = [0, 1100, 1100, 2500, n]                          # incl. an empty block
+    blocks = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        rp, c, v = sy.hashed_block_torch(5, lo, hi - lo, n, table, device=cuda)
+        blocks.append(canonicalize_block(RowBlock(lo, hi, n, rp, c, v)))
+    # the whole T as scipy, canonical
+    T = sp.vstack([sp.csr_matrix((b.val.cpu().numpy(), b.col.cpu().numpy(), b.rowptr.cpu().numpy()), shape=(b.n_local, n))
+                   for b in blocks]).tocsr()
+    for b in blocks:                                           # canonical: sorted, unique columns
+        cc, rp = b.col.cpu().numpy(), b.rowptr.cpu().numpy()
+        assert all((np.diff(cc[rp[i]:rp[i + 1]]) > 0).all() for i in range(0, b.n_local, 97))
+    A = sp.csr_matrix(T.T)
+    A.sort_indices()
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(cuda)  # noqa: E731
+    for r, alpha in ((0.5, None), (0.3, 0.2)):
+        fptr, fcol, fval = dev.normalize_adj(to(A.indptr, np.int64), to(A.indices, np.int32), to(A.data, np.float32), n, r, alpha)
+        deg = torch.zeros(n, dtype=torch.float64, device=cuda)
+        parts = []
+        for b in blocks:                                       # what the ranks' all-reduce would add up
+            p_, c_, v_, v64 = dev.normalize_block(b.rowptr, b.col, b.val, b.lo, n, 0.0, None, symmetric=False, return_fp64=True,
+                                                  deg=torch.ones(n, dtype=torch.float64))      # r = 0, deg = 1: T' itself
+            deg.index_add_(0, c_.long(), v64)
+        for b in blocks:
+            parts.append(dev.normalize_block(b.rowptr, b.col, b.val, b.lo, n, r, alpha, symmetric=False, deg=deg))
+        offs = np.concatenate([[0], np.cumsum([int(p[0][-1]) for p in parts])])
+        ptr_all = np.concatenate([p[0].cpu().numpy()[:-1] + o for p, o in zip(parts, offs[:-1])] + [offs[-1:]])
+        assert np.array_equal(ptr_all, fptr.cpu().numpy())
+        assert np.array_equal(np.concatenate([p[1].cpu().numpy() for p in parts]), fcol.cpu().numpy())
+        assert np.array_equal(np.concatenate([p[2].cpu().numpy() for p in parts]), fval.cpu().numpy())
+
+
 def test_adj_to_symmetric_norm_scipy_contract(goldens, cuda):
     from sgl_amd.operators.utils import adj_to_symmetric_norm
     g = goldens.graph("dir40")
