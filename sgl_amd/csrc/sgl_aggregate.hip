@@ -157,10 +157,30 @@ __device__ __forceinline__ typename Vt<VEC>::type load_masked(const float *p, in
 }
 
 // ---- row-wise reductions: LPR lanes cooperate on one row, 64/LPR rows per wavefront ------------------------
+// All-lanes sum over groups of LPR consecutive lanes.  Inside a 16-lane row the exchange is done by the VALU's DPP
+// modifiers (quad permutes, half-row / row mirrors) -- no LDS-crossbar instruction; only the steps that cross rows
+// (LPR = 32, 64) use gfx950's v_permlane16_swap / v_permlane32_swap (VALU as well).  (With all steps on ds_bpermute the fused NAFS kernel, 2H reductions per row, ran at
+// 0.48-0.52 of the streaming rate.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    static_assert(LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "groups of 8 / 16 / 32 / 64 lanes");
+    v += dpp_xchg<0xB1>(v);                        // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_xchg<0x4E>(v);                        // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_xchg<0x141>(v);                       // row_half_mirror: lane i <-> 7 - i (the other quad of the 8)
+    if constexpr (LPR >= 16) v += dpp_xchg<0x140>(v);   // row_mirror: lane i <-> 15 - i (the other half of the row)
+    if constexpr (LPR >= 32) {   // gfx950 v_permlane16_swap: odd rows of the first operand <-> even rows of the second;
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // with both operands = v the two results are v[lane] and v[lane ^ 16]
+    }
+    if constexpr (LPR >= 64) {   // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v;
 }
 
@@ -225,9 +245,7 @@ __global__ __launch_bounds__(256) void hop_rowdot_reg_kernel(const Hops hx, cons
             for (int e = 0; e < 4; ++e) acc[h] = __builtin_fmaf(gv[c][e], xv[h][c][e], acc[h]);
     }
 #pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1)
-#pragma unroll
-        for (int h = 0; h < HMAX; ++h) acc[h] += __shfl_xor(acc[h], off, 64);
+    for (int h = 0; h < HMAX; ++h) acc[h] = group_sum<LPR>(acc[h]);   // independent chains: the scheduler interleaves them
     if (live && l == 0) {
 #pragma unroll
         for (int h = 0; h < HMAX; ++h)
