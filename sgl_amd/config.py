@@ -13,7 +13,11 @@ slab_hops     GraphOp.propagate writes hop k into column slice k of ONE [N, (K+1
               ConcatMessageOp over consecutive hops is a zero-copy view of it instead of a copy of every hop
 fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / simple_weighted aggregation into the SpMM epilogue
               (GraphOp.propagate_reduce): no pass over the hop matrices, only two hop buffers alive; the K+1 hop list
-              (`_processed_feat_list`) is then not kept (the reference's own consumers never read it for these ops)
+              (`_processed_feat_list`) is then not kept (the reference's own consumers never read it for these ops).
+              `last` costs nothing and is always folded.  sum / mean / weighted cost ~2 % more time than the separate
+              pass (the running aggregate is read and written once per hop) and save K-1 hop buffers:
+              "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
+              device memory; True / False force it
 """
 import os
 
@@ -30,5 +34,6 @@ host_output = _env_bool("SGL_AMD_HOST_OUTPUT", False)
 strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
 strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
 cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
-fuse_aggregate = _env_bool("SGL_AMD_FUSE_AGGREGATE", True)
+_fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()
+fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)

@@ -49,11 +49,11 @@ class BaseSGAPModel(nn.Module):
             return
         self._pre_msg_learnable = self._pre_msg_op.aggr_type in _LEARNABLE
         gop = self._pre_graph_op
-        if (config.fuse_aggregate and not self._pre_msg_learnable and hasattr(gop, "propagate_reduce")
+        if (config.fuse_aggregate is not False and not self._pre_msg_learnable and hasattr(gop, "propagate_reduce")
                 and hasattr(self._pre_msg_op, "fused_spec") and not gop._opt("host_output")):
             # last / sum / mean / simple_weighted: accumulated in the SpMM epilogue, the K+1 hop matrices never coexist
             spec = self._pre_msg_op.fused_spec(gop._prop_steps + 1)
-            if spec is not None:
+            if spec is not None and (spec["kind"] == "last" or config.fuse_aggregate is True or self._hops_are_heavy(feature)):
                 with torch.no_grad():
                     fused = gop.propagate_reduce(adj, feature, **spec)
                 if fused is not None:
@@ -64,6 +64,16 @@ class BaseSGAPModel(nn.Module):
         if not self._pre_msg_learnable:
             with torch.no_grad():
                 self._processed_feature = self._pre_msg_op.aggregate(self._processed_feat_list)
+
+    def _hops_are_heavy(self, feature):
+        """fuse_aggregate = "auto": would the K+1 hop matrices take more than a quarter of the free device memory?"""
+        try:
+            n, d = feature.shape
+            need = (self._pre_graph_op._prop_steps + 1) * n * dev.row_pitch(d) * 4
+            free, _ = torch.cuda.mem_get_info()
+            return need > free // 4
+        except Exception:  # noqa: BLE001
+            return False
 
     def postprocess(self, adj, output):
         if self._post_graph_op is None:

@@ -681,9 +681,16 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
         config.fuse_aggregate = False
         mu = cls(*args)
         mu.preprocess(a, x)
-        config.fuse_aggregate = True
+        config.fuse_aggregate = "auto"
         assert mf._processed_feat_list is None and len(mu._processed_feat_list) == 4
         assert torch.equal(mf._processed_feature, mu._processed_feature), cls.__name__
+    # "auto": `last` is always folded (it is free); sum-like aggregates only when the hop list would be heavy
+    ma = SGC(3, d, 5)
+    ma.preprocess(a, x)
+    assert ma._processed_feat_list is None
+    mb = SSGC(3, d, 5)
+    mb.preprocess(a, x)
+    assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)
 
 
 def test_slab_hops_make_concat_a_view(goldens, cuda):
