@@ -1121,6 +1121,23 @@ def _two_rank_worker(rank, world, port, out_dir):
         nafs_c = opc.gather_full(opc.over_smooth_aggregate(hc))
         ok = ok and orc.parity_ok(nafs_c.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
         ok = ok and torch.equal(op.over_smooth_aggregate(hops), nafs)      # row-sharded: the fused kernel itself
+        # ROW-SHARDED STORAGE (the contract layout): rank 0 holds the raw graph and hands out row blocks; every rank
+        # normalises ITS block (degrees all-reduced), never sees the rest of A or A_hat, and passes only its feature rows
+        from sgl_amd.dist import RowBlock, balanced_bounds, exchange_checksums, scatter_row_blocks
+        from sgl_amd.operators.utils import canonical_csr
+        raw = canonical_csr(adj)
+        bnd = balanced_bounds(raw.indptr.astype(np.int64) + np.arange(2001), world)
+        full = tuple(torch.from_numpy(np.ascontiguousarray(a_, dtype=t_)).to(dv) for a_, t_ in
+                     ((raw.indptr, np.int64), (raw.indices, np.int32), (raw.data, np.float32))) if rank == 0 else None
+        blk = scatter_row_blocks(full, bnd, 2000, dv)
+        ok = ok and isinstance(blk, RowBlock) and (blk.lo, blk.hi) == (int(bnd[rank]), int(bnd[rank + 1])) and blk.nnz < raw.nnz
+        ops = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, col_chunks=1)
+        hs_ = ops.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))     # only my rows of X
+        ok = ok and (ops.lo, ops.hi) == (blk.lo, blk.hi) and ops.a_hat_block.nnz == blk.nnz + (blk.hi - blk.lo)
+        for h in range(4):
+            ok = ok and np.array_equal(hs_[h].cpu().numpy(), ref[h][ops.lo:ops.hi])     # strict order: bit-exact from raw A
+        rep_ = ops.gather_rows(hs_[3].contiguous())
+        ok = ok and exchange_checksums(rep_, hs_[3], bnd) and np.array_equal(rep_.cpu().numpy(), ref[3])
         open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
