@@ -882,7 +882,7 @@ def _replayed_profile(workload, world):
     return tj.get(workload) if world == 1 else None
 
 
-def papers_section(args, engine, rank, world, exchange):
+def papers_section(args, engine, rank, world, exchange, wl=None):
     """The same measurement on an ogbn-papers100M-shaped graph, row-sharded in storage over the same
     ranks: every rank generates ITS nnz-balanced row block and the feature replica on its own GPU (hash keyed by
     (seed, row): no traffic, no rank ever sees the whole graph), k = 3 hops with the per-hop all-gather, only the last
@@ -890,7 +890,7 @@ def papers_section(args, engine, rank, world, exchange):
     import torch.distributed as dist
     from sgl_amd import synthetic
     from sgl_amd.dist import ShardedPropagator, exchange_checksums, gather_piece_bounds
-    wl = dict(synthetic.WORKLOADS["S3_papers"], k=3)
+    wl = dict(synthetic.WORKLOADS["S3_papers"], k=3) if wl is None else wl      # (tests pass a small hashed workload)
     n, d, K = wl["n"], wl["d"], wl["k"]
     t0 = time.perf_counter()
     bounds, nnz = engine.hashed_bounds(args, wl, world)
@@ -899,12 +899,26 @@ def papers_section(args, engine, rank, world, exchange):
     pieces, handles, mine = engine.block_piece_spmms(args, blk, args.pieces)
     pb = gather_piece_bounds(mine) if world > 1 else np.asarray([[int(v) for v in mine]], dtype=np.int64)
     prop = ShardedPropagator(pieces, pb, rank, world, n, transport=exchange if exchange in ("p2p", "allgather", "staged") else "p2p")
-    xbufs = [torch.empty_like(x0) for _ in range(2)]
+    # N > 1: the feature block is held as two column chunks, software-pipelined across hops (chunk A's all-gather is in
+    # flight while chunk B is multiplied and hop h+1 of chunk A only waits for A's own exchange): the job is communication
+    # bound there (49.8 GB in-bound per rank per hop at 8 ranks) and this hides the SpMM behind the transfers.
+    from sgl_amd.dist import column_chunks
+    chunks = column_chunks(d, args.col_chunks if world > 1 else 1)
+    if len(chunks) > 1:
+        x_chunks = [x0[:, a:b].contiguous() for a, b in chunks]
+        del x0
+    else:
+        x_chunks = [x0]
+    cbufs = [[torch.empty_like(xc) for _ in range(2)] for xc in x_chunks]
     # the last hop reads replica (K-2) % 2, so its output can live in this rank's rows of the other one: no extra memory
-    ylast = xbufs[(K - 1) % 2][prop.lo:prop.hi]
+    ylast = [cb[(K - 1) % 2][prop.lo:prop.hi] for cb in cbufs]
 
     def step():
-        return prop.propagate(x0, K, x_buffers=xbufs, y_buffers=[None] * (K - 1) + [ylast], in_place=True)
+        if len(x_chunks) == 1:
+            return [[t] for t in prop.propagate(x_chunks[0], K, x_buffers=cbufs[0], y_buffers=[None] * (K - 1) + [ylast[0]],
+                                               in_place=True)]
+        return prop.propagate_chunked(x_chunks, K, buffers=cbufs, y_buffers=[[None] * (K - 1) + [yl] for yl in ylast],
+                                      in_place=True)
 
     def sync_all():
         engine.sync()
@@ -914,10 +928,14 @@ def papers_section(args, engine, rank, world, exchange):
 
     hops = step()                                             # warm-up + validation
     sync_all()
-    x_prev = xbufs[(K - 2) % 2]
-    ok = exchange_checksums(x_prev, x_prev[prop.lo:prop.hi], [int(v) for v in pb[:, 0]] + [int(pb[-1, -1])])
-    ok = ok and engine.sampled_rows_check(blk, x_prev, hops[K])
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=x0.device)
+    ok = True
+    bnds = [int(v) for v in pb[:, 0]] + [int(pb[-1, -1])]
+    for c in range(len(x_chunks)):
+        x_prev = cbufs[c][(K - 2) % 2]
+        ok = ok and exchange_checksums(x_prev, x_prev[prop.lo:prop.hi], bnds)
+        ok = ok and engine.sampled_rows_check(blk, x_prev, hops[K][c])
+    dev_ = x_chunks[0].device
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev_)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     steps = 2
@@ -926,7 +944,7 @@ def papers_section(args, engine, rank, world, exchange):
     for _ in range(steps):
         step()
     sync_all()
-    el = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=x0.device)
+    el = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev_)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -942,7 +960,8 @@ def papers_section(args, engine, rank, world, exchange):
                          "note": "per-GPU share of one hop / wall time per hop (the all-gather is inside that time for N>1)"},
             "parallelism": "single GPU" if world == 1 else
                            f"row-sharded x{world} (A_hat stored as one row block per GPU) + per-hop all-gather ({prop.transport}), "
-                           f"{args.pieces} row pieces, {inbound / 1e9:.1f} GB in-bound per rank per hop",
+                           f"{args.pieces} row pieces x {len(x_chunks)} column chunks pipelined across hops, "
+                           f"{inbound / 1e9:.1f} GB in-bound per rank per hop",
             "hops_retained": "last only (hop shards are written into the next replica in place)",
             "setup_s": round(time.perf_counter() - t0 - elapsed * (steps + 1) / steps, 2)}
 

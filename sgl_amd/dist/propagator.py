@@ -297,7 +297,7 @@ class ShardedPropagator:
             hops.append(outs)
         return hops
 
-    def propagate_chunked(self, x_chunks, prop_steps, buffers=None, y_buffers=None):
+    def propagate_chunked(self, x_chunks, prop_steps, buffers=None, y_buffers=None, in_place=False):
         """Software-pipelined variant: the feature block is held as C column chunks (separate contiguous [N, w_c]
         matrices, see column_chunks()).  SpMM is separable over columns, so while chunk c's new rows are in flight
         to the peers, chunk c+1 is being multiplied, and hop h+1 of chunk c only waits for chunk c's own exchange:
@@ -308,7 +308,9 @@ class ShardedPropagator:
         The dependency stall of the plain scheme (next hop cannot start before the whole all-gather landed)
         disappears; in the communication-bound regime the hop time is the transfer time.
         x_chunks: list of C replicas [N, w_c]; returns hops[h][c] = LOCAL shard [hi-lo, w_c].
-        y_buffers[c][h-1]: optional preallocated outputs (see propagate)."""
+        y_buffers[c][h-1]: optional preallocated outputs (see propagate).
+        in_place: as in propagate() -- hops 1..K-1 are produced directly in this rank's rows of the next replica (views that
+        the hop after next overwrites); only the last hop is retained."""
         C = len(x_chunks)
         n = x_chunks[0].shape[0]
         assert n == self.n and self.pieces >= 1
@@ -327,11 +329,16 @@ class ShardedPropagator:
                     w.wait()
                 pending[c] = []
                 w_c = x_chunks[c].shape[1]
-                y_local = y_buffers[c][h - 1] if y_buffers is not None else \
-                    torch.empty((self.hi - self.lo, w_c), dtype=x_chunks[c].dtype, device=x_chunks[c].device)
                 x_next = None if last else buffers[c][(h - 1) % len(buffers[c])]
                 if x_next is not None and x_next.numel() and x_next.data_ptr() == cur[c].data_ptr():
                     raise RuntimeError("need two distinct buffers per chunk to ping-pong between hops")
+                direct = in_place and not last
+                if direct:
+                    y_local = x_next[self.lo:self.hi]
+                elif y_buffers is not None and y_buffers[c][h - 1] is not None:
+                    y_local = y_buffers[c][h - 1]
+                else:
+                    y_local = torch.empty((self.hi - self.lo, w_c), dtype=x_chunks[c].dtype, device=x_chunks[c].device)
                 for p in range(self.pieces):
                     r0, r1 = int(self.pb[self.rank, p]) - self.lo, int(self.pb[self.rank, p + 1]) - self.lo
                     y_piece = y_local[r0:r1]
@@ -340,7 +347,8 @@ class ShardedPropagator:
                     if not last and self._exchanging():
                         pending[c].append(self._exchange_piece(p, y_piece, x_next))
                 if not last:
-                    x_next[self.lo:self.hi].copy_(y_local)
+                    if not direct:
+                        x_next[self.lo:self.hi].copy_(y_local)
                     cur[c] = x_next
                 outs.append(y_local)
             hops.append(outs)

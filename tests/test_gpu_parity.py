@@ -1265,6 +1265,45 @@ def test_bench_auto_selects_validated_push_with_two_ranks_on_one_gpu(cuda, tmp_p
     assert plan["layout"] == "cols" and j["config"]["parallelism"].startswith("feature-sharded x2")
 
 
+def _papers_worker(rank, world, port, out_dir):
+    import json as _json
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import bench
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        engine = bench.GpuEngine(0)
+        args = bench.parse_args(["--gpus", str(world), "--pieces", "2", "--col-chunks", "2"])
+        wl = dict(n=300_000, d=128, k=3, hashed=True, mean_deg=20.0, d_max=3000)
+        out = bench.papers_section(args, engine, rank, world, "staged", wl=wl)
+        with open(_os.path.join(out_dir, f"papers{rank}.json"), "w") as f:
+            _json.dump(out, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_papers_section_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """the papers100M-shaped section of bench.py (hashed row blocks generated per rank, in-place hops, column chunks pipelined
+    across hops, bit-checksum + sampled-row validation) with two real processes and the HIP kernels, at a small size"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_papers_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [json.load(open(tmp_path / f"papers{r}.json")) for r in range(2)]
+    for o in outs:
+        assert o["validated"] is True and o["n_gpus"] == 2 and o["value"] > 0 and o["nnz"] > 5_000_000
+        assert "2 column chunks pipelined" in o["parallelism"] and o["roofline"]["frac"] > 0
+    assert outs[0]["nnz"] == outs[1]["nnz"]
+
+
 def test_bench_grid_layout_with_four_ranks_on_one_gpu(cuda, tmp_path):
     """bench.py --layout grid with real kernels: 2 x 2 grid, relayed exchange, validated against the single-GPU chain"""
     import socket
