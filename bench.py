@@ -361,6 +361,9 @@ def parse_args(argv=None):
                     help="row pieces per rank of the grid layout; a comma list is tried and the fastest count kept")
     ap.add_argument("--setup-budget", type=float, default=float(os.environ.get("SGL_BENCH_SETUP_BUDGET", "120")),
                     help="seconds of untimed setup after which further layout candidates are skipped (and listed)")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SGL_BENCH_WATCHDOG", "600")),
+                    help="N>1: seconds after which a job that is stuck (a collective some rank never entered) is ended: rank 0 "
+                         "prints a JSON line with value null, the phase it was in and exits non-zero instead of hanging")
     ap.add_argument("--no-papers", action="store_true",
                     help="skip the ogbn-papers100M-shaped secondary measurement of an S1_products run")
     ap.add_argument("--papers-budget", type=float, default=float(os.environ.get("SGL_BENCH_PAPERS_BUDGET", "150")),
@@ -748,6 +751,7 @@ def _select_layout(job):
         # a candidate that raises is dropped on EVERY rank (the code path is the same on all of them, so an error is
         # too; agree() keeps the control flow identical even if it is not)
         c, good = None, True
+        _phase(f"select_layout: candidate {name!r}")
         try:
             if name != "rows" and ref is None:
                 ref = _Reference(job)
@@ -966,6 +970,13 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
             "setup_s": round(time.perf_counter() - t0 - elapsed * (steps + 1) / steps, 2)}
 
 
+_PHASE = ["start"]
+
+
+def _phase(name):
+    _PHASE[0] = name
+
+
 def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     import torch.distributed as dist
 
@@ -986,14 +997,30 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         workloads = synthetic.WORKLOADS
     wl = workloads[args.workload]
     job = _Job(args, engine, rank, world, wl)
+    guard = None
+    if world > 1 and emit is print and args.watchdog > 0:
+        # a rank that fails before a collective leaves the others waiting in it for ever: end the job with a diagnosis
+        import threading
+
+        def stuck():
+            if rank == 0:
+                quiet.unmute()
+                print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "edge\u00b7featdim/s", "n_gpus": world,
+                                  "error": f"watchdog: no progress after {args.watchdog:.0f} s", "phase": _PHASE[0]}), flush=True)
+            os._exit(3)
+        guard = threading.Timer(args.watchdog, stuck)
+        guard.daemon = True
+        guard.start()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        _phase("init_process_group")
         dist.init_process_group(engine.backend, rank=rank, world_size=world, **engine.init_kwargs())
         job.own_group = True
     n, d, K = job.n, job.d, job.K
 
     t_setup = time.perf_counter()
     job.t_setup = t_setup
+    _phase("load_workload (generate, scatter row blocks, normalise per block)")
     job.load_workload(wl)
     nnz = job.nnz
     sharded = world > 1 or args.force_sharded
@@ -1002,11 +1029,13 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         step, info0 = engine.single_step(args, job.rowptr, job.col, job.val, job.x0, n, d, K)
         job.info.update(info0)
     else:
+        _phase("select_layout")
         step, halves = _select_layout(job)
     info = job.info
     setup_s = time.perf_counter() - t_setup
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barrier + device synchronise ------------
+    _phase("timed region")
     for _ in range(args.warmup):
         step()
     job.sync_all()
@@ -1020,6 +1049,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
 
+    _phase("diagnostics")
     try:
         diag = _diagnostics(job, halves) if job.budget_left() > -60 else {"skipped": "setup budget exhausted"}
     except Exception as e:  # noqa: BLE001  (reporting only; the measured value is already in hand)
@@ -1088,6 +1118,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                    and hasattr(engine, "hashed_block"))
     if want_papers:
         import threading
+        _phase("papers100M section")
         done = threading.Event()
 
         def overrun():
@@ -1119,6 +1150,8 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         if rank == 0:
             out["papers100M"] = papers
     emit_line()
+    if guard is not None:
+        guard.cancel()
     if world > 1:
         dist.barrier()
     if job.own_group and dist.is_initialized():
