@@ -218,7 +218,10 @@ def test_bench_eight_ranks_gloo(tmp_path):
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])
     plan = j["config"]["plan"]
-    assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) == {"rows", "grid"} and "layout_rejected" not in plan
+    # rows (contract) + the grid; the communication-free layout joins ONLY through the fallback rule (no exchanging layout beat
+    # its estimate -- always the case with gloo on CPU), and says so
+    assert j["n_gpus"] == 8 and set(plan["layout_candidates_ms"]) - {"cols"} == {"rows", "grid"} and "layout_rejected" not in plan
+    assert ("cols" in plan["layout_candidates_ms"]) == ("cols_fallback" in plan)
     assert plan["rows"]["value"] > 0 and plan["contract_layout"] == "rows" and list(plan["grid_pieces_candidates_ms"]) == ["4"]
     assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0
     links = j["config"]["diagnostics"]["links"]     # gloo: the pairwise exchange works, all_to_all may not exist
