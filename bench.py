@@ -288,13 +288,20 @@ class GpuEngine:
         from sgl_amd import device as dev
         csr = dev.DeviceCSR(rowptr, col, val, (rowptr.numel() - 1, n), strict=args.strict)
         n_out = rowptr.numel() - 1
-        bufs = [dev.alloc_rows(n_out, d, self.device) for _ in range(K)]
+        free, _ = torch.cuda.mem_get_info()
+        pingpong = n_out == n and K > 2 and K * n_out * dev.row_pitch(d) * 4 > free // 2
+        # K hop matrices that would not fit (the whole papers100M-shaped graph: 57 GB each): two buffers, alternating
+        bufs = [dev.alloc_rows(n_out, d, self.device) for _ in range(2 if pingpong else K)]
+        if pingpong:
+            bufs = [bufs[h % 2] for h in range(K)]
         src0 = dev.upload_rows(x0, self.device) if dev.row_pitch(d) != d else x0   # re-pack into the line-aware pitch
 
         x_in = dev.padded_parent(src0)
         outs = [dev.padded_parent(b) for b in bufs]
 
         info = csr.info()
+        if pingpong:
+            info["hops_retained"] = "last two only (K hop matrices of this size do not fit one GPU)"
         if n_out != n:
             # a row block against the full replica (S3_papers_shard): K launches of the same hop
             def step():
