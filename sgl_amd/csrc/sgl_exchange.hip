@@ -8,6 +8,8 @@
 // link).  Received rows land in place in the replica.  Stream-ordered: nothing synchronises the host.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "sgl_common.h"
 
 namespace {
@@ -26,9 +28,7 @@ struct Rccl {
     const char *origin = "";
 };
 
-Rccl &rccl() {
-    static Rccl r;
-    if (r.tried) return r;
+void resolve_rccl(Rccl &r) {
     r.tried = true;
     void *h = RTLD_DEFAULT;                       // the host's own RCCL (an application linked against it, LD_PRELOAD, ...)
     r.origin = "process";
@@ -36,13 +36,19 @@ Rccl &rccl() {
         h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         r.origin = "librccl.so";
-        if (!h) return r;
+        if (!h) return;
     }
     r.send = (nccl_send_t)dlsym(h, "ncclSend");
     r.recv = (nccl_recv_t)dlsym(h, "ncclRecv");
     r.group_start = (nccl_group_t)dlsym(h, "ncclGroupStart");
     r.group_end = (nccl_group_t)dlsym(h, "ncclGroupEnd");
     r.errstr = (nccl_errstr_t)dlsym(h, "ncclGetErrorString");
+}
+
+Rccl &rccl() {   // resolved once, also when several host threads (one per GPU) make their first call together
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { resolve_rccl(r); });
     return r;
 }
 
