@@ -235,15 +235,17 @@ def agg_concat(feats, s, e):
 
 
 def agg_sum(feats, s, e):
-    """sum_message_op.py:9-10 -- Python sum(): ((0 + X_s) + X_{s+1}) + ..."""
-    acc = feats[s].astype(np.float32, copy=True)
-    for h in range(s + 1, e):
-        acc = acc + feats[h]
+    """sum_message_op.py:9-10 -- Python sum() over the SLICE feat_list[s:e] (an end beyond the list is clamped like any
+    Python slice): ((0 + X_s) + X_{s+1}) + ..."""
+    hops = feats[s:e]
+    acc = hops[0].astype(np.float32, copy=True)
+    for x in hops[1:]:
+        acc = acc + x
     return acc
 
 
 def agg_mean(feats, s, e):
-    """mean_message_op.py:9-10 -- sum then ONE true division by (e-s)"""
+    """mean_message_op.py:9-10 -- sum over the slice, then ONE true division by (e - s), whatever the slice held"""
     return agg_sum(feats, s, e) / np.float32(e - s)
 
 

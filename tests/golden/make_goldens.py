@@ -453,7 +453,40 @@ def gen_g7():
                         indptr=a.indptr.astype(np.int64), indices=a.indices.astype(np.int32), values=a.data.astype(np.float32))
 
 
+def gen_g8():
+    """hop-range quirks of the stateless aggregators, straight and on top of a real propagation (the fused
+    GraphOp.propagate_reduce path of sgl_amd must reproduce aggregate(propagate(...)) of the reference):
+    Mean divides by (end - start) whatever the slice held (mean_message_op.py:10), partial ranges, a single hop."""
+    out = {}
+    feats = agg_feats()
+    H = AGG_K + 1
+    for (s_, e_) in ((0, 10), (4, 5), (2, 9)):
+        out[f"mean|{s_}_{e_}"] = MeanMessageOp(s_, e_).aggregate(feats).numpy().copy()
+    for (s_, e_) in ((2, 3), (3, 10)):
+        out[f"sum|{s_}_{e_}"] = SumMessageOp(s_, e_).aggregate(feats).numpy().copy()
+    g = GRAPHS["pl256"]
+    x = hash_matrix(256, 20, seed=808)
+    K = 4
+    hops = LaplacianGraphOp(K, r=0.5).propagate(g, x)
+    hops_ppr = PprGraphOp(K, r=0.3, alpha=0.2).propagate(g, x)
+    for name, hp in (("lap", hops), ("ppr", hops_ppr)):
+        out[f"prop|{name}|last"] = LastMessageOp().aggregate(hp).numpy().copy()
+        out[f"prop|{name}|sum|0_{K + 1}"] = SumMessageOp(0, K + 1).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|sum|1_3"] = SumMessageOp(1, 3).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|mean|0_{K + 1}"] = MeanMessageOp(0, K + 1).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|mean|0_10"] = MeanMessageOp(0, 10).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|mean|2_4"] = MeanMessageOp(2, 4).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|simple_weighted|alpha0.85|0_{K + 1}"] = \
+            SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85).aggregate(hp).numpy().copy()
+        out[f"prop|{name}|simple_weighted|alpha0.3|1_{K + 1}"] = \
+            SimpleWeightedMessageOp(1, K + 1, "alpha", 0.3).aggregate(hp).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g8_ranges.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one family without touching the others
+        globals()["gen_" + sys.argv[2]]()
+        return
     save_graphs()
     gen_g1()
     gen_g2()
@@ -465,6 +498,7 @@ def main():
     gen_g5()
     gen_g6()
     gen_g7()
+    gen_g8()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

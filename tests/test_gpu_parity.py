@@ -693,6 +693,37 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)
 
 
+def test_hop_ranges_match_reference_goldens(goldens, cuda):
+    """G8 (recorded from the reference): Mean's divisor is (end - start) whatever the slice held, partial / single-hop
+    ranges; aggregate(propagate()) and the fused propagate_reduce both reproduce the reference -- sum / mean / last bit for
+    bit in strict order, simple_weighted within 1e-6"""
+    from sgl_amd.operators import message_op as m
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    g8 = goldens.npz("g8_ranges")
+    feats, _ = g3_feats(goldens, cuda)
+    for key, want in g8.items():
+        if key.startswith(("mean|", "sum|")):
+            kind, rng = key.split("|")
+            s_, e_ = (int(t) for t in rng.split("_"))
+            op = m.MeanMessageOp(s_, e_) if kind == "mean" else m.SumMessageOp(s_, e_)
+            assert np.array_equal(op.aggregate(feats).cpu().numpy(), want), key
+    g = goldens.graph("pl256")
+    x = hash_matrix(256, 20, seed=808)
+    K = 4
+    for name, gop in (("lap", LaplacianGraphOp(K, r=0.5, strict_order=True)), ("ppr", PprGraphOp(K, r=0.3, alpha=0.2, strict_order=True))):
+        hops = gop.propagate(g, x)
+        cases = [(m.LastMessageOp(), "last", True), (m.SumMessageOp(0, K + 1), f"sum|0_{K + 1}", True), (m.SumMessageOp(1, 3), "sum|1_3", True),
+                 (m.MeanMessageOp(0, K + 1), f"mean|0_{K + 1}", True), (m.MeanMessageOp(0, 10), "mean|0_10", True),
+                 (m.MeanMessageOp(2, 4), "mean|2_4", True),
+                 (m.SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85), f"simple_weighted|alpha0.85|0_{K + 1}", False),
+                 (m.SimpleWeightedMessageOp(1, K + 1, "alpha", 0.3), f"simple_weighted|alpha0.3|1_{K + 1}", False)]
+        for op, key, exact in cases:
+            want = g8[f"prop|{name}|{key}"]
+            for got in (op.aggregate(hops), gop.propagate_reduce(g, x, **op.fused_spec(K + 1))):
+                got = got.cpu().numpy()
+                assert (np.array_equal(got, want) if exact else oracle.parity_ok(got, want, 1e-6)), (name, key)
+
+
 def test_slab_hops_make_concat_a_view(goldens, cuda):
     """slab_hops: hop k is produced in column slice k of ONE [n, (K+1) d] buffer; the hops are bit-identical to the
     separate-buffer propagation and ConcatMessageOp over consecutive hops returns a zero-copy view of the slab"""

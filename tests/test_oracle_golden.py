@@ -173,3 +173,31 @@ def test_g7_ingest_coo_to_csr(goldens):
     # different order: 1 ulp there, exact everywhere else
     diff = val != g7["values"]
     assert diff.sum() <= 2 and np.allclose(val, g7["values"], rtol=3e-7, atol=0)
+
+
+def test_hop_range_quirks_match_reference(goldens):
+    """G8: Mean divides by (end - start) whatever the slice held, partial ranges, a single hop -- straight and on top of a
+    real propagation (what the fused propagate_reduce path of sgl_amd must reproduce)"""
+    g8 = goldens.npz("g8_ranges")
+    g3 = goldens.npz("g3_agg")
+    feats = [g3[f"feat{j}"] for j in range(5)]
+    for key in g8:
+        if key.startswith("mean|") or key.startswith("sum|"):
+            kind, rng = key.split("|")
+            s_, e_ = (int(t) for t in rng.split("_"))
+            got = oracle.agg_mean(feats, s_, e_) if kind == "mean" else oracle.agg_sum(feats, s_, e_)
+            assert np.array_equal(got, g8[key]), key
+    g = goldens.graph("pl256")
+    x = hash_matrix(256, 20, seed=808)
+    for name, norm in (("lap", oracle.laplacian_adj(g.indptr, g.indices, g.data, 256, 0.5)),
+                       ("ppr", oracle.ppr_adj(g.indptr, g.indices, g.data, 256, 0.3, 0.2))):
+        hops = oracle.propagate(norm, x, 4)
+        assert np.array_equal(oracle.agg_last(hops), g8[f"prop|{name}|last"])
+        assert np.array_equal(oracle.agg_sum(hops, 0, 5), g8[f"prop|{name}|sum|0_5"])
+        assert np.array_equal(oracle.agg_sum(hops, 1, 3), g8[f"prop|{name}|sum|1_3"])
+        assert np.array_equal(oracle.agg_mean(hops, 0, 5), g8[f"prop|{name}|mean|0_5"])
+        assert np.array_equal(oracle.agg_mean(hops, 0, 10), g8[f"prop|{name}|mean|0_10"])
+        assert np.array_equal(oracle.agg_mean(hops, 2, 4), g8[f"prop|{name}|mean|2_4"])
+        for a_, s_ in ((0.85, 0), (0.3, 1)):
+            got = oracle.agg_simple_weighted(hops, s_, 5, "alpha", a_)
+            assert oracle.parity_ok(got, g8[f"prop|{name}|simple_weighted|alpha{a_}|{s_}_5"], 1e-6)
