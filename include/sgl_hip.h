@@ -217,6 +217,13 @@ int sgl_norm_block_prepare(int64_t n, int64_t row0, int64_t nnz, const int64_t *
 int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
                          const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
                          double *d_out_val64, double *d_rowsum, void *stream);
+/* sgl_norm_block_build for a WHOLE matrix (row0 = 0) that also answers "is A symmetric, values included?": *d_sym_hash (one
+ * zero-initialised 64-bit word on the device) is 0 afterwards iff it is (every off-diagonal (i, j, v) adds +-h(min, max, v) in
+ * wrapping arithmetic; a false "symmetric" has probability 2^-64).  A symmetric A needs no transposition: sgl_norm_block_scale
+ * on the result IS adj_to_symmetric_norm -- no sort, no permutation, bit-identical to sgl_norm_execute. */
+int sgl_norm_build_symcheck(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                            int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col, double *d_out_val64, double *d_rowsum,
+                            uint64_t *d_sym_hash, void *stream);
 int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, const double *d_val64, double *d_colsum,
                           void *stream);
 int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_val64,

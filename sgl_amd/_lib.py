@@ -62,6 +62,8 @@ PROTOTYPES = {
     "sgl_norm_block_prepare": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
     "sgl_norm_block_build": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_build_symcheck": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "sgl_norm_block_colsum": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_norm_block_scale": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                      c_void_p, c_void_p, c_void_p]),

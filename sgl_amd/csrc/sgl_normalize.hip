@@ -160,17 +160,28 @@ __global__ __launch_bounds__(256) void degrees_kernel(const int64_t *__restrict_
 // ---- row-block normalisation (multi-GPU: every rank owns rows [row0, row0 + n) of A_hat) ---------------------------------
 // rows of T' = T + I for a block of rows of T (global column ids), as CSR with the diagonal merged / inserted in sorted
 // position; fp64 values; row sums
+__device__ __forceinline__ uint64_t sym_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 __global__ __launch_bounds__(256) void block_build_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                           const float *__restrict__ val, const int64_t *__restrict__ shift,
                                                           int64_t n, int64_t row0, int64_t *__restrict__ o_rowptr,
                                                           int32_t *__restrict__ o_col, double *__restrict__ o_val,
-                                                          double *__restrict__ rowsum) {
+                                                          double *__restrict__ rowsum, unsigned long long *sym_hash) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     if (i == n) {
         o_rowptr[n] = rowptr[n] + shift[n];
         return;
     }
+    // symmetry fingerprint (whole matrices only): every off-diagonal entry (i, j, v) adds +h(min, max, v) if i < j and
+    // -h(...) if i > j, in wrapping 64-bit arithmetic: the sum over a matrix with A[i,j] == A[j,i] bit for bit is 0, and
+    // it is non-zero for any other matrix except with probability 2^-64
+    uint64_t fp = 0;
     const int32_t me = (int32_t)(row0 + i);
     const int64_t b = rowptr[i], e = rowptr[i + 1];
     int64_t o = b + shift[i];
@@ -195,6 +206,11 @@ __global__ __launch_bounds__(256) void block_build_kernel(const int64_t *__restr
         o_val[o] = v;
         s += v;
         ++o;
+        if (sym_hash && c != me) {
+            const uint64_t lo_ = (uint64_t)(c < me ? c : me), hi_ = (uint64_t)(c < me ? me : c);
+            const uint64_t h = sym_mix(sym_mix(lo_ * 0x100000001B3ull + hi_) ^ (uint64_t)__float_as_uint(val[p]));
+            fp += (me < c) ? h : (0ull - h);
+        }
     }
     if (!placed) {
         o_col[o] = me;
@@ -202,6 +218,7 @@ __global__ __launch_bounds__(256) void block_build_kernel(const int64_t *__restr
         s += 1.0;
     }
     rowsum[i] = s;
+    if (sym_hash && fp) atomicAdd(sym_hash, (unsigned long long)fp);
 }
 
 __global__ __launch_bounds__(256) void block_diag_missing_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -436,9 +453,9 @@ SGL_EXPORT int sgl_norm_block_prepare(int64_t n, int64_t row0, int64_t nnz, cons
     return SGL_OK;
 }
 
-SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
-                                    const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
-                                    double *d_out_val64, double *d_rowsum, void *stream) {
+static int norm_block_build_impl(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                                 const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
+                                 double *d_out_val64, double *d_rowsum, unsigned long long *d_sym_hash, void *stream) {
     SGL_REQUIRE(n >= 0 && nnz >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_build: bad sizes");
     SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_block_build: nnz_out inconsistent (call sgl_norm_block_prepare)");
     SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX, "sgl_norm_block_build: nnz >= 2^32 per block not supported (use more row blocks)");
@@ -463,10 +480,28 @@ SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const 
     if ((rc = tmp.alloc(&scratch, bytes)) != SGL_OK) return rc;
     SGL_HIP_CHECK(rocprim::exclusive_scan(scratch, bytes, miss, shift, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
     hipLaunchKernelGGL(block_build_kernel, dim3(blocks_for(n + 1)), dim3(256), 0, st, d_rowptr, d_col, d_val, shift, n, row0,
-                       d_out_rowptr, d_out_col, d_out_val64, d_rowsum);
+                       d_out_rowptr, d_out_col, d_out_val64, d_rowsum, d_sym_hash);
     SGL_HIP_CHECK(hipGetLastError());
     SGL_HIP_CHECK(hipStreamSynchronize(st));  // temporaries are freed on return
     return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_block_build(int64_t n, int64_t row0, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col,
+                                    const float *d_val, int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col,
+                                    double *d_out_val64, double *d_rowsum, void *stream) {
+    return norm_block_build_impl(n, row0, nnz, d_rowptr, d_col, d_val, nnz_out, d_out_rowptr, d_out_col, d_out_val64, d_rowsum,
+                                 nullptr, stream);
+}
+
+// The same for a WHOLE matrix (row0 = 0, n rows and columns), additionally answering "is A symmetric, values included?":
+// *d_sym_hash (one zero-initialised 64-bit word on the device) ends up 0 iff it is (up to a 2^-64 collision).  A symmetric A
+// needs no transposition: A_hat[j,i] = (A'[j,i] * L[j]) * R[i] row by row (sgl_norm_block_scale) -- no sort, no permutation.
+SGL_EXPORT int sgl_norm_build_symcheck(int64_t n, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                                       int64_t nnz_out, int64_t *d_out_rowptr, int32_t *d_out_col, double *d_out_val64,
+                                       double *d_rowsum, uint64_t *d_sym_hash, void *stream) {
+    SGL_REQUIRE(d_sym_hash != nullptr, "sgl_norm_build_symcheck: NULL fingerprint word");
+    return norm_block_build_impl(n, 0, nnz, d_rowptr, d_col, d_val, nnz_out, d_out_rowptr, d_out_col, d_out_val64, d_rowsum,
+                                 reinterpret_cast<unsigned long long *>(d_sym_hash), stream);
 }
 
 SGL_EXPORT int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, const double *d_val64, double *d_colsum,

@@ -13,7 +13,7 @@ from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
-    "normalize_block", "degree_powers",
+    "normalize_block", "degree_powers", "PreparedAdjacency",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
 ]
 
@@ -314,22 +314,88 @@ class ChainGraph:
 def degree_powers(deg, r):
     """deg^(r-1), deg^(-r) with inf -> 0, evaluated on the HOST by numpy exactly as the reference does
     (operators/utils.py:79-84): the same libm, hence bit-identical degree factors.  deg: fp64 tensor (any device);
-    returns two fp64 CPU tensors."""
-    d = deg.detach().cpu().numpy().astype(np.float64, copy=False)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        left = np.power(d, r - 1)
-        left[np.isinf(left)] = 0.
-        right = np.power(d, -r)
-        right[np.isinf(right)] = 0.
-    return torch.from_numpy(left), torch.from_numpy(right)
+    returns two fp64 tensors on deg's device.  On the GPU only the DISTINCT degree values travel (a graph has far fewer
+    distinct degrees than nodes: 2.4 M nodes -> a few thousand values), the factors are gathered back on the device."""
+    def host(d_):
+        d = d_.detach().cpu().numpy().astype(np.float64, copy=False)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            left = np.power(d, r - 1)
+            left[np.isinf(left)] = 0.
+            right = np.power(d, -r)
+            right[np.isinf(right)] = 0.
+        return torch.from_numpy(left), torch.from_numpy(right)
+    if deg.is_cuda and deg.numel() > 4096:
+        uniq, inv = torch.unique(deg, return_inverse=True)
+        if uniq.numel() * 4 <= deg.numel():
+            lu, ru = host(uniq)
+            return lu.to(deg.device)[inv], ru.to(deg.device)[inv]
+    left, right = host(deg)
+    return left.to(deg.device), right.to(deg.device)
 
 
-def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_pow=True):
+class PreparedAdjacency:
+    """A + I of a whole matrix on the device (CSR, fp64 values), its row sums = degrees, and whether A is symmetric --
+    everything about a graph that does not depend on r / alpha (sgl_norm_build_symcheck).  One preparation serves every
+    normalisation of the same graph: the r-sweep of the NAFS task, the alpha-sweep of a PaSca search."""
+
+    def __init__(self, rowptr, col, val, n):
+        _lib.require_gpu()
+        dev = rowptr.device
+        nnz = int(col.numel())
+        self.n, self.src = int(n), (rowptr, col, val)
+        nnz_out = c_int64(0)
+        with torch.cuda.device(dev):
+            check(lib().sgl_norm_block_prepare(n, 0, nnz, ptr(rowptr), ptr(col), ctypes.byref(nnz_out), current_stream_ptr()),
+                  "sgl_norm_block_prepare")
+            m = nnz_out.value
+            self.rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            self.col = torch.empty(m, dtype=torch.int32, device=dev)
+            self.t64 = torch.empty(m, dtype=torch.float64, device=dev)
+            self.deg = torch.empty(n, dtype=torch.float64, device=dev)
+            fp = torch.zeros(1, dtype=torch.int64, device=dev)
+            check(lib().sgl_norm_build_symcheck(n, nnz, ptr(rowptr), ptr(col), ptr(val), m, ptr(self.rowptr), ptr(self.col),
+                                                ptr(self.t64), ptr(self.deg), ptr(fp), current_stream_ptr()),
+                  "sgl_norm_build_symcheck")
+            self.symmetric = int(fp.item()) == 0
+        self.nnz_out = m
+
+    def normalize(self, r, alpha=None, return_fp64=False):
+        """A_hat for this (r, alpha).  Symmetric A: one scaling pass over A + I, A_hat[j,i] = (A'[j,i] L[j]) R[i] -- no
+        transposition; otherwise the general pipeline (transpose by stable sort), re-using the degrees computed here.
+        Both are bit-identical to the reference's scipy result."""
+        dev = self.rowptr.device
+        left, right = degree_powers(self.deg, r)
+        with torch.cuda.device(dev):
+            if self.symmetric:
+                o_val = torch.empty(self.nnz_out, dtype=torch.float32, device=dev)
+                o_v64 = torch.empty(self.nnz_out, dtype=torch.float64, device=dev) if return_fp64 else None
+                check(lib().sgl_norm_block_scale(self.n, 0, ptr(self.rowptr), ptr(self.col), ptr(self.t64), ptr(left), ptr(right),
+                                                 int(alpha is not None), float(alpha if alpha is not None else 0.0), ptr(o_val),
+                                                 ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_scale")
+                return (self.rowptr, self.col, o_val, o_v64) if return_fp64 else (self.rowptr, self.col, o_val)
+            rowptr, col, val = self.src
+            m = self.nnz_out
+            o_ptr = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
+            o_col = torch.empty(m, dtype=torch.int32, device=dev)
+            o_val = torch.empty(m, dtype=torch.float32, device=dev)
+            o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
+            check(lib().sgl_norm_execute_lr(self.n, int(col.numel()), ptr(rowptr), ptr(col), ptr(val), ptr(left), ptr(right),
+                                            int(alpha is not None), float(alpha if alpha is not None else 0.0), m,
+                                            ptr(o_ptr), ptr(o_col), ptr(o_val), ptr(o_v64) if return_fp64 else None,
+                                            current_stream_ptr()), "sgl_norm_execute_lr")
+        return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
+
+
+def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_pow=True, prepared=None):
     """Device adj_to_symmetric_norm (+ optional PPR mix): canonical CSR of A on device -> CSR of A_hat.
     rowptr int64 [n+1], col int32, val float32 (CUDA).  Returns (rowptr, col, val[, val64]).
-    host_pow: the two degree powers (n values) are evaluated by the host's numpy like the reference's, everything per
-    non-zero stays on the GPU; the rounded A_hat is then bit-identical to scipy's."""
+    host_pow (default): the two degree powers are evaluated by the host's numpy like the reference's, everything per
+    non-zero stays on the GPU; the rounded A_hat is then bit-identical to scipy's.  `prepared`: a PreparedAdjacency of the
+    same matrix (re-used across r / alpha); host_pow=False is the all-device pipeline with the GPU's pow()."""
     _lib.require_gpu()
+    if host_pow:
+        prep = prepared if prepared is not None else PreparedAdjacency(rowptr, col, val, n)
+        return prep.normalize(r, alpha, return_fp64=return_fp64)
     nnz = int(col.numel())
     dev = rowptr.device
     nnz_out = c_int64(0)
@@ -341,19 +407,9 @@ def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_po
         o_col = torch.empty(m, dtype=torch.int32, device=dev)
         o_val = torch.empty(m, dtype=torch.float32, device=dev)
         o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
-        if host_pow:
-            deg = torch.empty(n, dtype=torch.float64, device=dev)
-            check(lib().sgl_norm_degrees(n, 0, ptr(rowptr), ptr(col), ptr(val), ptr(deg), current_stream_ptr()),
-                  "sgl_norm_degrees")
-            left, right = (t.to(dev) for t in degree_powers(deg, r))
-            check(lib().sgl_norm_execute_lr(n, nnz, ptr(rowptr), ptr(col), ptr(val), ptr(left), ptr(right),
-                                            int(alpha is not None), float(alpha if alpha is not None else 0.0), m,
-                                            ptr(o_ptr), ptr(o_col), ptr(o_val), ptr(o_v64) if return_fp64 else None,
-                                            current_stream_ptr()), "sgl_norm_execute_lr")
-        else:
-            check(lib().sgl_norm_execute(n, nnz, ptr(rowptr), ptr(col), ptr(val), float(r), int(alpha is not None),
-                                         float(alpha if alpha is not None else 0.0), m, ptr(o_ptr), ptr(o_col), ptr(o_val),
-                                         ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_execute")
+        check(lib().sgl_norm_execute(n, nnz, ptr(rowptr), ptr(col), ptr(val), float(r), int(alpha is not None),
+                                     float(alpha if alpha is not None else 0.0), m, ptr(o_ptr), ptr(o_col), ptr(o_val),
+                                     ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_execute")
     return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
 
 
@@ -399,9 +455,8 @@ def normalize_block(rowptr, col, val, row0, n_cols, r, alpha=None, symmetric=Tru
                   "sgl_norm_block_colsum")
             if multi:
                 dist.all_reduce(deg, group=group)
-        left, right = degree_powers(deg, r)
-        left_loc = left[row0:row0 + n_loc].contiguous().to(dev)
-        right = right.to(dev)
+        left, right = degree_powers(deg.to(dev), r)
+        left_loc = left[row0:row0 + n_loc].contiguous()
         o_val = torch.empty(m, dtype=torch.float32, device=dev)
         o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
         check(lib().sgl_norm_block_scale(n_loc, row0, ptr(o_ptr), ptr(o_col), ptr(t64), ptr(left_loc), ptr(right),

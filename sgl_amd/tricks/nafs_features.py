@@ -4,10 +4,11 @@ Reference: NodeClusteringNAFS._k_hop_cluster (sgl/tasks/node_clustering.py:205-2
 tasks/link_prediction.py:233-284: for every r in r_list normalise the adjacency (D^{r-1}(A+I)^T D^{-r}), propagate
 `hops` times with torch.spmm, weight the hops per node by softmax(cosine similarity to hop 0) -- an O(N * hops)
 Python loop in the reference -- and finally ensemble the per-r results (mean / max / concat; 'simple' = plain
-hops-step propagation with the first r).  Here the raw adjacency is uploaded ONCE; every r is normalised from that
-device copy (sgl_norm_*), re-using one SpMM plan (the sparsity structure does not depend on r: sgl_csr_set_values) and
-one set of hop buffers; the fused NAFS kernel reads each hop of an r exactly once, and one streaming reduction kernel
-forms the ensemble.  Nothing but the first upload crosses PCIe."""
+hops-step propagation with the first r).  Here the raw adjacency is uploaded ONCE and prepared ONCE (A + I, degrees,
+symmetry: device.PreparedAdjacency); every r then costs the degree powers of the distinct degrees plus one scaling pass
+(symmetric graphs: no transposition at all), re-using one SpMM plan (the sparsity structure does not depend on r:
+sgl_csr_set_values) and one set of hop buffers; the fused NAFS kernel reads each hop of an r exactly once, and one
+streaming reduction kernel forms the ensemble.  Nothing but the first upload crosses PCIe."""
 import scipy.sparse as sp
 import torch
 
@@ -37,8 +38,9 @@ def nafs_ensemble_features(adj, x, hops, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), me
     hop_bufs = [dev.alloc_rows(n, d, device) for _ in range(hops)]                  # shared by all r
     csr = None
     per_r = []
+    prep = dev.PreparedAdjacency(dadj.rowptr, dadj.col, dadj.val, n)               # r-independent part, once
     for r in r_list:
-        rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, r, None)
+        rowptr, col, val = prep.normalize(r, None)
         if csr is None:
             csr = dev.DeviceCSR(rowptr, col, val, dadj.shape, strict=strict_order)  # one plan: the structure is r-independent
         else:

@@ -459,6 +459,35 @@ def test_device_normalisation_matches_reference_goldens(goldens, cuda, gname):
     assert n_diff32 == 0, (gname, n_diff32, total)
 
 
+def test_prepared_adjacency_symmetric_fast_path(goldens, cuda):
+    """PreparedAdjacency: A + I, degrees and the symmetry fingerprint once per graph; a symmetric A is normalised without
+    any transposition and is bit-identical to the general pipeline (and hence to the reference goldens); a directed or
+    value-asymmetric A is detected and takes the general path; one preparation serves every (r, alpha)."""
+    from sgl_amd.operators.utils import canonical_csr
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(cuda)  # noqa: E731
+    g1 = goldens.npz("g1_norm")
+    for gname, want_sym in (("sym64", True), ("pl2000", True), ("dir40", False)):
+        g = canonical_csr(goldens.graph(gname))
+        n = g.shape[0]
+        prep = dev.PreparedAdjacency(to(g.indptr, np.int64), to(g.indices, np.int32), to(g.data, np.float32), n)
+        assert prep.symmetric == want_sym, gname
+        for kind, r, a in G1_VARIANTS:
+            key = f"{gname}|{kind}|{r}" + ("" if a is None else f"|{a}")
+            p_, c_, v32, v64 = prep.normalize(r, a, return_fp64=True)
+            assert np.array_equal(p_.cpu().numpy(), g1[gname + "|indptr"]) and np.array_equal(c_.cpu().numpy(), g1[gname + "|indices"])
+            assert np.array_equal(v32.cpu().numpy(), g1[key].astype(np.float32)), key      # bit-identical to scipy's rounding
+            assert np.abs(v64.cpu().numpy() - g1[key]).max() <= 1e-14 * np.abs(g1[key]).max()
+    # symmetric structure but ONE asymmetric value: not symmetric
+    g = canonical_csr(goldens.graph("pl2000")).copy()
+    i = int(np.nonzero(np.diff(g.indptr) > 0)[0][5])
+    g.data[g.indptr[i]] = 3.0
+    prep = dev.PreparedAdjacency(to(g.indptr, np.int64), to(g.indices, np.int32), to(g.data, np.float32), g.shape[0])
+    assert not prep.symmetric
+    ref = oracle.sym_norm_csr(g.indptr, g.indices, g.data, g.shape[0], 0.5, None)
+    _, _, v32 = prep.normalize(0.5)
+    assert np.array_equal(v32.cpu().numpy(), ref[2].astype(np.float32))
+
+
 @pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
 def test_row_block_normalisation_matches_full(goldens, cuda, gname):
     """sgl_norm_block_*: every rank of a row-sharded job normalises only ITS rows; the blocks laid end to end are

@@ -37,8 +37,14 @@ def main():
     device = torch.device("cuda", 0)
     a_ptr, a_col, a_val = synthetic.chung_lu_torch(n, wl["m"], wl["d_max"], seed=0, device=device)
     x0 = synthetic.features_torch(n, d, seed=0, device=device)
+    t_prep, prep = timed(lambda: dev.PreparedAdjacency(a_ptr, a_col, a_val, n), reps=1)
+    print(f"SWEEP prepare (A + I, degrees, symmetry check; once per graph) ms={t_prep:8.2f} symmetric={prep.symmetric}", flush=True)
     for name, r, alpha in (("laplacian r=0.5", 0.5, None), ("ppr a=0.1", 0.5, 0.1), ("ppr a=0.2", 0.5, 0.2), ("ppr a=0.3", 0.5, 0.3)):
-        t_norm, (rowptr, col, val) = timed(lambda: dev.normalize_adj(a_ptr, a_col, a_val, n, r, alpha), reps=1)
+        t_norm, (rowptr, col, val) = timed(lambda: prep.normalize(r, alpha), reps=2)
+        if name.startswith("lap"):
+            t_full, _ = timed(lambda: dev.normalize_adj(a_ptr, a_col, a_val, n, r, alpha), reps=2)
+            t_dev, _ = timed(lambda: dev.normalize_adj(a_ptr, a_col, a_val, n, r, alpha, host_pow=False), reps=2)
+            print(f"SWEEP normalise from scratch ms={t_full:8.2f} (prepare + this r); general all-device pipeline with sort ms={t_dev:8.2f}", flush=True)
         csr = dev.DeviceCSR(rowptr, col, val, (n, n))
 
         def prop():
