@@ -641,6 +641,7 @@ static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t s
     do {                                               \
         if (n_hops <= 4) SGL_RR(L, C, 4);              \
         else if (n_hops <= 8) SGL_RR(L, C, 8);         \
+        else if (n_hops <= 12) SGL_RR(L, C, 12);       \
         else SGL_RR(L, C, 16);                         \
     } while (0)
             if (two_rows) SGL_RR_H(32, 2);
@@ -818,6 +819,7 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     do {                                               \
         if (n_hops <= 4) SGL_NF(L, C, 4);              \
         else if (n_hops <= 8) SGL_NF(L, C, 8);         \
+        else if (n_hops <= 12) SGL_NF(L, C, 12);       \
         else SGL_NF(L, C, 16);                         \
     } while (0)
         if (two_rows) SGL_NF_H(32, 2);
