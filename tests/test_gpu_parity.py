@@ -1405,6 +1405,85 @@ def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
     assert empty.nnz == 0 and empty.rowptr.cpu().tolist() == [0] * 6
 
 
+def test_sharded_ingest_builds_only_this_ranks_rows(goldens, cuda, tmp_path):
+    """load_custom_homo_raw_sharded: the row blocks of every rank, stitched, are the CSR the whole-matrix ingest builds
+    (= Edge's csr_matrix, G7) -- for several world sizes and with chunks so small that every pass takes many of them"""
+    from sgl_amd import io
+    g7 = goldens.npz("g7_ingest")
+    n = int(g7["n"])
+    x = hash_matrix(n, 12, seed=5)
+    io.save_custom_homo_raw(str(tmp_path), g7["row"], g7["col"], g7["data"], x=x, labels=np.arange(n) % 3)
+    whole = io.load_custom_homo_raw(str(tmp_path), device=cuda)["adj"]
+    wp, wc, wv = whole.rowptr.cpu().numpy(), whole.col.cpu().numpy(), whole.val.cpu().numpy()
+    for world, chunk in ((1, 1 << 20), (3, 97), (4, 1000)):
+        parts = [io.load_custom_homo_raw_sharded(str(tmp_path), r, world, device=cuda, chunk_edges=chunk) for r in range(world)]
+        b = parts[0]["bounds"]
+        assert b[0] == 0 and b[-1] == n and all(np.array_equal(b, q["bounds"]) for q in parts)
+        for r, q in enumerate(parts):
+            blk = q["block"]
+            assert (blk.lo, blk.hi, blk.n) == (int(b[r]), int(b[r + 1]), n) and blk.shape == (blk.hi - blk.lo, n)
+            a0, a1 = int(wp[blk.lo]), int(wp[blk.hi])
+            assert np.array_equal(blk.rowptr.cpu().numpy(), wp[blk.lo:blk.hi + 1] - a0)
+            assert np.array_equal(blk.col.cpu().numpy(), wc[a0:a1])
+            assert np.array_equal(blk.val.cpu().numpy(), wv[a0:a1])          # same sort, same summation order: bit-equal
+            assert np.array_equal(q["x"], x[blk.lo:blk.hi]) and q["y"].shape == (n,)
+        if world > 1:   # nnz-balanced: no block holds more than its share plus one row's worth
+            sizes = [q["block"].nnz + q["block"].n_local for q in parts]
+            assert max(sizes) <= (whole.nnz + n) / world + int(np.diff(wp).max()) + 1
+    with pytest.raises(ValueError):
+        io.load_custom_homo_raw_sharded(str(tmp_path), 3, 3, device=cuda)
+
+
+def _ingest_rank_worker(rank, world, port, raw_dir, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    import torch.distributed as dist
+    import oracle as orc
+    from sgl_amd import io
+    from sgl_amd.dist import ShardedGraphOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        q = io.load_custom_homo_raw_sharded(raw_dir, rank, world, device="cuda:0", chunk_edges=211, group=dist.group.WORLD)
+        blk = q["block"]
+        op = ShardedGraphOp(2, r=0.5, strict_order=True, pieces=2, col_chunks=2)
+        hops = op.propagate(blk, q["x"])                 # disk -> this rank's rows -> row-sharded propagation
+        f = np.load(_os.path.join(raw_dir, "adj_matrix.npz"))
+        n = blk.n
+        full = sp.csr_matrix((f["data"], (f["row"], f["col"])), shape=(n, n))
+        full.sort_indices()
+        x = np.load(_os.path.join(raw_dir, "x.npy"))
+        ref = orc.propagate(orc.laplacian_adj(full.indptr, full.indices, full.data, n, 0.5), x, 2)
+        ok = 0 < blk.hi - blk.lo < n and (op.lo, op.hi) == (blk.lo, blk.hi)
+        for h in range(3):
+            ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][blk.lo:blk.hi], 1e-5)
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ingest_feeds_row_sharded_propagation(goldens, cuda, tmp_path):
+    """two processes: raw files -> each rank's row block (edge counts all-reduced over the group) -> ShardedGraphOp on
+    the block; nobody ever holds the whole adjacency"""
+    import socket
+    import torch.multiprocessing as mp
+    from sgl_amd import io
+    g7 = goldens.npz("g7_ingest")
+    n = int(g7["n"])
+    raw = tmp_path / "raw"
+    w = np.abs(g7["data"]) + 0.5                     # both directions of every edge: a symmetric weighted graph
+    io.save_custom_homo_raw(str(raw), np.concatenate([g7["row"], g7["col"]]), np.concatenate([g7["col"], g7["row"]]),
+                            np.concatenate([w, w]), x=hash_matrix(n, 20, seed=9))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ingest_rank_worker, args=(2, port, str(raw), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
 def test_hashed_generator_device_equals_host_mirror(cuda):
     """sgl_synth_* (rows generated per shard on device, keyed by (seed, row)) against the numpy mirror, bit for bit: small
     blocks anywhere in a papers100M-sized id range, and a block large enough (> 2^30 threads) that the kernels must
