@@ -148,13 +148,17 @@ int sgl_chain_graph_destroy(sgl_graph_t *graph);
 int sgl_spmm_axpb_clamp_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                             float alpha, const float *d_res, int64_t ldres, float lo, float hi, void *stream);
 
-/* Y = A . X and, in the same pass, the running aggregate  ACC <- ACC + Y  (weighted = 0)  or  ACC <- ACC + w * Y  (weighted != 0:
- * rounded product, then add), followed by ACC <- ACC / divisor when divisor != 1 (Mean's single true division, on the last
- * hop).  Same arithmetic and order as sgl_hop_reduce_f32 over the materialised hops (SUM / MEAN / WSUM): the Sum / Mean /
- * SimpleWeighted MessageOps (message_op/sum_message_op.py:10, mean_message_op.py:10, simple_weighted_message_op.py:41-56)
- * then cost no pass of their own and no hop matrix has to be kept.  ACC is initialised by the caller (X_s, or w_s * X_s). */
+/* Y = A . X and, in the same pass, the running aggregate over hops:
+ *   SGL_ACC_SUM   ACC <- ACC + Y                    SGL_ACC_WSUM  ACC <- ACC + w * Y   (rounded product, then add)
+ *   SGL_ACC_MAX   ACC <- max(ACC, Y)                SGL_ACC_MIN   ACC <- min(ACC, Y)   (a NaN in any hop wins, as in torch)
+ * followed, for the two sums, by ACC <- ACC / divisor when divisor != 1 (Mean's single true division, on the last hop).
+ * Same arithmetic and order as sgl_hop_reduce_f32 over the materialised hops (SUM / MEAN / WSUM / MAX / MIN): the Sum / Mean /
+ * SimpleWeighted / Max / Min MessageOps (message_op/sum_message_op.py:10, mean_message_op.py:10,
+ * simple_weighted_message_op.py:41-56, max_message_op.py:10, min_message_op.py:10) then cost no pass of their own and no hop
+ * matrix has to be kept.  ACC is initialised by the caller (X_s, or w_s * X_s). */
+enum { SGL_ACC_SUM = 0, SGL_ACC_WSUM = 1, SGL_ACC_MAX = 2, SGL_ACC_MIN = 3 };
 int sgl_spmm_acc_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
-                     int64_t ldacc, float w, int weighted, float divisor, void *stream);
+                     int64_t ldacc, float w, int mode, float divisor, void *stream);
 
 /* ---- multi-GPU exchange (row-sharded layout): the all-gather of the feature block between hops ---------------- */
 /* Rank `rank` of `world` owns rows [h_bounds[rank], h_bounds[rank+1]) of the [n, ldx] replica d_x (row-major, whole padded

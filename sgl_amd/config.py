@@ -11,7 +11,7 @@ strict_order  True  -> SpMM walks every row as ONE sequential fmaf chain (bit-ex
 cache_adj     reuse the normalised device adjacency across propagate() calls on the same scipy matrix
 slab_hops     GraphOp.propagate writes hop k into column slice k of ONE [N, (K+1) d] buffer (when d % 4 == 0), so that
               ConcatMessageOp over consecutive hops is a zero-copy view of it instead of a copy of every hop
-fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / simple_weighted aggregation into the SpMM epilogue
+fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / simple_weighted aggregation into the SpMM epilogue
               (GraphOp.propagate_reduce): no pass over the hop matrices, only two hop buffers alive; the K+1 hop list
               (`_processed_feat_list`) is then not kept (the reference's own consumers never read it for these ops).
               `last` costs nothing and is always folded.  sum / mean / weighted cost ~2 % more time than the separate

@@ -156,8 +156,8 @@ struct Epilogue {
     int on;
     // running aggregate over hops, updated where the row is produced (Sum / Mean / SimpleWeighted MessageOps without a
     // second pass over the hop matrices): acc_mode 1: ACC += Y, 2: ACC += w * Y (rounded product, then add: the order of
-    // hop_reduce_kernel), +4: ACC /= acc_div afterwards (Mean's one true division, on the last hop).  Y itself is stored
-    // unchanged: it is the next hop's input.
+    // hop_reduce_kernel), 3: ACC = max(ACC, Y) (+8: min), +4: ACC /= acc_div afterwards (Mean's one true division, on the
+    // last hop).  Y itself is stored unchanged: it is the next hop's input.
     float *acc;         // row pointer already applied (nullptr = off)
     int64_t ldacc;
     float acc_w, acc_div;
@@ -165,6 +165,8 @@ struct Epilogue {
 };
 
 __device__ __forceinline__ float acc_apply(float a, float y, const Epilogue &e) {
+    if ((e.acc_mode & 3) == 3)   // running extremum with torch's NaN rule (a NaN in any hop wins), +8: min instead of max
+        return (e.acc_mode & 8) ? ((y < a || y != y) ? y : a) : ((y > a || y != y) ? y : a);
     a = ((e.acc_mode & 3) == 2) ? __fadd_rn(a, __fmul_rn(y, e.acc_w)) : __fadd_rn(a, y);
     if (e.acc_mode & 4) a = __fdiv_rn(a, e.acc_div);
     return a;
@@ -1007,19 +1009,22 @@ SGL_EXPORT int sgl_chain_graph_destroy(sgl_graph_t *g) {
     return SGL_OK;
 }
 
-// Y = A X  and, in the same pass,  ACC <- ACC + w * Y  [ / divisor ]: the running aggregate of the Sum / Mean /
-// SimpleWeighted MessageOps (message_op/{sum,mean,simple_weighted}_message_op.py) kept up to date where each row is
-// produced, so those aggregators need no pass of their own over the hop matrices and no hop needs to be kept.
+// Y = A X  and, in the same pass,  ACC <- ACC + w * Y  [ / divisor ]  or  ACC <- max / min(ACC, Y): the running aggregate of
+// the Sum / Mean / SimpleWeighted / Max / Min MessageOps (message_op/{sum,mean,simple_weighted,max,min}_message_op.py) kept
+// up to date where each row is produced, so those aggregators need no pass of their own over the hop matrices and no hop
+// needs to be kept.
 SGL_EXPORT int sgl_spmm_acc_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
-                                int64_t ldacc, float w, int weighted, float divisor, void *stream) {
+                                int64_t ldacc, float w, int mode, float divisor, void *stream) {
     SGL_REQUIRE(d_acc != nullptr, "sgl_spmm_acc_f32: NULL accumulator");
     SGL_REQUIRE(!(divisor == 0.f), "sgl_spmm_acc_f32: zero divisor");
+    SGL_REQUIRE(mode >= SGL_ACC_SUM && mode <= SGL_ACC_MIN, "sgl_spmm_acc_f32: unknown mode %d", mode);
+    SGL_REQUIRE(mode < SGL_ACC_MAX || divisor == 1.f, "sgl_spmm_acc_f32: max / min take no divisor");
     EpiHost eh;
     eh.acc = d_acc;
     eh.ldacc = ldacc;
     eh.acc_w = w;
     eh.acc_div = divisor;
-    eh.acc_mode = (weighted ? 2 : 1) | (divisor != 1.f ? 4 : 0);
+    eh.acc_mode = mode >= SGL_ACC_MAX ? (3 | (mode == SGL_ACC_MIN ? 8 : 0)) : ((mode == SGL_ACC_WSUM ? 2 : 1) | (divisor != 1.f ? 4 : 0));
     return spmm_impl(h, d_x, ldx, d_y, ldy, d, 0, stream, eh, "sgl_spmm_acc_f32");
 }
 

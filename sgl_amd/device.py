@@ -164,9 +164,13 @@ class DeviceCSR:
                                      current_stream_ptr()), "sgl_spmm_f32")
         return out
 
-    def spmm_acc(self, x, out, acc, w=1.0, weighted=False, divisor=1.0):
+    ACC_MODES = {"sum": 0, "wsum": 1, "max": 2, "min": 3}
+
+    def spmm_acc(self, x, out, acc, w=1.0, weighted=False, divisor=1.0, mode=None):
         """out = A @ x and, in the same kernel, acc <- acc + out (weighted: acc + w * out), then acc / divisor if
-        divisor != 1 (sgl_spmm_acc_f32): the running hop aggregate of Sum / Mean / SimpleWeighted"""
+        divisor != 1, or acc <- max / min(acc, out) (sgl_spmm_acc_f32): the running hop aggregate of Sum / Mean /
+        SimpleWeighted / Max / Min"""
+        mode = self.ACC_MODES[mode] if mode is not None else int(bool(weighted))
         _check_mat(x, "x")
         _check_mat(out, "out")
         _check_mat(acc, "acc")
@@ -174,7 +178,7 @@ class DeviceCSR:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
         with torch.cuda.device(self.device):
             check(lib().sgl_spmm_acc_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), x.shape[1], ptr(acc), _ld(acc),
-                                         float(w), int(bool(weighted)), float(divisor), current_stream_ptr()),
+                                         float(w), mode, float(divisor), current_stream_ptr()),
                   "sgl_spmm_acc_f32")
         return out
 

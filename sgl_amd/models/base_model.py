@@ -51,7 +51,7 @@ class BaseSGAPModel(nn.Module):
         gop = self._pre_graph_op
         if (config.fuse_aggregate is not False and not self._pre_msg_learnable and hasattr(gop, "propagate_reduce")
                 and hasattr(self._pre_msg_op, "fused_spec") and not gop._opt("host_output")):
-            # last / sum / mean / simple_weighted: accumulated in the SpMM epilogue, the K+1 hop matrices never coexist
+            # last / sum / mean / max / min / simple_weighted: accumulated in the SpMM epilogue, the K+1 hop matrices never coexist
             spec = self._pre_msg_op.fused_spec(gop._prop_steps + 1)
             if spec is not None and (spec["kind"] == "last" or config.fuse_aggregate is True or self._hops_are_heavy(feature)):
                 with torch.no_grad():

@@ -53,7 +53,8 @@ class AdjIdentity:
 
 def _lib_reduce(kind):
     from .. import _lib
-    return {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "wsum": _lib.SGL_REDUCE_WSUM}[kind]
+    return {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "wsum": _lib.SGL_REDUCE_WSUM,
+            "max": _lib.SGL_REDUCE_MAX, "min": _lib.SGL_REDUCE_MIN}[kind]
 
 
 class GraphOp:
@@ -127,10 +128,10 @@ class GraphOp:
         return cur
 
     def propagate_reduce(self, adj, feature, kind, start=0, end=None, weights=None, divisor=None):
-        """The hop aggregate WITHOUT the hops: `last`, `sum`, `mean` or `wsum` (fixed weights) of hops start..end-1 of
+        """The hop aggregate WITHOUT the hops: `last`, `sum`, `mean`, `max`, `min` or `wsum` (fixed weights) of hops start..end-1 of
         [X, A_hat X, ..., A_hat^K X], accumulated in the SpMM epilogue where each row is produced
         (sgl_spmm_acc_f32).  Same arithmetic and order as aggregate(propagate(...)) with the corresponding MessageOp
-        (bit-identical for last / sum / mean; wsum identical to the HIP aggregator), but no pass over the hop matrices
+        (bit-identical for last / sum / mean / max / min; wsum identical to the HIP aggregator), but no pass over the hop matrices
         and only two hop buffers alive at any time instead of K + 1.  Returns the [n, d] device tensor, or None when the
         hop range is not one this path handles (the caller then uses propagate + aggregate)."""
         K = self._prop_steps
@@ -155,7 +156,7 @@ class GraphOp:
         def begin(x_s):           # the aggregate's first term, with the aggregator kernel's own arithmetic
             if kind == "wsum":
                 return dev.padded_parent(dev.hop_reduce(_lib_reduce("wsum"), [x_s[:, :d]], torch.tensor(w[:1])))
-            return dev.padded_parent(dev.hop_reduce(_lib_reduce("sum"), [x_s[:, :d]]))
+            return dev.padded_parent(dev.hop_reduce(_lib_reduce(kind if kind in ("max", "min") else "sum"), [x_s[:, :d]]))
 
         acc = begin(src) if (s == 0 and kind != "last") else None
         x = src
@@ -164,7 +165,8 @@ class GraphOp:
             if acc is not None:
                 last = h == e - 1
                 div = float(divisor if divisor is not None else (e - s)) if (kind == "mean" and last) else 1.0
-                self._adj.spmm_acc(x, y, acc, w=w[h - s] if kind == "wsum" else 1.0, weighted=kind == "wsum", divisor=div)
+                self._adj.spmm_acc(x, y, acc, w=w[h - s] if kind == "wsum" else 1.0, divisor=div,
+                                   mode=kind if kind in ("wsum", "max", "min") else "sum")
             else:
                 self._adj.spmm(x, out=y)
                 if h == s and kind != "last":

@@ -81,7 +81,7 @@ def _reduction(kind, doc):
             return reduce_hops(kind, hops)
 
         def fused_spec(self, n_hops):
-            if kind not in ("sum", "mean") or not (isinstance(self._start, int) and isinstance(self._end, int)):
+            if kind not in ("sum", "mean", "max", "min") or not (isinstance(self._start, int) and isinstance(self._end, int)):
                 return None
             if self._start < 0 or self._end <= self._start:
                 return None

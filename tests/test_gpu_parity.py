@@ -673,7 +673,7 @@ def test_simple_aggregators_bit_exact(goldens, cuda):
 @pytest.mark.parametrize("d", [100, 147, 7, 64])
 def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     """GraphOp.propagate_reduce (sgl_spmm_acc_f32: the running aggregate updated where each row is produced) against
-    aggregate(propagate(...)): bit-identical for last / sum / mean / simple_weighted, any hop range, also when long rows
+    aggregate(propagate(...)): bit-identical for last / sum / mean / max / min / simple_weighted, any hop range, also when long rows
     are split (fix-up path) and when the range ends before the last hop."""
     from sgl_amd.operators import message_op as m
     from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
@@ -685,7 +685,8 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     ops = [m.LastMessageOp(), m.SumMessageOp(0, K + 1), m.SumMessageOp(1, 4), m.SumMessageOp(2, 3), m.MeanMessageOp(0, K + 1),
            m.MeanMessageOp(1, K + 1), m.MeanMessageOp(0, 10), m.MeanMessageOp(K, K + 1),
            m.SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85), m.SimpleWeightedMessageOp(1, K + 1, "alpha", 0.3),
-           m.SimpleWeightedMessageOp(0, 3, "hand_crafted", [0.5, -0.25, 2.0])]
+           m.SimpleWeightedMessageOp(0, 3, "hand_crafted", [0.5, -0.25, 2.0]),
+           m.MaxMessageOp(0, K + 1), m.MaxMessageOp(1, 4), m.MinMessageOp(0, K + 1), m.MinMessageOp(2, K + 1), m.MaxMessageOp(3, 4)]
     for gop in (LaplacianGraphOp(K, r=0.5), PprGraphOp(K, r=0.3, alpha=0.2), LaplacianGraphOp(K, r=0.5, strict_order=True)):
         hops = gop.propagate(a, x)
         for op in ops:
@@ -695,7 +696,15 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
             want = op.aggregate(hops)
             assert fused.shape == want.shape and torch.equal(fused, want), (type(op).__name__, op._start, op._end, d)
     # ops that cannot ride on the SpMM say so; weird ranges fall back
-    assert m.MaxMessageOp(0, 3).fused_spec(5) is None and m.ConcatMessageOp(0, 3).fused_spec(5) is None
+    assert m.ConcatMessageOp(0, 3).fused_spec(5) is None
+    # a NaN in any hop wins in max / min (torch's rule), also in the running form
+    xn = x.copy()
+    xn[7, 0] = np.nan
+    hn = gop.propagate(a, xn)
+    for op in (m.MaxMessageOp(0, K + 1), m.MinMessageOp(1, K + 1)):
+        fused, want = gop.propagate_reduce(a, xn, **op.fused_spec(K + 1)), op.aggregate(hn)
+        assert torch.isnan(want).any() and torch.equal(torch.isnan(fused), torch.isnan(want))
+        assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(want))
     assert gop.propagate_reduce(a, x, kind="sum", start=3, end=2) is None
     # the reference's exceptions come first, exactly as in propagate()
     with pytest.raises(TypeError):
