@@ -1,24 +1,24 @@
 // Memory-system probes (measurement infrastructure, not part of the propagation path): what the MI355X delivers to the
 // two access patterns the SpMM is made of, with no CSR stream, no row bookkeeping and no stores in the way --
-//   * sgl_probe_stream_f32: every lane reads consecutive 16-byte words of one large array (sequential-read ceiling);
+//   * sgl_probe_stream_f32: every lane reads one 16-byte word of one large array (sequential-read ceiling);
 //   * sgl_probe_gather_f32: every wavefront reads whole rows table[idx[i], 0:row_floats] for a list of row ids with
 //     U independent rows in flight per lane (random-row-gather ceiling for a given row width / table size).
 // bench.py / tools/mem_ceilings.py report the SpMM kernel's rate next to these ceilings.
+#include <algorithm>
+
 #include "sgl_common.h"
 
 namespace {
 
 using F4 = float __attribute__((ext_vector_type(4)));
 
+// One 16-byte word per thread and as many blocks as that takes: on this memory system the plain mapping beats every
+// persistent / grid-stride variant (tools/native/stream_patterns.hip, profiles/r02_stream_patterns.log: 6.8 TB/s against
+// 5.5-6.5 for grid-stride loops with 1k-16k blocks); the loop only serves arrays beyond 2^31 blocks.
 __global__ __launch_bounds__(256) void probe_stream_kernel(const F4 *__restrict__ x, int64_t n_vec, float *__restrict__ sink) {
     F4 acc = {0.f, 0.f, 0.f, 0.f};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n_vec; i += 4 * stride) {
-        const F4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
-        acc += a + b + c + d;
-    }
-    for (; i < n_vec; i += stride) acc += x[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) acc += x[i];
     const float s = acc[0] + acc[1] + acc[2] + acc[3];
     if (s == 1.2345678e-30f) sink[0] = s;   // never true for real data: keeps the loads alive without a store stream
 }
@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const float *__restri
 
 SGL_EXPORT int sgl_probe_stream_f32(const float *d_x, int64_t n_floats, float *d_sink, void *stream) {
     SGL_REQUIRE(d_x && d_sink && n_floats >= 4 && (reinterpret_cast<uintptr_t>(d_x) % 16) == 0, "sgl_probe_stream_f32: bad arguments");
-    hipLaunchKernelGGL(probe_stream_kernel, dim3(256 * 8), dim3(256), 0, sgl::as_stream(stream),
-                       reinterpret_cast<const F4 *>(d_x), n_floats / 4, d_sink);
+    const int64_t n_vec = n_floats / 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_vec + 255) / 256, (int64_t)1 << 30);
+    hipLaunchKernelGGL(probe_stream_kernel, dim3(blocks), dim3(256), 0, sgl::as_stream(stream),
+                       reinterpret_cast<const F4 *>(d_x), n_vec, d_sink);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sgl::fail((int)e, "sgl_probe_stream_f32: launch failed: %s", hipGetErrorString(e));
     return SGL_OK;
