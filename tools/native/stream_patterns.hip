@@ -101,6 +101,42 @@ __global__ __launch_bounds__(256) void cp_tile(const F4 *__restrict__ x, F4 *__r
     for (int u = 0; u < U; ++u) if (base + u * 256 < n) { if (NT) __builtin_nontemporal_store(v[u], y + base + u * 256); else y[base + u * 256] = v[u]; }
 }
 
+// H input streams summed into one output (the shape of the hop aggregators): dynamic hop loop (loads serialised behind
+// the adds) vs all H loads issued first
+struct Ptrs { const F4 *p[16]; };
+__global__ __launch_bounds__(256) void sum_dyn(Ptrs in, int H, F4 *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    F4 acc = in.p[0][i];
+    for (int h = 1; h < H; ++h) acc += in.p[h][i];
+    y[i] = acc;
+}
+template <int HM, bool NT>
+__global__ __launch_bounds__(256) void sum_unrolled(Ptrs in, int H, F4 *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    F4 v[HM];
+#pragma unroll
+    for (int h = 0; h < HM; ++h) if (h < H) v[h] = NT ? __builtin_nontemporal_load(in.p[h] + i) : in.p[h][i];
+    F4 acc = v[0];
+#pragma unroll
+    for (int h = 1; h < HM; ++h) if (h < H) acc += v[h];
+    if (NT) __builtin_nontemporal_store(acc, y + i); else y[i] = acc;
+}
+// two elements per thread, 128 B apart? no: two consecutive 4 KB tiles per block
+template <int HM>
+__global__ __launch_bounds__(256) void sum_unrolled2(Ptrs in, int H, F4 *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    if (i + 256 >= n) return;
+    F4 a[HM], b[HM];
+#pragma unroll
+    for (int h = 0; h < HM; ++h) if (h < H) { a[h] = in.p[h][i]; b[h] = in.p[h][i + 256]; }
+    F4 s = a[0], t = b[0];
+#pragma unroll
+    for (int h = 1; h < HM; ++h) if (h < H) { s += a[h]; t += b[h]; }
+    y[i] = s; y[i + 256] = t;
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -148,5 +184,23 @@ int main(int argc, char **argv) {
     CP("tile U=8", (cp_tile<8, false><<<(unsigned)((n + 2047) / 2048), 256>>>(x, y, n)));
     CP("tile U=4 nontemporal", (cp_tile<4, true><<<(unsigned)((n + 1023) / 1024), 256>>>(x, y, n)));
     CP("hipMemcpyDtoD", CK(hipMemcpyAsync(y, x, n * 16, hipMemcpyDeviceToDevice, 0)));
+    for (int H : {4, 6, 11}) {
+        const int64_t m = n / (H + 1);          // H inputs + 1 output carved out of x / y
+        Ptrs in;
+        for (int h = 0; h < 16; ++h) in.p[h] = x + (int64_t)(h % H) * (n / H);
+        const int64_t mm = n / H < m ? n / H : m;
+        const double b2 = (double)mm * 16 * (H + 1);
+        const unsigned g = (unsigned)((mm + 255) / 256);
+        char nm[64];
+#define SM(name, expr) { double ms = time_ms([&] { expr; }); printf("STREAM sum H=%-2d %-30s ms=%7.3f TBps=%.2f (reads+write)\n", H, name, ms, b2 / ms / 1e9); }
+        SM("dynamic hop loop", (sum_dyn<<<g, 256>>>(in, H, y, mm)));
+        if (H <= 4) SM("unrolled HM=4", (sum_unrolled<4, false><<<g, 256>>>(in, H, y, mm)));
+        if (H <= 8) SM("unrolled HM=8", (sum_unrolled<8, false><<<g, 256>>>(in, H, y, mm)));
+        if (H <= 12) SM("unrolled HM=12", (sum_unrolled<12, false><<<g, 256>>>(in, H, y, mm)));
+        SM("unrolled HM=16", (sum_unrolled<16, false><<<g, 256>>>(in, H, y, mm)));
+        SM("unrolled HM=16 nontemporal", (sum_unrolled<16, true><<<g, 256>>>(in, H, y, mm)));
+        if (H <= 8) SM("unrolled HM=8, 2 tiles per block", (sum_unrolled2<8><<<g / 2, 256>>>(in, H, y, mm)));
+        (void)nm;
+    }
     return 0;
 }
