@@ -425,6 +425,64 @@ __global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const in
     }
 }
 
+// Any d, rows of >= 256 floats: the output row is assembled in LDS.  One block per tile of kConcatTile output floats of one
+// row: every ALIGNED 16-byte vector of the source rows that overlaps the tile is loaded exactly once (thread-strided over
+// the <= H + 1 segments the tile cuts), its floats are dropped at their (dword-aligned) place in LDS, and after the barrier
+// the tile leaves as aligned 16-byte stores.  Every source byte is read once and every output byte written once with full
+// vectors on both sides -- the per-thread funnel version below reads each source vector twice through L1.
+constexpr int kConcatTile = 1024;
+constexpr int kConcatRows = 8;     // rows per block: R independent 16-byte loads in flight per thread (a block with one is latency-bound)
+__global__ __launch_bounds__(256) void hop_concat_lds_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+                                                             const int64_t ldo, const int64_t n, const int d,
+                                                             const int tiles_per_row) {
+    __shared__ float tile[kConcatRows][kConcatTile];
+    const int width = d * n_hops;
+    const int64_t rb = blockIdx.x / tiles_per_row;                      // row block
+    const int o0 = (int)(blockIdx.x - rb * tiles_per_row) * kConcatTile;
+    const int o1 = min(o0 + kConcatTile, width);
+    const int64_t row0 = rb * kConcatRows;
+    const int rows = (int)min<int64_t>(kConcatRows, n - row0);
+    // segments of the tile: hop h covers output floats [max(o0, h d), min(o1, (h+1) d))
+    const int h0 = o0 / d, h1 = (o1 - 1) / d;
+    int done = 0;                                   // aligned source vectors of the previous segments
+    const int t = threadIdx.x;
+    for (int h = h0; h <= h1; ++h) {
+        const int k0 = max(o0 - h * d, 0), k1 = min(o1 - h * d, d);       // source floats [k0, k1) of hop h
+        const int a0 = k0 & ~3;
+        const int nv = (k1 - a0 + 3) >> 2;
+        const float *src = hx.p[h] + row0 * hx.ld[h];
+        // threads [done, done + nv) modulo 256 take this segment's vectors: consecutive threads, consecutive vectors
+        for (int v = (t - done) & 255; v < nv; v += 256) {
+            const int a = a0 + v * 4;
+            f4 x[kConcatRows];
+#pragma unroll
+            for (int r = 0; r < kConcatRows; ++r)                        // inside the row's 4-float pitch
+                x[r] = (r < rows) ? *reinterpret_cast<const f4 *>(src + r * hx.ld[h] + a) : (f4){0.f, 0.f, 0.f, 0.f};
+            const int o = h * d + a - o0;
+#pragma unroll
+            for (int r = 0; r < kConcatRows; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (a + e >= k0 && a + e < k1) tile[r][o + e] = x[r][e];
+        }
+        done += nv;
+    }
+    __syncthreads();
+    const int c = t * 4;
+#pragma unroll
+    for (int r = 0; r < kConcatRows; ++r) {
+        if (r >= rows) break;
+        float *orow = out + (row0 + r) * ldo + o0;
+        if (o0 + c + 4 <= o1) {
+            *reinterpret_cast<f4 *>(orow + c) = *reinterpret_cast<const f4 *>(&tile[r][c]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (o0 + c + e < o1) orow[c + e] = tile[r][c + e];
+        }
+    }
+}
+
 // The same for ANY d (d % 4 != 0: the hops' segments start at arbitrary 4-byte offsets of the output row): one thread per
 // ALIGNED 16-byte vector of the output row; its four floats are consecutive in one source row except where the vector
 // straddles a hop boundary, so they are fetched with one dword-aligned 16-byte load (legal on gfx950: vector memory
@@ -786,6 +844,12 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
     if (vec4) {
         const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && sgl::tuning("concat_lds", 1) != 0 &&
+               sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((d * n_hops + kConcatTile - 1) / kConcatTile), 256)) {
+        // any d, long rows: assembled in LDS, every source vector read once
+        const int tiles = (int)((d * n_hops + kConcatTile - 1) / kConcatTile);
+        hipLaunchKernelGGL(hop_concat_lds_kernel, dim3((unsigned)((n + kConcatRows - 1) / kConcatRows * tiles)), dim3(256), 0, st, hx,
+                           n_hops, d_out, ldo, n, (int)d, tiles);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops)) {   // any d: aligned 16-byte stores, aligned 16-byte loads + select
         const int grid = stream_grid(n * ((d * n_hops + 3) / 4));
         hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);

@@ -32,6 +32,7 @@ static std::map<std::string, int64_t> &tune_map() {
         {"agg_blocks", 0},       // 0 = default cap (2048 blocks) on the grid of the streaming aggregators
         {"nafs_fused", 1},       // 0 = force the two-pass NAFS path
         {"row_lpr32x2", 1},      // row-wise kernels, 128 < d <= 256: 32 lanes x 2 chunks per row (2 rows per wavefront)
+        {"concat_lds", 1},       // any-width concat of rows >= 256 floats: assemble the output row in LDS (0 = funnel-select kernel)
     };
     return m;
 }

@@ -856,6 +856,30 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("d,H", [(147, 6), (147, 11), (501, 5), (65, 16), (257, 4), (86, 3), (85, 3), (1023, 2), (1025, 3)])
+def test_concat_any_width_lds_tiles(cuda, d, H):
+    """any-width concat of long rows (assembled in LDS, 1024-float tiles): rows shorter / longer than a tile, hop
+    boundaries that fall inside and exactly on tile boundaries, the last partial vector -- bit-equal to numpy's hstack
+    and to the funnel-select kernel it replaces"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    n = 301
+    host = [hash_matrix(n, d, seed=90 + h) for h in range(H)]
+    feats = []
+    for x in host:
+        t = dev.alloc_rows(n, d, cuda)
+        t.copy_(torch.from_numpy(x))
+        feats.append(t)
+    want = np.hstack(host)
+    got = dev.hop_concat(feats)
+    assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
+    _lib.set_tuning("concat_lds", 0)
+    try:
+        assert torch.equal(dev.hop_concat(feats), got)
+    finally:
+        _lib.set_tuning("concat_lds", 1)
+
+
 @pytest.mark.parametrize("d", [147, 7, 100, 500, 1, 5, 12, 13, 33])
 @pytest.mark.parametrize("padded", [True, False])
 def test_aggregators_any_width_and_layout(cuda, d, padded):
