@@ -220,7 +220,11 @@ __global__ __launch_bounds__(256) void hop_rowdot_kernel(const Hops hx, const in
 
 // The same with the H hop vectors of the row in registers: dOut is loaded once (not once per hop), the H x loads are in
 // flight together and the H butterflies interleave.  d <= LPR * 4 * CH, H <= HMAX.
-template <int LPR, int CH, int HMAX>
+// GU: the second operand's rows are only dword-aligned (autograd's dense [n, d] gradient with d % 4 != 0): it is read with
+// dword-aligned 16-byte loads (legal on gfx950, split by the hardware -- but it is one stream of H + 1, cheaper than the
+// padded copy that would otherwise precede the kernel), the partial vector at column d element by element.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int LPR, int CH, int HMAX, bool GU = false>
 __global__ __launch_bounds__(256) void hop_rowdot_reg_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
                                                              const int64_t ldg, float *__restrict__ dw, const int64_t lddw,
                                                              const int64_t n, const int d) {
@@ -234,7 +238,22 @@ __global__ __launch_bounds__(256) void hop_rowdot_reg_kernel(const Hops hx, cons
     for (int c = 0; c < CH; ++c) {
         const int col = (c * LPR + l) * 4;
         const bool on = live && col < d;
-        gv[c] = on ? load_masked<4>(g + r * ldg, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (GU) {
+            gv[c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (on) {
+                const float *gp = g + r * ldg + col;
+                if (col + 4 <= d) {
+                    const f4u t = *reinterpret_cast<const f4u *>(gp);
+                    gv[c] = (f4){t[0], t[1], t[2], t[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (col + e < d) gv[c][e] = gp[e];
+                }
+            }
+        } else {
+            gv[c] = on ? load_masked<4>(g + r * ldg, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int h = 0; h < HMAX; ++h)
             xv[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
@@ -684,9 +703,8 @@ SGL_EXPORT int sgl_hop_wsum2d_f32(int n_hops, const float *const *h_x, const int
 }
 
 template <int VEC>
-static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t st, const Hops &hx, int n_hops,
+static void launch_rowdot(int lpr, int g_unaligned, hipStream_t st, const Hops &hx, int n_hops,
                           const float *g, int64_t ldg, float *dw, int64_t lddw, int64_t n, int d) {
-    (void)grid_rows_per_block_unused;
     if constexpr (VEC == 4) {
         // the row's H hop vectors fit in registers: one load of dOut, all loads in flight, interleaved butterflies
         int ch = (d > lpr * 4) ? 2 : 1;
@@ -697,13 +715,22 @@ static void launch_rowdot(int lpr, int grid_rows_per_block_unused, hipStream_t s
         }
         if (n_hops <= 16 && d <= lpr * 4 * ch) {
             const unsigned grid = (unsigned)((n + (256 / lpr) - 1) / (256 / lpr));
-#define SGL_RR(L, C, HM) \
-    hipLaunchKernelGGL((hop_rowdot_reg_kernel<L, C, HM>), dim3(grid), dim3(256), 0, st, hx, n_hops, g, ldg, dw, lddw, n, d)
+#define SGL_RR(L, C, HM)                                                                                                        \
+    do {                                                                                                                       \
+        if (g_unaligned)                                                                                                       \
+            hipLaunchKernelGGL((hop_rowdot_reg_kernel<L, C, HM, true>), dim3(grid), dim3(256), 0, st, hx, n_hops, g, ldg, dw, lddw, n, d); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((hop_rowdot_reg_kernel<L, C, HM, false>), dim3(grid), dim3(256), 0, st, hx, n_hops, g, ldg, dw, lddw, n, d); \
+    } while (0)
 #define SGL_RR_H(L, C)                                 \
     do {                                               \
-        if (n_hops <= 4) SGL_RR(L, C, 4);              \
+        if (n_hops <= 2) SGL_RR(L, C, 2);              \
+        else if (n_hops <= 4) SGL_RR(L, C, 4);         \
+        else if (n_hops <= 6) SGL_RR(L, C, 6);         \
         else if (n_hops <= 8) SGL_RR(L, C, 8);         \
+        else if (n_hops <= 10) SGL_RR(L, C, 10);       \
         else if (n_hops <= 12) SGL_RR(L, C, 12);       \
+        else if (n_hops <= 14) SGL_RR(L, C, 14);       \
         else SGL_RR(L, C, 16);                         \
     } while (0)
             if (two_rows) SGL_RR_H(32, 2);
@@ -734,10 +761,15 @@ SGL_EXPORT int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const
                                       float *const *h_dx, const int64_t *h_lddx, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: bad sizes");
     Hops hx;
-    bool row4 = (lddo % 4 == 0) && aligned_to(d_dout, 16);   // 16-byte row accesses possible (any d, masked tail)
-    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, row4);
+    bool hops4 = true;                                         // 16-byte row accesses possible (any d, masked tail)
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, hops4);
     if (rc != SGL_OK) return rc;
-    bool vec4 = row4 && (d % 4 == 0);                          // element-wise kernels need whole vectors
+    const bool g4 = (lddo % 4 == 0) && aligned_to(d_dout, 16);
+    // a dword-aligned dOut (autograd's dense gradient, d % 4 != 0) still takes the 16-byte path for the H hop reads when the
+    // register-resident kernel applies: it reads dOut with dword-aligned vector loads
+    const bool g_unaligned = hops4 && !g4 && n_hops <= 16 && d <= 512;
+    const bool row4 = hops4 && (g4 || g_unaligned);
+    bool vec4 = hops4 && g4 && (d % 4 == 0);                   // element-wise kernels need whole vectors
     if (n == 0 || d == 0) return SGL_OK;
     SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum2d_bwd_f32: bad dOut");
     hipStream_t st = sgl::as_stream(stream);
@@ -746,7 +778,7 @@ SGL_EXPORT int sgl_hop_wsum2d_bwd_f32(int n_hops, const float *const *h_x, const
         const int lpr = pick_lpr(d, row4 ? 4 : 1);
         SGL_REQUIRE((n + (256 / lpr) - 1) / (256 / lpr) < INT32_MAX, "sgl_hop_wsum2d_bwd_f32: too many rows");
         if (row4)
-            launch_rowdot<4>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
+            launch_rowdot<4>(lpr, g_unaligned ? 1 : 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
         else
             launch_rowdot<1>(lpr, 0, st, hx, n_hops, d_dout, lddo, d_dw, lddw, n, (int)d);
         SGL_LAUNCH_CHECK("sgl_hop_wsum2d_bwd_f32(dW)");
@@ -885,9 +917,13 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d)
 #define SGL_NF_H(L, C)                                 \
     do {                                               \
-        if (n_hops <= 4) SGL_NF(L, C, 4);              \
+        if (n_hops <= 2) SGL_NF(L, C, 2);              \
+        else if (n_hops <= 4) SGL_NF(L, C, 4);         \
+        else if (n_hops <= 6) SGL_NF(L, C, 6);         \
         else if (n_hops <= 8) SGL_NF(L, C, 8);         \
+        else if (n_hops <= 10) SGL_NF(L, C, 10);       \
         else if (n_hops <= 12) SGL_NF(L, C, 12);       \
+        else if (n_hops <= 14) SGL_NF(L, C, 14);       \
         else SGL_NF(L, C, 16);                         \
     } while (0)
         if (two_rows) SGL_NF_H(32, 2);

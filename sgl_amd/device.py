@@ -557,15 +557,16 @@ class _WSum2D(torch.autograd.Function):
         g = gout.detach().to(torch.float32)
         if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
             g = g.contiguous()
-        if n > 1 and d > 4 and (g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0):
-            # autograd hands over a dense [n, d] gradient: for d % 4 != 0 its rows are not 16-byte aligned and the row-dot
-            # would fall back to 4-byte lanes (measured 0.36 of peak at d = 147); one copy into a padded buffer restores
-            # the 16-byte path for all H hop reads
+        need_w = ctx.needs_input_grad[0]
+        need_x = [ctx.needs_input_grad[1 + h] for h in range(H)]
+        if n > 1 and d > 4 and (g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0) and (any(need_x) or H > 16 or d > 512):
+            # autograd hands over a dense [n, d] gradient: for d % 4 != 0 its rows are not 16-byte aligned.  The dW row-dot
+            # reads such a gradient directly (dword-aligned vector loads, sgl_hop_wsum2d_bwd_f32); the element-wise dX
+            # kernel and the wide / many-hop fallback would drop to 4-byte lanes (0.36 of peak at d = 147), so for those
+            # one copy into a padded buffer restores the 16-byte path
             gp = alloc_rows(n, d, g.device)
             gp.copy_(g)
             g = gp
-        need_w = ctx.needs_input_grad[0]
-        need_x = [ctx.needs_input_grad[1 + h] for h in range(H)]
         dw = torch.empty((n, H), dtype=torch.float32, device=g.device) if need_w else None
         dxs = [alloc_rows(n, d, g.device) if need_x[h] else None for h in range(H)]
         ptrs, lds = _lib.hop_arrays(feats)
