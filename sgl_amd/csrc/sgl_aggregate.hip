@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, cons
 }
 
 // dw[h] = sum_{n,k} dOut[n,k] X_h[n,k]: per-block partials, then a sequential (deterministic) second level
-constexpr int kW1dBlocks = 1024;
+constexpr int kW1dBlocks = 8192;   // a grid-stride stream wants >= 8k blocks on this part (profiles/r02_stream_patterns.log)
 
 __global__ __launch_bounds__(256) void hop_dot_partial_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
                                                               const int64_t ldg, float *__restrict__ scratch,
@@ -580,13 +580,72 @@ __global__ __launch_bounds__(256) void hop_dot_partial_kernel(const Hops hx, con
     }
 }
 
-__global__ void hop_dot_final_kernel(const float *__restrict__ scratch, const int n_blocks, const int n_hops,
-                                     float *__restrict__ dw) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_hops) return;
+// Single pass for 16-byte rows (any d: padded rows, masked tail): every block walks a contiguous range of (row, vector)
+// positions, dOut's vector is loaded once and multiplied into all H hop vectors (H + 1 streams instead of the 2 H of the
+// scalar kernel above, which re-reads dOut per hop), per-thread partial sums for all hops live in registers.
+// GU: dOut's rows are only dword-aligned (autograd's dense gradient, d % 4 != 0) -> dword-aligned vector loads.
+template <int HMAX, bool GU>
+__global__ __launch_bounds__(256) void hop_dot_partial_vec_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
+                                                                  const int64_t ldg, float *__restrict__ scratch,
+                                                                  const int64_t n, const int d, const int64_t per_block) {
+    __shared__ float red[4][HMAX];
+    const int dv = (d + 3) >> 2;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = min(lo + per_block, total);
+    float acc[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) acc[h] = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * 4;
+        f4 gv;
+        if constexpr (GU) {
+            const float *gp = g + row * ldg + col;
+            if (col + 4 <= d) {
+                const f4u t = *reinterpret_cast<const f4u *>(gp);
+                gv = (f4){t[0], t[1], t[2], t[3]};
+            } else {
+                gv = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (col + e < d) gv[e] = gp[e];
+            }
+        } else {
+            gv = load_masked<4, true>(g + row * ldg, col, d);
+        }
+        f4 xv[HMAX];
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) xv[h] = load_masked<4, true>(hx.p[h] + row * hx.ld[h], col, d);
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[h] = __builtin_fmaf(gv[e], xv[h][e], acc[h]);
+            }
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) acc[h] = group_sum<64>(acc[h]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) red[threadIdx.x >> 6][h] = acc[h];
+    }
+    __syncthreads();
+    if (threadIdx.x < n_hops)
+        scratch[(int64_t)blockIdx.x * n_hops + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// second level: one wavefront per hop, every lane adds its strided share of the block partials in block order, then a
+// fixed butterfly -- deterministic for a given block count
+__global__ __launch_bounds__(64) void hop_dot_final_kernel(const float *__restrict__ scratch, const int n_blocks, const int n_hops,
+                                                           float *__restrict__ dw) {
+    const int h = blockIdx.x;
     float acc = 0.f;
-    for (int b = 0; b < n_blocks; ++b) acc += scratch[(int64_t)b * n_hops + h];
-    dw[h] = acc;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) acc += scratch[(int64_t)b * n_hops + h];
+    acc = group_sum<64>(acc);
+    if (threadIdx.x == 0) dw[h] = acc;
 }
 
 bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -854,10 +913,33 @@ SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const
         return SGL_OK;
     }
     SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum1d_bwd_f32: bad dOut");
-    int blocks = (int)std::min<int64_t>(kW1dBlocks, (n * d + 255) / 256);
-    hipLaunchKernelGGL(hop_dot_partial_kernel, dim3(blocks), dim3(256), 0, st, hx, n_hops, d_dout, lddo, d_scratch, n, (int)d);
+    int blocks;
+    const bool g4 = (lddo % 4 == 0) && aligned_to(d_dout, 16);
+    if (vec4_rows(hx, n_hops)) {
+        const int64_t total = n * ((d + 3) / 4);
+        blocks = (int)std::min<int64_t>(kW1dBlocks, (total + 255) / 256);
+        const int64_t per_block = ((total + blocks - 1) / blocks + 255) / 256 * 256;
+        blocks = (int)((total + per_block - 1) / per_block);
+#define SGL_DP(HM)                                                                                                             \
+    do {                                                                                                                       \
+        if (g4)                                                                                                                \
+            hipLaunchKernelGGL((hop_dot_partial_vec_kernel<HM, false>), dim3(blocks), dim3(256), 0, st, hx, n_hops, d_dout, lddo, \
+                               d_scratch, n, (int)d, per_block);                                                              \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((hop_dot_partial_vec_kernel<HM, true>), dim3(blocks), dim3(256), 0, st, hx, n_hops, d_dout, lddo, \
+                               d_scratch, n, (int)d, per_block);                                                              \
+    } while (0)
+        if (n_hops <= 4) SGL_DP(4);
+        else if (n_hops <= 8) SGL_DP(8);
+        else if (n_hops <= 12) SGL_DP(12);
+        else SGL_DP(16);
+#undef SGL_DP
+    } else {
+        blocks = (int)std::min<int64_t>(kW1dBlocks, (n * d + 255) / 256);
+        hipLaunchKernelGGL(hop_dot_partial_kernel, dim3(blocks), dim3(256), 0, st, hx, n_hops, d_dout, lddo, d_scratch, n, (int)d);
+    }
     SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(partial)");
-    hipLaunchKernelGGL(hop_dot_final_kernel, dim3(1), dim3(64), 0, st, d_scratch, blocks, n_hops, d_dw);
+    hipLaunchKernelGGL(hop_dot_final_kernel, dim3(n_hops), dim3(64), 0, st, d_scratch, blocks, n_hops, d_dw);
     SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(final)");
     return SGL_OK;
 }

@@ -906,6 +906,11 @@ def test_aggregators_any_width_and_layout(cuda, d, padded):
     w1 = np.linspace(0.5, -0.2, H).astype(np.float32)
     y = dev.hop_reduce(_lib.SGL_REDUCE_WSUM, feats, torch.from_numpy(w1)).cpu().numpy()
     assert oracle.parity_ok(y, oracle.one_dim_weighted_add(host, w1), 1e-6, rowwise=False)
+    w1t = torch.from_numpy(w1).to(cuda).requires_grad_(True)
+    g1 = hash_matrix(n, d, seed=78)
+    dev.hop_wsum1d(feats, w1t).backward(torch.from_numpy(g1).to(cuda))     # dw[h] = <dOut, X_h>: single-pass vector kernel
+    dw1_ref = np.array([(g1.astype(np.float64) * x).sum() for x in host])
+    assert np.allclose(w1t.grad.cpu().numpy(), dw1_ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(dw1_ref).max()))
     w2 = oracle.softmax32(hash_matrix(n, H, seed=9), 1)
     w2t = torch.from_numpy(w2).to(cuda).requires_grad_(True)
     out = dev.hop_wsum2d(feats, w2t)

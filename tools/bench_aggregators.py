@@ -55,6 +55,12 @@ def main():
         out = dev.hop_wsum2d(feats, w2g)
         g = torch.randn_like(out)
         rep("wsum2d bwd (dW)", timeit(lambda: torch.autograd.grad(out, w2g, g, retain_graph=True)), (H + 1) * nb + n * H * 4)
+        w1g = w1.clone().requires_grad_(True)
+        out1 = dev.hop_wsum1d(feats, w1g)
+        rep("wsum1d bwd (dw)", timeit(lambda: torch.autograd.grad(out1, w1g, g, retain_graph=True)), (H + 1) * nb)
+        del out1
+        v = torch.randn(d, device=device)
+        rep("gate scores (rowdot)", timeit(lambda: dev.hop_scores(feats, v)), H * nb + n * H * 4)
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
