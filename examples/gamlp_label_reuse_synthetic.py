@@ -48,6 +48,7 @@ def main():
     feats[:, :d] = x
     t_prep = t_train = 0.0
     n_prep = 0
+    calls = []
     for epoch in range(a.epochs):
         # label use: one-hot labels of a random half of the training nodes as extra input columns
         mask = train_idx[torch.rand(train_idx.numel(), generator=g, device=device) < 0.5]
@@ -57,6 +58,7 @@ def main():
             torch.cuda.synchronize(); t0 = time.time()
             model.preprocess(adj, feats)                           # prop_steps SpMMs over [N, d + C]
             torch.cuda.synchronize(); t_prep += time.time() - t0; n_prep += 1
+            calls.append((time.time() - t0) * 1e3)
             if it < a.label_iters:                                   # label reuse: feed predictions back
                 model.eval()
                 with torch.no_grad():
@@ -73,6 +75,7 @@ def main():
             opt.step()
         torch.cuda.synchronize(); t_train += time.time() - t0
         print(f"epoch {epoch}: loss {loss.item():.4f}")
+    print("preprocess() calls, ms: " + " ".join(f"{c:.1f}" for c in calls))
     nnz_hat = adj.nnz + n
     rate = nnz_hat * (d + C + 1) * a.prop_steps * n_prep / t_prep    # padded width d + C rounded up to 148
     print(f"{n_prep} preprocess() calls, {a.prop_steps} hops each over [N={n}, {d + C}]: {t_prep / n_prep * 1e3:.1f} ms per call "
