@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import torch  # noqa: F401  (must precede the CDLL: shares torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgl_hip.so")
+# SGL_HIP_LIB: load another build of the library (A/B timing of a kernel change on one GPU box); default: the in-tree build
+LIB_PATH = os.environ.get("SGL_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgl_hip.so")
 
 SGL_CSR_STRICT_ORDER = 0x1
 SGL_CSR_NO_XCD_REMAP = 0x2
