@@ -915,7 +915,7 @@ SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const
     SGL_REQUIRE(d_dout && lddo >= d, "sgl_hop_wsum1d_bwd_f32: bad dOut");
     int blocks;
     const bool g4 = (lddo % 4 == 0) && aligned_to(d_dout, 16);
-    if (vec4_rows(hx, n_hops)) {
+    if (vec4_rows(hx, n_hops) && n_hops <= 16) {   // the per-thread partials of all hops live in registers
         const int64_t total = n * ((d + 3) / 4);
         blocks = (int)std::min<int64_t>(kW1dBlocks, (total + 255) / 256);
         const int64_t per_block = ((total + blocks - 1) / blocks + 255) / 256 * 256;

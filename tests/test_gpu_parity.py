@@ -856,6 +856,45 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("d", [100, 13])
+def test_aggregators_with_more_than_sixteen_hops(cuda, d):
+    """21 hop matrices (a 20-hop NAFS run): beyond the register-resident kernels' 16-hop limit every aggregator must take
+    its general path -- two-pass NAFS, the LDS / scalar row-dot, the scalar 1-D weight gradient -- and still match"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    n, H = 333, 21
+    host = [np.ascontiguousarray(hash_matrix(n, d, seed=120 + h) * (1.0 - 0.03 * h), dtype=np.float32) for h in range(H)]
+    feats = []
+    for x in host:
+        t = dev.alloc_rows(n, d, cuda)
+        t.copy_(torch.from_numpy(x))
+        feats.append(t)
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_SUM, feats).cpu().numpy(), oracle.agg_sum(host, 0, H))
+    assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MAX, feats).cpu().numpy(), oracle.agg_max(host, 0, H))
+    assert np.array_equal(dev.hop_concat(feats).cpu().numpy(), np.hstack(host))
+    w1 = np.linspace(0.5, -0.2, H).astype(np.float32)
+    w1t = torch.from_numpy(w1).to(cuda).requires_grad_(True)
+    y1 = dev.hop_wsum1d(feats, w1t)
+    assert oracle.parity_ok(y1.detach().cpu().numpy(), oracle.one_dim_weighted_add(host, w1), 1e-6, rowwise=False)
+    g = hash_matrix(n, d, seed=7)
+    y1.backward(torch.from_numpy(g).to(cuda))
+    ref1 = np.array([(g.astype(np.float64) * x).sum() for x in host])
+    assert np.allclose(w1t.grad.cpu().numpy(), ref1, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref1).max()))
+    w2 = oracle.softmax32(hash_matrix(n, H, seed=9), 1)
+    w2t = torch.from_numpy(w2).to(cuda).requires_grad_(True)
+    y2 = dev.hop_wsum2d(feats, w2t)
+    assert oracle.parity_ok(y2.detach().cpu().numpy(), oracle.two_dim_weighted_add(host, w2), 1e-6, rowwise=False)
+    y2.backward(torch.from_numpy(g).to(cuda))
+    ref2 = np.stack([(g.astype(np.float64) * x).sum(1) for x in host], 1)
+    assert np.allclose(w2t.grad.cpu().numpy(), ref2, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref2).max()))
+    yn, wn = dev.nafs_aggregate(feats, return_weights=True)
+    assert np.allclose(wn.cpu().numpy(), oracle.nafs_weights(host), rtol=2e-5, atol=2e-6)
+    assert oracle.parity_ok(yn.cpu().numpy(), oracle.agg_over_smooth_distance(host), 1e-5, rowwise=False)
+    v = hash_matrix(1, d, seed=3).reshape(-1)
+    sc = dev.hop_scores(feats, torch.from_numpy(v).to(cuda)).cpu().numpy()
+    assert np.allclose(sc, np.stack([x.astype(np.float64) @ v for x in host], 1), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("d,H", [(147, 6), (147, 11), (501, 5), (65, 16), (257, 4), (86, 3), (85, 3), (1023, 2), (1025, 3)])
 def test_concat_any_width_lds_tiles(cuda, d, H):
     """any-width concat of long rows (assembled in LDS, 1024-float tiles): rows shorter / longer than a tile, hop
