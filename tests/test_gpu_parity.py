@@ -1848,6 +1848,13 @@ def _rccl_world1_worker(rank, port, out_dir):
         w2.wait()
         torch.cuda.synchronize()
         ok = ok and torch.equal(out[0], x[0]) and torch.equal(out[1], x[2])
+        # the grouped point-to-point batch of the row-sharded exchange (transports._post): row-range views, peer = a rank of
+        # the group (here the rank itself -- the only peer a 1-GPU box offers)
+        got = torch.zeros((5, 4), dtype=torch.float32, device=dev_)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, x[1:3], 0), dist.P2POp(dist.irecv, got[2:4], 0)]):
+            w.wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(got[2:4], x[1:3]) and float(got[0].abs().sum()) == 0.0
         gathered = torch.empty((3, 4), dtype=torch.float32, device=dev_)
         dist.all_gather_into_tensor(gathered, x, async_op=True).wait()
         flag = torch.tensor([1], dtype=torch.int32, device=dev_)
@@ -1866,7 +1873,7 @@ def _rccl_world1_worker(rank, port, out_dir):
 
 def test_rccl_backend_accepts_the_calls_the_layouts_make(cuda, tmp_path):
     """one RCCL rank on the one GPU: all_to_all on lists of row-range views issued asynchronously from a side stream,
-    all_gather_into_tensor, the agreement all-reduces, all_gather_object, barrier -- the exact call shapes of
+    the grouped isend / irecv batch of the row-sharded exchange, all_gather_into_tensor, the agreement all-reduces, all_gather_object, barrier -- the exact call shapes of
     sgl_amd/dist/ and bench.py, accepted by the real backend (multi-rank behaviour is covered under gloo)"""
     import socket
     import torch.multiprocessing as mp
