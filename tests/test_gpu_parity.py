@@ -856,6 +856,57 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+def test_aggregators_fuzz_random_shapes(cuda):
+    """40 random (rows, width, hops, padded / dense) shapes through every aggregator kernel family: the bit-exact ones
+    (sum / max / concat) against numpy bit for bit, the weighted ones and their gradients within tolerance -- widths 1..600
+    hit every lane layout (8 / 16 / 32 / 64 lanes, 1 / 2 chunks), the LDS concat tiles, the masked tails and the unaligned
+    gradient path; hop counts 1..20 hit every register instantiation and the general fallbacks"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    rng = np.random.default_rng(20260927)
+    for case in range(40):
+        n = int(rng.integers(1, 400))
+        d = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 33, 64, 65, 100, 127, 128, 129, 147, 255, 256, 257, 300, 511, 513, 600]))
+        H = int(rng.integers(1, 21))
+        padded = bool(rng.integers(0, 2))
+        host = [np.ascontiguousarray(rng.standard_normal((n, d)).astype(np.float32)) for _ in range(H)]
+        if padded:
+            feats = []
+            for x in host:
+                t = dev.alloc_rows(n, d, cuda)
+                t.copy_(torch.from_numpy(x))
+                feats.append(t)
+        else:
+            feats = [torch.from_numpy(x).to(cuda) for x in host]
+        tag = (case, n, d, H, padded)
+        assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_SUM, feats).cpu().numpy(), oracle.agg_sum(host, 0, H)), tag
+        assert np.array_equal(dev.hop_reduce(_lib.SGL_REDUCE_MAX, feats).cpu().numpy(), oracle.agg_max(host, 0, H)), tag
+        assert np.array_equal(dev.hop_concat(feats).cpu().numpy(), np.hstack(host)), tag
+        g = rng.standard_normal((n, d)).astype(np.float32)
+        gt = torch.from_numpy(g).to(cuda)
+        w1 = rng.standard_normal(H).astype(np.float32)
+        w1t = torch.from_numpy(w1).to(cuda).requires_grad_(True)
+        y1 = dev.hop_wsum1d(feats, w1t)
+        assert oracle.parity_ok(y1.detach().cpu().numpy(), oracle.one_dim_weighted_add(host, w1), 1e-5, rowwise=False), tag
+        y1.backward(gt)
+        ref1 = np.array([(g.astype(np.float64) * x).sum() for x in host])
+        assert np.allclose(w1t.grad.cpu().numpy(), ref1, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref1).max())), tag
+        w2 = oracle.softmax32(rng.standard_normal((n, H)).astype(np.float32), 1)
+        w2t = torch.from_numpy(w2).to(cuda).requires_grad_(True)
+        y2 = dev.hop_wsum2d(feats, w2t)
+        assert oracle.parity_ok(y2.detach().cpu().numpy(), oracle.two_dim_weighted_add(host, w2), 1e-5, rowwise=False), tag
+        y2.backward(gt)
+        ref2 = np.stack([(g.astype(np.float64) * x).sum(1) for x in host], 1)
+        assert np.allclose(w2t.grad.cpu().numpy(), ref2, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref2).max())), tag
+        yn, wn = dev.nafs_aggregate(feats, return_weights=True)
+        assert np.allclose(wn.cpu().numpy(), oracle.nafs_weights(host), rtol=5e-5, atol=5e-6), tag
+        assert oracle.parity_ok(yn.cpu().numpy(), oracle.agg_over_smooth_distance(host), 2e-5, rowwise=False), tag
+        v = rng.standard_normal(d).astype(np.float32)
+        sc = dev.hop_scores(feats, torch.from_numpy(v).to(cuda)).cpu().numpy()
+        ref = np.stack([x.astype(np.float64) @ v for x in host], 1)
+        assert np.allclose(sc, ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max())), tag
+
+
 @pytest.mark.parametrize("d", [100, 13])
 def test_aggregators_with_more_than_sixteen_hops(cuda, d):
     """21 hop matrices (a 20-hop NAFS run): beyond the register-resident kernels' 16-hop limit every aggregator must take
