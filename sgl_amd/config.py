@@ -18,6 +18,11 @@ fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / s
               pass (the running aggregate is read and written once per hop) and save K-1 hop buffers:
               "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
               device memory; True / False force it
+reorder       None -> the adjacency is used with the caller's node ids; "community" -> a plan-time locality ordering
+              (sgl_amd/reorder.py: label propagation on the device, ~0.3 s at products size, cached with the adjacency)
+              relabels the problem so that communities are contiguous; propagate() permutes features in and hops out.
+              Pays on graphs that HAVE communities and whose ids do not show them (-37 % per hop on the shuffled
+              community graph of tools/exp_reorder.py), neutral on the random benchmark graph; not with strict_order
 """
 import os
 
@@ -37,3 +42,4 @@ cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
 _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()
 fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)
+reorder = os.environ.get("SGL_AMD_REORDER") or None

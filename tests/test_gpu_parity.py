@@ -856,6 +856,70 @@ def test_weighted_and_nafs_aggregators(goldens, cuda):
     assert np.allclose(wts.sum(1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+def _planted_communities(n, bs, deg, p_in, seed):
+    rng = np.random.default_rng(seed)
+    a = np.repeat(np.arange(n), deg)
+    near = (a // bs) * bs + rng.integers(0, bs, a.size)
+    far = rng.integers(0, n, a.size)
+    b = np.where(rng.random(a.size) < p_in, np.minimum(near, n - 1), far)
+    keep = a != b
+    m = sp.coo_matrix((np.ones(keep.sum(), np.float32), (a[keep], b[keep])), shape=(n, n)).tocsr()
+    m = ((m + m.T) > 0).astype(np.float32).tocsr()
+    m.sort_indices()
+    return m
+
+
+def test_community_reorder_is_transparent(cuda):
+    """GraphOp(reorder="community"): the plan-time locality ordering relabels the problem (P A P^T), propagate() and
+    propagate_reduce() permute features in and results out -- callers get the same hops as without it (different summation
+    order: tolerance, not bits), the order is a permutation that makes the planted communities contiguous, permute_csr is
+    scipy's P A P^T, and strict_order refuses the combination"""
+    from sgl_amd import device as dev
+    from sgl_amd.io import DeviceAdjacency
+    from sgl_amd.operators import message_op as m
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    from sgl_amd.reorder import community_order, permute_csr
+    n, bs = 3000, 100
+    adj0 = _planted_communities(n, bs, 12, 0.9, seed=4)
+    shuffle = np.random.default_rng(5).permutation(n)                 # hide the communities in the ids
+    P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
+    adj = (P @ adj0 @ P.T).tocsr()
+    adj.sort_indices()
+    x = hash_matrix(n, 20, seed=6)
+    d_adj = DeviceAdjacency.from_scipy(adj, device=cuda)
+    order, info = community_order(d_adj.rowptr, d_adj.col, n)
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(n)), info
+    # the relabelled matrix keeps the planted communities together: most edges join nodes less than 2 communities apart
+    rp, cc, vv = permute_csr(d_adj.rowptr, d_adj.col, d_adj.val, order)
+    Q = sp.coo_matrix((np.ones(n, np.float32), (o, np.arange(n))), shape=(n, n)).tocsr()
+    want = (Q @ adj @ Q.T).tocsr()
+    want.sort_indices()
+    assert np.array_equal(rp.cpu().numpy(), want.indptr) and np.array_equal(cc.cpu().numpy(), want.indices)
+    assert np.array_equal(vv.cpu().numpy(), want.data)
+    coo = want.tocoo()
+    near_after = np.mean(np.abs(coo.row - coo.col) < 2 * bs)
+    coo0 = adj.tocoo()
+    near_before = np.mean(np.abs(coo0.row - coo0.col) < 2 * bs)
+    assert near_before < 0.2 and near_after > 0.8, (near_before, near_after, info)
+    for plain, reord in ((LaplacianGraphOp(3, r=0.5), LaplacianGraphOp(3, r=0.5, reorder="community")),
+                         (PprGraphOp(2, r=0.3, alpha=0.2), PprGraphOp(2, r=0.3, alpha=0.2, reorder="community"))):
+        ha, hb = plain.propagate(adj, x), reord.propagate(adj, x)
+        assert len(ha) == len(hb) and torch.equal(ha[0], hb[0])
+        for a, b in zip(ha[1:], hb[1:]):
+            assert oracle.parity_ok(b.cpu().numpy(), a.cpu().numpy(), 1e-5)
+        for op in (m.LastMessageOp(), m.MeanMessageOp(0, 3), m.MaxMessageOp(1, 3)):
+            spec = op.fused_spec(len(ha))
+            fa, fb = plain.propagate_reduce(adj, x, **spec), reord.propagate_reduce(adj, x, **spec)
+            assert oracle.parity_ok(fb.cpu().numpy(), fa.cpu().numpy(), 1e-5), type(op).__name__
+        assert reord._adj.order is not None and plain._adj.order is None
+        reord.propagate(adj, x)                                        # cached: the ordering is found once per adjacency
+    with pytest.raises(ValueError):
+        LaplacianGraphOp(2, reorder="community", strict_order=True).propagate(adj, x)
+    with pytest.raises(ValueError):
+        LaplacianGraphOp(2, reorder="rcm").propagate(adj, x)
+
+
 def test_aggregators_fuzz_random_shapes(cuda):
     """40 random (rows, width, hops, padded / dense) shapes through every aggregator kernel family: the bit-exact ones
     (sum / max / concat) against numpy bit for bit, the weighted ones and their gradients within tolerance -- widths 1..600

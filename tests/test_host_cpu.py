@@ -326,3 +326,30 @@ def test_exchange_entry_point_argument_contract():
     b3 = (ctypes.c_int64 * 3)(0, 10, 20)
     assert lib.sgl_allgather_rows(None, 0, 2, b3, None, 16, None) != 0      # NULL matrix / communicator
     assert isinstance(lib.sgl_exchange_backend(), bytes)
+
+
+def test_community_order_on_cpu_tensors():
+    """sgl_amd.reorder.community_order is plain tensor code: on a small planted-partition graph with shuffled ids it returns
+    a permutation under which most edges join nodes of the same (now contiguous) community"""
+    import scipy.sparse as sp
+    from sgl_amd.reorder import community_order
+    n, bs = 1200, 60
+    rng = np.random.default_rng(3)
+    a = np.repeat(np.arange(n), 10)
+    near = (a // bs) * bs + rng.integers(0, bs, a.size)
+    far = rng.integers(0, n, a.size)
+    b = np.where(rng.random(a.size) < 0.9, near, far)
+    keep = a != b
+    m = sp.coo_matrix((np.ones(keep.sum(), np.float32), (a[keep], b[keep])), shape=(n, n)).tocsr()
+    m = ((m + m.T) > 0).astype(np.float32).tocsr()
+    shuffle = rng.permutation(n)
+    P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
+    adj = (P @ m @ P.T).tocsr()
+    adj.sort_indices()
+    order, info = community_order(torch.from_numpy(adj.indptr.astype(np.int64)), torch.from_numpy(adj.indices.astype(np.int32)), n)
+    o = order.numpy()
+    assert np.array_equal(np.sort(o), np.arange(n)), info
+    coo = adj.tocoo()
+    before = np.mean(np.abs(coo.row - coo.col) < 2 * bs)
+    after = np.mean(np.abs(o[coo.row] - o[coo.col]) < 2 * bs)
+    assert before < 0.3 and after > 0.8, (before, after, info)
