@@ -160,6 +160,17 @@ enum { SGL_ACC_SUM = 0, SGL_ACC_WSUM = 1, SGL_ACC_MAX = 2, SGL_ACC_MIN = 3 };
 int sgl_spmm_acc_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
                      int64_t ldacc, float w, int mode, float divisor, void *stream);
 
+/* ---- plan-time locality ordering ------------------------------------------------------------------------------------------ */
+/* d_order[i] = position of node i in an order that keeps communities contiguous: `rounds` (1..64, typically 8) rounds of
+ * semi-synchronous label propagation on the structure (d_rowptr, d_col) of a symmetric adjacency -- every node adopts the most
+ * frequent label among (a strided sample of at most 256 of) its neighbours, ties to the smaller label, half of the nodes per
+ * round, all in the last -- followed by a stable sort of the nodes by label.  Deterministic.  h_info (optional, host):
+ * [0] number of communities, [1] nodes that changed label in the last round.  Runs once per adjacency (tens of ms at
+ * ogbn-products size); the caller relabels the problem (sgl_coo_to_csr on the relabelled COO) and permutes features / results.
+ * Synchronises the stream. */
+int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_col, int64_t n, int rounds, int64_t *d_order,
+                          int64_t *h_info, void *stream);
+
 /* ---- multi-GPU exchange (row-sharded layout): the all-gather of the feature block between hops ---------------- */
 /* Rank `rank` of `world` owns rows [h_bounds[rank], h_bounds[rank+1]) of the [n, ldx] replica d_x (row-major, whole padded
  * rows travel) and has already written them; on completion (stream-ordered) every rank's rows are in place.  One grouped

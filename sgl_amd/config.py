@@ -19,7 +19,8 @@ fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / s
               "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
               device memory; True / False force it
 reorder       None -> the adjacency is used with the caller's node ids; "community" -> a plan-time locality ordering
-              (sgl_amd/reorder.py: label propagation on the device, ~0.3 s at products size, cached with the adjacency)
+              (sgl_amd/reorder.py -> sgl_reorder_community: label propagation on the device, ~70 ms at products size, cached
+              with the adjacency)
               relabels the problem so that communities are contiguous; propagate() permutes features in and hops out.
               Pays on graphs that HAVE communities and whose ids do not show them (-37 % per hop on the shuffled
               community graph of tools/exp_reorder.py), neutral on the random benchmark graph; not with strict_order

@@ -8,13 +8,36 @@ hits; ids as they come out of a dump carry no such order.
 
 The ordering is a few rounds of semi-synchronous label propagation (every node adopts the most frequent label among its
 neighbours, ties to the smaller label; half of the nodes move per round so two-coloured structures cannot oscillate), then a
-stable sort by label.  It is a heuristic that runs once per graph; nothing of the propagation path depends on it, results are
-the permuted results (GraphOp(reorder=...) permutes features in and hops out)."""
+stable sort by label: sgl_reorder_community in the HIP library (one wavefront per node, the neighbours' labels counted in LDS).
+It is a heuristic that runs once per graph; nothing of the propagation path depends on it, results are the permuted results
+(GraphOp(reorder=...) permutes features in and hops out).  `community_order_reference` is the same algorithm in plain tensor
+code -- the readable statement the tests pin the kernel to (identical labels when no node has more than 256 neighbours; the
+kernel samples longer rows)."""
+import ctypes
+
 import torch
 
-from . import io
+from . import _lib, io
+from ._lib import check, current_stream_ptr, lib, ptr
 
-__all__ = ["community_order", "permute_csr"]
+__all__ = ["community_order", "community_order_reference", "permute_csr"]
+
+
+@torch.no_grad()
+def community_order(rowptr, col, n, rounds=8):
+    """rowptr int64 [n+1], col int32 [nnz] on the GPU (a symmetric adjacency; self-loops do not matter).
+    Returns (order int64 [n] with order[i] = new id of node i, info string)."""
+    _lib.require_gpu()
+    if not (rowptr.is_cuda and col.is_cuda):
+        raise ValueError("community_order runs on the device: pass device tensors (sgl_amd.io.DeviceAdjacency)")
+    rowptr = rowptr.to(torch.int64).contiguous()
+    col = col.to(torch.int32).contiguous()
+    order = torch.empty(n, dtype=torch.int64, device=rowptr.device)
+    info = (ctypes.c_int64 * 2)(0, 0)
+    with torch.cuda.device(rowptr.device):
+        check(lib().sgl_reorder_community(ptr(rowptr), ptr(col), n, int(rounds), ptr(order), info, current_stream_ptr()),
+              "sgl_reorder_community")
+    return order, f"{info[0]} communities after {int(rounds)} rounds, {info[1]} nodes moved in the last"
 
 
 def _mix(x, salt):
@@ -24,9 +47,8 @@ def _mix(x, salt):
 
 
 @torch.no_grad()
-def community_order(rowptr, col, n, rounds=8):
-    """rowptr int64 [n+1], col int32 [nnz] on the device (a symmetric adjacency; self-loops do not matter).
-    Returns (order int64 [n], info string)."""
+def community_order_reference(rowptr, col, n, rounds=8):
+    """the algorithm of sgl_reorder_community in tensor code (any device; every neighbour counted, no sampling)"""
     device = rowptr.device
     deg = rowptr[1:] - rowptr[:-1]
     row = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
@@ -48,14 +70,12 @@ def community_order(rowptr, col, n, rounds=8):
         moved = int(upd.sum())
         labels = torch.where(upd, new, labels)
         del key, run, cnt, node, lab, score, best, new
-        if moved == 0:
-            break
     # communities in the order of their smallest label, members in id order
     perm = torch.argsort(labels, stable=True)                          # perm[k] = old id at new position k
     order = torch.empty_like(perm)
     order[perm] = ids
     n_comm = int(torch.unique(labels).numel())
-    return order, f"{n_comm} communities after {it + 1} rounds, {moved} nodes still moving"
+    return order, f"{n_comm} communities after {it + 1} rounds, {moved} nodes moved in the last"
 
 
 @torch.no_grad()

@@ -878,7 +878,7 @@ def test_community_reorder_is_transparent(cuda):
     from sgl_amd.io import DeviceAdjacency
     from sgl_amd.operators import message_op as m
     from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
-    from sgl_amd.reorder import community_order, permute_csr
+    from sgl_amd.reorder import community_order, community_order_reference, permute_csr
     n, bs = 3000, 100
     adj0 = _planted_communities(n, bs, 12, 0.9, seed=4)
     shuffle = np.random.default_rng(5).permutation(n)                 # hide the communities in the ids
@@ -890,6 +890,8 @@ def test_community_reorder_is_transparent(cuda):
     order, info = community_order(d_adj.rowptr, d_adj.col, n)
     o = order.cpu().numpy()
     assert np.array_equal(np.sort(o), np.arange(n)), info
+    ref_order, _ = community_order_reference(d_adj.rowptr, d_adj.col, n)      # no node has > 256 neighbours: the kernel
+    assert torch.equal(order, ref_order)                                        # samples nothing and must agree exactly
     # the relabelled matrix keeps the planted communities together: most edges join nodes less than 2 communities apart
     rp, cc, vv = permute_csr(d_adj.rowptr, d_adj.col, d_adj.val, order)
     Q = sp.coo_matrix((np.ones(n, np.float32), (o, np.arange(n))), shape=(n, n)).tocsr()

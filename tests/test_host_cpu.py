@@ -329,10 +329,11 @@ def test_exchange_entry_point_argument_contract():
 
 
 def test_community_order_on_cpu_tensors():
-    """sgl_amd.reorder.community_order is plain tensor code: on a small planted-partition graph with shuffled ids it returns
-    a permutation under which most edges join nodes of the same (now contiguous) community"""
+    """sgl_amd.reorder.community_order_reference (the tensor-code statement of sgl_reorder_community): on a small
+    planted-partition graph with shuffled ids it returns a permutation under which most edges join nodes of the same (now
+    contiguous) community"""
     import scipy.sparse as sp
-    from sgl_amd.reorder import community_order
+    from sgl_amd.reorder import community_order_reference as community_order
     n, bs = 1200, 60
     rng = np.random.default_rng(3)
     a = np.repeat(np.arange(n), 10)
