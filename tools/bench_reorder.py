@@ -54,7 +54,7 @@ def main():
     n, d = wl["n"], wl["d"]
     x0 = synthetic.features_torch(n, d, seed=0, device=device)
     y = torch.empty_like(x0)
-    for bs in (2048, 16384):
+    for bs in [int(b) for b in os.environ.get("REORDER_BLOCKS", "2048,16384").split(",")]:
         rp, cc, vv = community_graph(n, wl["m"], bs, device)
         g = torch.Generator(device=device).manual_seed(11)
         shuffle = torch.randperm(n, generator=g, device=device)            # new id of old node i
