@@ -4,7 +4,10 @@
 // (the reference calls are, too).  The device-resident API (sgl_csr_create / sgl_spmm_f32) is the fast path.
 #include "sgl_common.h"
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 
@@ -17,8 +20,8 @@
 
 namespace {
 
-constexpr size_t kChunk = (size_t)32 << 20;   // staging granularity
-constexpr int kMaxThreads = 16;
+constexpr size_t kChunk = (size_t)16 << 20;   // staging granularity
+constexpr int kMaxThreads = 32;
 
 struct DevBuf {
     void *p = nullptr;
@@ -45,6 +48,24 @@ int team_size() {
     if (hc == 0) hc = 4;
     return (int)std::min<unsigned>(kMaxThreads, std::max<unsigned>(1, hc / 2));
 }
+
+// SGL_SHIM_TRACE=1: wall time of every phase of a shim call on stderr (where the PCIe-inclusive time goes)
+struct Phases {
+    bool on = std::getenv("SGL_SHIM_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string log;
+    void mark(const char *name) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof(buf), " %s=%.2fms", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        log += buf;
+        t0 = t1;
+    }
+    ~Phases() {
+        if (on) fprintf(stderr, "[sgl shim]%s\n", log.c_str());
+    }
+};
 
 template <typename F>
 void run_team(int threads, F fn) {
@@ -119,8 +140,11 @@ struct Shim {
     const void *indptr_p = nullptr, *indices_p = nullptr;
     int64_t n = -1, nnz = -1;
     uint64_t h_indptr = 0, h_indices = 0, h_data = 0;
-    sgl_csr_t *handle = nullptr;
-    DevBuf d_rp, d_col, d_val, d_x, d_y;
+    sgl_csr_t *handle = nullptr;          // == pieces[0] while a graph is cached
+    std::vector<sgl_csr_t *> pieces;       // row pieces of the cached adjacency, each with its own plan
+    std::vector<int64_t> piece_rows;       // [pieces + 1] row boundaries
+    std::vector<hipEvent_t> piece_done;
+    DevBuf d_rp, d_col, d_val, d_x, d_y, d_rp_local;
     // staging
     void *pinned[kMaxThreads] = {};
     hipStream_t streams[kMaxThreads] = {};
@@ -128,10 +152,52 @@ struct Shim {
     int64_t hits = 0, misses = 0;
 
     void drop_graph() {
-        if (handle) sgl_csr_destroy(handle);
+        for (sgl_csr_t *h : pieces) sgl_csr_destroy(h);
+        pieces.clear();
+        piece_rows.clear();
         handle = nullptr;
         indptr_p = indices_p = nullptr;
         n = nnz = -1;
+    }
+    // nnz-balanced row pieces (at most kPieces, none for tiny graphs), local row pointers behind one another in d_rp_local
+    int build_pieces(const std::vector<int64_t> &rp64, int64_t n_rows, int64_t n_nz) {
+        constexpr int kPieces = 8;
+        const int want = (n_nz >= ((int64_t)1 << 22)) ? kPieces : 1;
+        piece_rows.assign(1, 0);
+        for (int p = 1; p < want; ++p) {
+            const int64_t target = n_nz * p / want;
+            int64_t r = std::lower_bound(rp64.begin(), rp64.end(), target) - rp64.begin();
+            r = std::min<int64_t>(std::max<int64_t>(r, piece_rows.back()), n_rows);
+            if (r > piece_rows.back() && r < n_rows) piece_rows.push_back(r);
+        }
+        piece_rows.push_back(n_rows);
+        const size_t np = piece_rows.size() - 1;
+        std::vector<int64_t> local;
+        std::vector<size_t> at(np);
+        for (size_t p = 0; p < np; ++p) {
+            at[p] = local.size();
+            const int64_t base = rp64[piece_rows[p]];
+            for (int64_t r = piece_rows[p]; r <= piece_rows[p + 1]; ++r) local.push_back(rp64[r] - base);
+        }
+        int rc = d_rp_local.reserve(local.size() * sizeof(int64_t));
+        if (rc != SGL_OK) return rc;
+        SGL_HIP_CHECK(hipMemcpy(d_rp_local.p, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        for (size_t p = 0; p < np; ++p) {
+            const int64_t base = rp64[piece_rows[p]], rows = piece_rows[p + 1] - piece_rows[p];
+            const int64_t pnz = rp64[piece_rows[p + 1]] - base;
+            sgl_csr_t *h = nullptr;
+            rc = sgl_csr_create(&h, rows, n_rows, pnz, (const int64_t *)d_rp_local.p + at[p], (const int32_t *)d_col.p + base,
+                                (const float *)d_val.p + base, SGL_CSR_STRICT_ORDER, 0, 0, nullptr);
+            if (rc != SGL_OK) return rc;
+            pieces.push_back(h);
+        }
+        while (piece_done.size() < np) {
+            hipEvent_t e;
+            SGL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            piece_done.push_back(e);
+        }
+        handle = pieces[0];
+        return SGL_OK;
     }
     int ensure_staging(int threads) {
         for (int t = staged_threads; t < threads; ++t) {
@@ -196,13 +262,32 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
     std::lock_guard<std::mutex> lk(S.mu);
     const int threads = team_size();
     int rc;
+    Phases ph;
 
-    // ---- the adjacency: re-used when it is bit-for-bit the previous call's --------------------------------------------
+    // ---- the dense input starts travelling at once: it does not depend on whether the adjacency is cached -----------------
+    const size_t dense = (size_t)n * d * sizeof(float);
+    if ((rc = S.d_x.reserve(dense)) != SGL_OK) return rc;
+    if ((rc = S.d_y.reserve(dense)) != SGL_OK) return rc;
+    int rc_x = SGL_OK;
+    std::string err_x;
+    std::thread up_x([&] {
+        rc_x = S.copy(S.d_x.p, const_cast<float *>(mat), dense, true, threads);
+        if (rc_x != SGL_OK) err_x = sgl::get_error();     // the error text is thread-local: carry it over
+    });
+
+    // ---- meanwhile: is the adjacency bit-for-bit the previous call's?  is `answer` all zeros? -----------------------------
     const uint64_t hp = content_hash(indptr, ((size_t)n + 1) * sizeof(int), threads);
     const uint64_t hi = content_hash(indices, (size_t)nnz * sizeof(int), threads);
     const uint64_t hd = content_hash(data, (size_t)nnz * sizeof(float), threads);
     const bool hit = S.handle && S.indptr_p == indptr && S.indices_p == indices && S.n == n && S.nnz == nnz &&
                      S.h_indptr == hp && S.h_indices == hi && S.h_data == hd;
+    int acc = accumulate;
+    if (acc && all_zero(answer, dense, threads)) acc = 0;   // the reference pre-zeroes `answer` (utils.py:31): 0 + A.X = A.X
+    ph.mark("hash+zero_scan");
+    up_x.join();
+    ph.mark("x_upload_rest");
+    if (rc_x != SGL_OK) return sgl::fail(rc_x, "%s", err_x.c_str());
+
     if (!hit) {
         ++S.misses;
         S.drop_graph();
@@ -214,11 +299,10 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
         if ((rc = S.copy(S.d_rp.p, rp64.data(), rp64.size() * sizeof(int64_t), true, threads)) != SGL_OK) return rc;
         if ((rc = S.copy(S.d_col.p, const_cast<int *>(indices), (size_t)nnz * sizeof(int32_t), true, threads)) != SGL_OK) return rc;
         if ((rc = S.copy(S.d_val.p, const_cast<float *>(data), (size_t)nnz * sizeof(float), true, threads)) != SGL_OK) return rc;
-        // strict order: the shim promises the reference's exact per-row fmaf chain
-        rc = sgl_csr_create(&S.handle, n, n, nnz, (const int64_t *)S.d_rp.p, (const int32_t *)S.d_col.p,
-                            (const float *)S.d_val.p, SGL_CSR_STRICT_ORDER, 0, 0, nullptr);
-        if (rc != SGL_OK) {
-            S.handle = nullptr;
+        // strict order: the shim promises the reference's exact per-row fmaf chain.  The rows are cut into pieces with
+        // their own plans so that the download of a finished piece overlaps the computation of the next ones.
+        if ((rc = S.build_pieces(rp64, n, nnz)) != SGL_OK) {
+            S.drop_graph();
             return rc;
         }
         S.indptr_p = indptr;
@@ -228,22 +312,31 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
         S.h_indptr = hp;
         S.h_indices = hi;
         S.h_data = hd;
+        ph.mark("adjacency_upload+plan");
     } else {
         ++S.hits;
     }
 
-    // ---- the dense operands ---------------------------------------------------------------------------------------------
-    const size_t dense = (size_t)n * d * sizeof(float);
-    if ((rc = S.d_x.reserve(dense)) != SGL_OK) return rc;
-    if ((rc = S.d_y.reserve(dense)) != SGL_OK) return rc;
-    if ((rc = S.copy(S.d_x.p, const_cast<float *>(mat), dense, true, threads)) != SGL_OK) return rc;
-    int acc = accumulate;
-    if (acc && all_zero(answer, dense, threads)) acc = 0;   // the reference pre-zeroes `answer` (utils.py:31): 0 + A.X = A.X
     if (acc && (rc = S.copy(S.d_y.p, answer, dense, true, threads)) != SGL_OK) return rc;
-    rc = sgl_spmm_f32(S.handle, (const float *)S.d_x.p, d, (float *)S.d_y.p, d, d, acc, nullptr);
-    if (rc != SGL_OK) return rc;
-    SGL_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return S.copy(S.d_y.p, answer, dense, false, threads);
+    if (acc) ph.mark("answer_upload");
+    // all pieces are queued at once; each piece's rows are downloaded as soon as its event has fired
+    const size_t np = S.pieces.size();
+    for (size_t p = 0; p < np; ++p) {
+        const int64_t r0 = S.piece_rows[p], r1 = S.piece_rows[p + 1];
+        rc = sgl_spmm_f32(S.pieces[p], (const float *)S.d_x.p, d, (float *)S.d_y.p + r0 * d, d, d, acc, nullptr);
+        if (rc != SGL_OK) return rc;
+        SGL_HIP_CHECK(hipEventRecord(S.piece_done[p], nullptr));
+        (void)r1;
+    }
+    for (size_t p = 0; p < np; ++p) {
+        const int64_t r0 = S.piece_rows[p], r1 = S.piece_rows[p + 1];
+        SGL_HIP_CHECK(hipEventSynchronize(S.piece_done[p]));
+        if (p == 0) ph.mark("first_piece");
+        if ((rc = S.copy((float *)S.d_y.p + r0 * d, answer + r0 * d, (size_t)(r1 - r0) * d * sizeof(float), false, threads)) != SGL_OK)
+            return rc;
+    }
+    ph.mark("remaining_compute+download");
+    return SGL_OK;
 }
 
 }  // namespace
