@@ -160,6 +160,12 @@ enum { SGL_ACC_SUM = 0, SGL_ACC_WSUM = 1, SGL_ACC_MAX = 2, SGL_ACC_MIN = 3 };
 int sgl_spmm_acc_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, float *d_acc,
                      int64_t ldacc, float w, int mode, float divisor, void *stream);
 
+/* ---- device memory -> pageable host memory --------------------------------------------------------------------------------- */
+/* Contiguous copy through a team of host threads and pinned staging buffers, huge pages requested for a freshly allocated
+ * destination: the reference contract's CPU hop tensors (base_op.py:36 returns torch.FloatTensor(host array)) without a pinned
+ * allocation per result.  Synchronous; waits for `stream` (the producer) first. */
+int sgl_download(void *h_dst, const void *d_src, int64_t bytes, void *stream);
+
 /* ---- plan-time locality ordering ------------------------------------------------------------------------------------------ */
 /* d_order[i] = position of node i in an order that keeps communities contiguous: `rounds` (1..64, typically 8) rounds of
  * semi-synchronous label propagation on the structure (d_rowptr, d_col) of a symmetric adjacency -- every node adopts the most

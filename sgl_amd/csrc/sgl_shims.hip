@@ -11,6 +11,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sys/mman.h>
+
 // The unmodified reference calls the CPU symbol K times per propagate() with the SAME adjacency (base_op.py:29-35) and fresh
 // `answer` / `mat` arrays (utils.py:31-35).  So: the uploaded CSR, its execution plan and every device / pinned buffer are
 // kept between calls and re-used when the adjacency is bit-for-bit the one of the previous call (pointers for indptr /
@@ -66,6 +68,15 @@ struct Phases {
         if (on) fprintf(stderr, "[sgl shim]%s\n", log.c_str());
     }
 };
+
+// A freshly allocated host destination is faulted in by the copy itself: ask for huge pages on its 2 MiB-aligned interior
+// (500 x fewer faults where transparent huge pages are in "madvise" / "always" mode; a no-op elsewhere).
+void want_huge_pages(void *p, size_t bytes) {
+    if (bytes < ((size_t)4 << 20)) return;
+    const uintptr_t two_mb = (uintptr_t)2 << 20;
+    const uintptr_t a = ((uintptr_t)p + two_mb - 1) & ~(two_mb - 1), b = ((uintptr_t)p + bytes) & ~(two_mb - 1);
+    if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+}
 
 template <typename F>
 void run_team(int threads, F fn) {
@@ -319,6 +330,7 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
 
     if (acc && (rc = S.copy(S.d_y.p, answer, dense, true, threads)) != SGL_OK) return rc;
     if (acc) ph.mark("answer_upload");
+    want_huge_pages(answer, dense);     // utils.py:31 hands over a fresh np.zeros: its pages are faulted in by the download
     // all pieces are queued at once; each piece's rows are downloaded as soon as its event has fired
     const size_t np = S.pieces.size();
     for (size_t p = 0; p < np; ++p) {
@@ -360,6 +372,18 @@ SGL_EXPORT int FloatCSRMulDense(float answer[], int data_nnz, float data[], int 
 }
 
 // number of calls served from / not served from the cached adjacency (tests, INTEGRATION.md figures)
+// Device memory -> pageable host memory through the same team of threads and pinned staging buffers the shims use: for
+// callers that must receive ordinary host arrays -- the reference contract's CPU hop tensors (base_op.py:36).  Synchronous.
+// (The other direction gains nothing over torch's own pageable upload, measured; there is no sgl_upload.)
+SGL_EXPORT int sgl_download(void *h_dst, const void *d_src, int64_t bytes, void *stream) {
+    SGL_REQUIRE(bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "sgl_download: bad arguments");
+    SGL_HIP_CHECK(hipStreamSynchronize(sgl::as_stream(stream)));   // the producer's work is complete before the copy starts
+    want_huge_pages(h_dst, (size_t)bytes);
+    Shim &S = shim();
+    std::lock_guard<std::mutex> lk(S.mu);
+    return S.copy(const_cast<void *>(d_src), h_dst, (size_t)bytes, false, team_size());
+}
+
 SGL_EXPORT int sgl_shim_cache_stats(int64_t *hits, int64_t *misses) {
     Shim &S = shim();
     std::lock_guard<std::mutex> lk(S.mu);

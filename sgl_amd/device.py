@@ -72,6 +72,9 @@ def padded_parent(t):
     return torch.as_strided(t, (n, ld), (ld, 1), t.storage_offset())
 
 
+_STAGED_MIN_BYTES = 8 << 20     # below this a plain copy is as fast as the staging team
+
+
 def upload_rows(x, device):
     """host ndarray / tensor [n, d] (any float dtype / order) -> padded device buffer view [n, d] float32"""
     if isinstance(x, np.ndarray):
@@ -81,6 +84,18 @@ def upload_rows(x, device):
     out = alloc_rows(n, d, device)
     out.copy_(x.to(dtype=torch.float32), non_blocking=False)
     return out
+
+
+def download_rows(t):
+    """device [n, d] float32 (any row pitch) -> contiguous pageable CPU tensor, at link rate (sgl_download)"""
+    src = t if t.is_contiguous() else t.contiguous()
+    host = torch.empty(src.shape, dtype=torch.float32)
+    if src.numel() * 4 < _STAGED_MIN_BYTES:
+        host.copy_(src)
+        return host
+    with torch.cuda.device(src.device):
+        check(lib().sgl_download(host.data_ptr(), ptr(src), src.numel() * 4, current_stream_ptr()), "sgl_download")
+    return host
 
 
 def _check_mat(t, name):

@@ -233,18 +233,15 @@ class GraphOp:
             prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
 
         if self._opt("host_output"):
-            # reference contract: CPU FloatTensors.  Download through pinned staging buffers (cached by torch's host
-            # allocator) so the copies run at PCIe rate and overlap each other instead of ~6 GB/s pageable copies.
+            # reference contract: CPU FloatTensors (ordinary pageable memory, like the reference's).  The download runs through
+            # the library's pinned staging team (sgl_download): ~43 GB/s instead of ~6 GB/s for a pageable .cpu()
             alias0 = isinstance(feature, np.ndarray) and feature.dtype == np.float32
             out = []
             for i, f in enumerate(prop_feat_list):
                 if i == 0 and alias0:
                     out.append(torch.from_numpy(feature))  # the reference's first element aliases the caller's array
                     continue
-                host = torch.empty(f.shape, dtype=torch.float32, pin_memory=True)
-                host.copy_(f, non_blocking=True)
-                out.append(host)
-            torch.cuda.synchronize(device)
+                out.append(dev.download_rows(f))
             return out
         return prop_feat_list
 
