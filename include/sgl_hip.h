@@ -177,6 +177,17 @@ int sgl_download(void *h_dst, const void *d_src, int64_t bytes, void *stream);
 int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_col, int64_t n, int rounds, int64_t *d_order,
                           int64_t *h_info, void *stream);
 
+/* The rows of a CSR in processing order: storage row k of the output = input row d_perm[k]; column ids and the order of every
+ * row's entries unchanged (out_rowptr [n+1], out_col / out_val [nnz] caller-allocated).  A handle created on the output and
+ * given the same array as its row map computes bit for bit the products of the original matrix -- X and Y keep the caller's node
+ * order, only the order in which rows are processed (and with it the reuse of gathered rows in L2 / the Infinity Cache) changes. */
+int sgl_csr_permute_rows(const int64_t *d_rowptr, const int32_t *d_col, const float *d_val, int64_t n, const int32_t *d_perm,
+                         int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val, void *stream);
+/* Storage row i of the handle is output row d_rowmap[i] (a permutation of 0..n_rows-1; NULL removes the map; the array must
+ * outlive its use).  Applies to sgl_spmm_f32 / _chain / _acc / _axpb_clamp (outputs, residual and running aggregate are addressed
+ * through the map); the split layout and sgl_spmm_multi_f32 refuse a mapped handle. */
+int sgl_csr_set_rowmap(sgl_csr_t *csr, const int32_t *d_rowmap, void *stream);
+
 /* ---- multi-GPU exchange (row-sharded layout): the all-gather of the feature block between hops ---------------- */
 /* Rank `rank` of `world` owns rows [h_bounds[rank], h_bounds[rank+1]) of the [n, ldx] replica d_x (row-major, whole padded
  * rows travel) and has already written them; on completion (stream-ordered) every rank's rows are in place.  One grouped

@@ -18,12 +18,12 @@ fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / s
               pass (the running aggregate is read and written once per hop) and save K-1 hop buffers:
               "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
               device memory; True / False force it
-reorder       None -> the adjacency is used with the caller's node ids; "community" -> a plan-time locality ordering
+reorder       None -> the rows of A_hat are processed in the caller's node order; "community" -> a plan-time locality ordering
               (sgl_amd/reorder.py -> sgl_reorder_community: label propagation on the device, ~70 ms at products size, cached
-              with the adjacency)
-              relabels the problem so that communities are contiguous; propagate() permutes features in and hops out.
-              Pays on graphs that HAVE communities and whose ids do not show them (-37 % per hop on the shuffled
-              community graph of tools/exp_reorder.py), neutral on the random benchmark graph; not with strict_order
+              with the adjacency) decides the order in which the rows are STORED and PROCESSED (sgl_csr_permute_rows +
+              sgl_csr_set_rowmap); node ids, X, Y and every row's summation order are untouched, results are bit-identical.
+              Pays on graphs that HAVE communities their ids do not show (-32 % per hop on the shuffled community graph of
+              tools/bench_reorder.py), neutral on the random benchmark graph
 """
 import os
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -93,6 +94,27 @@ __global__ __launch_bounds__(256) void lpa_finish_kernel(const int32_t *__restri
     }
 }
 
+// rows of a CSR into processing order: storage row k of the output is row perm[k] of the input, entries untouched
+__global__ __launch_bounds__(256) void permute_len_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ perm,
+                                                          const int64_t n, int64_t *__restrict__ len) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k <= n; k += (int64_t)gridDim.x * 256)
+        len[k] = (k < n) ? rowptr[perm[k] + 1] - rowptr[perm[k]] : 0;
+}
+
+__global__ __launch_bounds__(256) void permute_copy_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const float *__restrict__ val, const int32_t *__restrict__ perm,
+                                                           const int64_t n, const int64_t *__restrict__ out_rowptr,
+                                                           int32_t *__restrict__ out_col, float *__restrict__ out_val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;   // one wavefront per row
+    if (k >= n) return;
+    const int64_t src = rowptr[perm[k]], dst = out_rowptr[k], len = out_rowptr[k + 1] - dst;
+    for (int64_t j = lane; j < len; j += 64) {
+        out_col[dst + j] = col[src + j];
+        out_val[dst + j] = val[src + j];
+    }
+}
+
 struct Tmp {
     std::vector<void *> ptrs;
     ~Tmp() {
@@ -160,5 +182,39 @@ SGL_EXPORT int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_c
         h_info[0] = (int64_t)h[0];
         h_info[1] = (int64_t)h[1];
     }
+    return SGL_OK;
+}
+
+// out = the rows of (d_rowptr, d_col, d_val) in the order d_perm (storage row k = input row d_perm[k]); column ids and the
+// order of every row's entries are unchanged.  out_rowptr [n+1], out_col / out_val [nnz] are the caller's.  With
+// sgl_csr_set_rowmap(handle_of_out, d_perm) the permuted matrix computes exactly the products of the original one.
+SGL_EXPORT int sgl_csr_permute_rows(const int64_t *d_rowptr, const int32_t *d_col, const float *d_val, int64_t n,
+                                    const int32_t *d_perm, int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val,
+                                    void *stream) {
+    SGL_REQUIRE(d_rowptr && d_perm && d_out_rowptr && n >= 0 && n < INT32_MAX, "sgl_csr_permute_rows: bad arguments");
+    hipStream_t st = sgl::as_stream(stream);
+    if (n == 0) {
+        SGL_HIP_CHECK(hipMemsetAsync(d_out_rowptr, 0, sizeof(int64_t), st));
+        return SGL_OK;
+    }
+    SGL_REQUIRE(sgl::launch_fits((n + 3) / 4, 256), "sgl_csr_permute_rows: too many rows for one launch");
+    Tmp tmp;
+    int rc;
+    int64_t *len = nullptr;
+    if ((rc = tmp.alloc(&len, (size_t)n + 1)) != SGL_OK) return rc;
+    const unsigned sgrid = (unsigned)std::min<int64_t>((n + 256) / 256, 1 << 20);
+    hipLaunchKernelGGL(permute_len_kernel, dim3(sgrid), dim3(256), 0, st, d_rowptr, d_perm, n, len);
+    SGL_HIP_CHECK(hipGetLastError());
+    size_t bytes = 0;
+    SGL_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, len, d_out_rowptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+    char *scratch = nullptr;
+    if ((rc = tmp.alloc(&scratch, bytes)) != SGL_OK) return rc;
+    SGL_HIP_CHECK(rocprim::exclusive_scan(scratch, bytes, len, d_out_rowptr, (int64_t)0, (size_t)n + 1, rocprim::plus<int64_t>(), st));
+    if (d_col && d_val && d_out_col && d_out_val) {
+        hipLaunchKernelGGL(permute_copy_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_rowptr, d_col, d_val, d_perm, n,
+                           d_out_rowptr, d_out_col, d_out_val);
+        SGL_HIP_CHECK(hipGetLastError());
+    }
+    SGL_HIP_CHECK(hipStreamSynchronize(st));   // the temporaries are freed on return
     return SGL_OK;
 }

@@ -132,6 +132,7 @@ struct SpmmArgs {
     float *yt;
     int64_t ldxt, ldyt;
     int32_t d_main, tail_full, tail_nt;
+    const int32_t *rowmap;     // optional [n_rows]: storage row -> output row (sgl_csr_set_rowmap); NULL = identity
 };
 
 struct TailArgs {
@@ -180,13 +181,22 @@ __device__ __forceinline__ float epi_apply(float v, float r, const Epilogue &e, 
 
 // One wavefront walks `nrows` consecutive rows whose non-zeros are colb/valb[0 .. tot) ; lane i of `my_rel`
 // holds the offset of row i's first non-zero (lane nrows holds tot).
+// Row map (sgl_csr_set_rowmap): the CSR's rows are stored in PROCESSING order (a locality ordering found at plan time), row i
+// of the storage is row my_map[i] of the product.  Only the output side is indirect -- Y, the residual and the running
+// aggregate are addressed with the mapped index from un-offset base pointers; the gathers use the original column ids, and a
+// row's terms are added in their original order, so the result is bit-identical to the unpermuted matrix's.
+struct RowMap {
+    int my_map = 0;      // lane i: output row of the item's row i
+    bool on = false;
+};
+
 template <int VEC, int GROUP, int NCH, int U, bool NT, bool MULTI, bool TAIL = false>
 __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const float *__restrict__ valb,
                                          const int my_rel, const int nrows, const int tot,
                                          const float *__restrict__ x, const int64_t ldx, float *__restrict__ out,
                                          const int64_t ldo, const int d, const bool accumulate, const int lane,
                                          const Epilogue epi, const int64_t ldres, const MultiOut mo,
-                                         const TailArgs ta = TailArgs()) {
+                                         const TailArgs ta = TailArgs(), const RowMap rm = RowMap()) {
     using V = typename VecT<VEC>::type;
     constexpr int R = 64 / GROUP;
     static_assert(!TAIL || (R == 1 && NCH == 1 && VEC == 4 && !MULTI), "split layout: one 16-byte lane per 4 columns");
@@ -224,14 +234,15 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
     for (int ri = 0; ri < nrows; ++ri) {
         const int jb = __builtin_amdgcn_readlane(my_rel, ri);
         const int je = __builtin_amdgcn_readlane(my_rel, ri + 1);
-        float *orow = out + (int64_t)ri * ldo;
+        const int64_t ro = rm.on ? (int64_t)__builtin_amdgcn_readlane(rm.my_map, ri) : (int64_t)ri;   // output row
+        float *orow = out + ro * ldo;
         V acc[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = vzero<VEC>();
         if (accumulate && s == 0) {
             if constexpr (TAIL) {
                 if (on[0])
-                    acc[0] = (is_tail && ta.ot) ? *reinterpret_cast<const V *>(ta.ot + (int64_t)ri * ta.ldot + (colofs[0] - ta.d_main))
+                    acc[0] = (is_tail && ta.ot) ? *reinterpret_cast<const V *>(ta.ot + ro * ta.ldot + (colofs[0] - ta.d_main))
                                                 : *reinterpret_cast<const V *>(orow + colofs[0]);
             } else {
 #pragma unroll
@@ -321,7 +332,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                     if (epi.on) {
                         const bool has_res = epi.res != nullptr;
                         V r = vzero<VEC>();
-                        if (has_res) r = *reinterpret_cast<const V *>(epi.res + (int64_t)ri * ldres + colofs[ch]);
+                        if (has_res) r = *reinterpret_cast<const V *>(epi.res + ro * ldres + colofs[ch]);
                         if constexpr (VEC == 1) {
                             v = epi_apply(v, r, epi, has_res);
                         } else {
@@ -330,7 +341,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                         }
                     }
                     if (epi.acc) {
-                        float *ap = epi.acc + (int64_t)ri * epi.ldacc + colofs[ch];
+                        float *ap = epi.acc + ro * epi.ldacc + colofs[ch];
                         V a = *reinterpret_cast<const V *>(ap);
                         if constexpr (VEC == 1) {
                             a = acc_apply(a, v, epi);
@@ -343,7 +354,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                     if constexpr (TAIL) {
                         if (!is_tail || ta.full) st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
                         if (is_tail && ta.ot)
-                            *reinterpret_cast<V *>(ta.ot + (int64_t)ri * ta.ldot + (colofs[ch] - ta.d_main)) = v;
+                            *reinterpret_cast<V *>(ta.ot + ro * ta.ldot + (colofs[ch] - ta.d_main)) = v;
                     } else {
                         st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
                     }
@@ -352,7 +363,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
 #pragma unroll
                         for (int q = 0; q < 7; ++q)  // replicas (peer memory): posted stores, nothing waits on them
                             if (q < mo.n && ((need >> q) & 1))
-                                *reinterpret_cast<V *>(mo.p[q] + (int64_t)ri * ldo + colofs[ch]) = v;
+                                *reinterpret_cast<V *>(mo.p[q] + ro * ldo + colofs[ch]) = v;
                     }
                 }
         }
@@ -396,13 +407,17 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         const int64_t base = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
         const int my_rel = (int)(rp - base);
         const int tot = __builtin_amdgcn_readlane(my_rel, nrows);
+        RowMap rm;
+        rm.on = a.rowmap != nullptr;            // then the output-side pointers stay un-offset: rows are addressed through the map
+        rm.my_map = rm.on ? a.rowmap[(int64_t)row_begin + max(min(lane, nrows - 1), 0)] : 0;
+        const int64_t first = rm.on ? 0 : row_begin;
         Epilogue epi;
-        epi.res = a.res ? a.res + (int64_t)row_begin * a.ldres : nullptr;
+        epi.res = a.res ? a.res + first * a.ldres : nullptr;
         epi.alpha = a.epi_alpha;
         epi.lo = a.epi_lo;
         epi.hi = a.epi_hi;
         epi.on = a.epi;
-        epi.acc = a.acc ? a.acc + (int64_t)row_begin * a.ldacc : nullptr;
+        epi.acc = a.acc ? a.acc + first * a.ldacc : nullptr;
         epi.ldacc = a.ldacc;
         epi.acc_w = a.acc_w;
         epi.acc_div = a.acc_div;
@@ -413,8 +428,8 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
 #pragma unroll
         for (int q = 0; q < 7; ++q) mo.p[q] = (MULTI && q < a.n_more) ? a.y_more[q] + (int64_t)row_begin * a.ldy : nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, MULTI>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
-                                         a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
-                                         a.ldres, mo);
+                                         a.y + first * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
+                                         a.ldres, mo, TailArgs(), rm);
     }
 }
 
@@ -566,6 +581,8 @@ struct sgl_csr {
     size_t partial_cap = 0;  // floats
     std::vector<float *> retired;   // outgrown workspaces: a captured hipGraph may still replay into them (freed at destroy)
     int device = 0;
+    const int32_t *d_rowmap = nullptr;   // caller's [n_rows] storage row -> output row (sgl_csr_set_rowmap), not owned
+    int32_t *d_long_out = nullptr;       // output rows of the split rows under the row map
 };
 
 SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
@@ -638,8 +655,36 @@ SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
     (void)hipFree(h->d_long_row);
     (void)hipFree(h->d_long_first);
     (void)hipFree(h->d_partial);
+    (void)hipFree(h->d_long_out);
     for (float *p : h->retired) (void)hipFree(p);
     delete h;
+    return SGL_OK;
+}
+
+// The handle's rows are stored in processing order: storage row i is row d_rowmap[i] of the product (a permutation of
+// 0..n_rows-1, e.g. sgl_reorder_community's order applied with sgl_csr_permute_rows).  Every product of this handle then writes
+// (and, for the epilogues, reads the residual / running aggregate of) output row d_rowmap[i]; X is gathered by the ORIGINAL
+// column ids and every row keeps the order of its terms, so results are bit-identical to the unpermuted matrix's.  NULL
+// removes the map.  The array must stay alive as long as the handle uses it.
+SGL_EXPORT int sgl_csr_set_rowmap(sgl_csr_t *h, const int32_t *d_rowmap, void *stream) {
+    if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_set_rowmap: NULL handle");
+    h->d_rowmap = nullptr;
+    if (!d_rowmap || h->n_rows == 0) return SGL_OK;
+    if (h->n_long > 0) {   // the split rows' fix-up writes whole output rows: give it their mapped ids
+        hipStream_t st = sgl::as_stream(stream);
+        std::vector<int32_t> map((size_t)h->n_rows), rows((size_t)h->n_long);
+        SGL_HIP_CHECK(hipMemcpyAsync(map.data(), d_rowmap, map.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SGL_HIP_CHECK(hipMemcpyAsync(rows.data(), h->d_long_row, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SGL_HIP_CHECK(hipStreamSynchronize(st));
+        for (auto &r : rows) {
+            SGL_REQUIRE(r >= 0 && r < h->n_rows && map[r] >= 0 && map[r] < h->n_rows, "sgl_csr_set_rowmap: map entry outside [0, n_rows)");
+            r = map[r];
+        }
+        if (!h->d_long_out) SGL_HIP_CHECK(hipMalloc(&h->d_long_out, rows.size() * sizeof(int32_t)));
+        SGL_HIP_CHECK(hipMemcpyAsync(h->d_long_out, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        SGL_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    h->d_rowmap = d_rowmap;
     return SGL_OK;
 }
 
@@ -774,6 +819,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.d_main = eh.xt ? eh.d_main : d;
     a.tail_full = eh.xt ? eh.tail_full : 1;
     a.tail_nt = sgl::tuning("spmm_tail_nt", 0) != 0 ? 1 : 0;
+    a.rowmap = h->d_rowmap;
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
     a.xcd_remap = (!(h->flags & SGL_CSR_NO_XCD_REMAP) && sgl::tuning("spmm_xcd_remap", 1) != 0) ? 1 : 0;
@@ -836,7 +882,8 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         fmo.n = eh.n_more;
         fmo.mask = eh.row_mask;
         for (int q = 0; q < 7; ++q) fmo.p[q] = eh.y_more[q];
-        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_long_row, h->d_long_first, h->d_partial, a.ldp,
+        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_rowmap ? h->d_long_out : h->d_long_row,
+                           h->d_long_first, h->d_partial, a.ldp,
                            d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo, a.yt, a.ldyt, a.d_main, a.tail_full);
         e = hipGetLastError();
         if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: fix-up launch failed: %s", hipGetErrorString(e));
@@ -850,6 +897,8 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
     SGL_REQUIRE(d >= 0 && d < INT32_MAX, "%s: bad d", who);
     if (d == 0 || h->n_rows == 0) return SGL_OK;
     SGL_REQUIRE(d_x && d_y, "%s: NULL X or Y", who);
+    if (h->d_rowmap && (eh.xt || eh.n_more > 0))
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: a row-mapped handle supports neither the split layout nor replicas", who);
     if (eh.xt)   // split layout (validated by the caller): the kernel walks d_main + padded tail columns
         return spmm_slice(h, d_x, ldx, d_y, ldy, eh.d_main + (int)((d - eh.d_main + 3) / 4 * 4), 4, accumulate,
                           sgl::as_stream(stream), eh);

@@ -86,6 +86,20 @@ def upload_rows(x, device):
     return out
 
 
+def permute_rows(rowptr, col, val, perm):
+    """the rows of a device CSR in the order `perm` (storage row k = input row perm[k]); column ids and every row's entries
+    untouched (sgl_csr_permute_rows).  perm: int32 permutation on the device."""
+    n = rowptr.numel() - 1
+    perm = perm.to(torch.int32).contiguous()
+    out_ptr = torch.empty(n + 1, dtype=torch.int64, device=rowptr.device)
+    out_col = torch.empty_like(col)
+    out_val = torch.empty_like(val)
+    with torch.cuda.device(rowptr.device):
+        check(lib().sgl_csr_permute_rows(ptr(rowptr), ptr(col), ptr(val), n, ptr(perm), ptr(out_ptr), ptr(out_col), ptr(out_val),
+                                         current_stream_ptr()), "sgl_csr_permute_rows")
+    return out_ptr, out_col, out_val
+
+
 def download_rows(t):
     """device [n, d] float32 (any row pitch) -> contiguous pageable CPU tensor, at link rate (sgl_download)"""
     src = t if t.is_contiguous() else t.contiguous()
@@ -152,6 +166,20 @@ class DeviceCSR:
             raise TypeError("val must be a contiguous float32 CUDA tensor with one entry per non-zero")
         check(lib().sgl_csr_set_values(self._h, ptr(val)), "sgl_csr_set_values")
         self.val = val
+        return self
+
+    rowmap = None
+
+    def set_rowmap(self, rowmap):
+        """the handle's rows are stored in processing order: storage row i is output row rowmap[i] (int32 permutation on the
+        device, kept alive here; None removes it).  sgl_csr_set_rowmap."""
+        if rowmap is not None and not (rowmap.is_cuda and rowmap.dtype == torch.int32 and rowmap.dim() == 1
+                                       and rowmap.is_contiguous() and rowmap.numel() == self.shape[0]):
+            raise TypeError("rowmap must be a contiguous int32 CUDA tensor with one entry per row")
+        with torch.cuda.device(self.device):
+            check(lib().sgl_csr_set_rowmap(self._h, ptr(rowmap) if rowmap is not None else None, current_stream_ptr()),
+                  "sgl_csr_set_rowmap")
+        self.rowmap = rowmap
         return self
 
     def info(self):

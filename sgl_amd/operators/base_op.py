@@ -91,33 +91,27 @@ class GraphOp:
         reorder = self._opt("reorder") or None
         if reorder not in (None, "community"):
             raise ValueError("reorder must be None or 'community'")
-        if reorder and self._opt("strict_order"):
-            raise ValueError("reorder changes the order in which a row's terms are added: it cannot be combined with strict_order")
         params = (r, alpha, bool(self._opt("strict_order")), str(self._opt("device")), reorder)
         if self._opt("cache_adj") and self._adj is not None and self._adj_key is not None:
             ident, cached_params = self._adj_key
             if cached_params == params and ident.matches(adj):
                 return self._adj
-        order = None
-        if reorder:
-            # plan-time locality ordering (sgl_amd/reorder.py): communities contiguous -> gathered rows of X are re-used
-            # while they are still in L2 / the Infinity Cache.  The whole path then runs on P A P^T; propagate() permutes
-            # the features in and the hops out, so callers never see the relabelling.
-            from ..reorder import community_order, permute_csr
-            dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=self._opt("device"))
-            order, _ = community_order(dadj.rowptr, dadj.col, dadj.shape[0])
-            rowptr, col, val = permute_csr(dadj.rowptr, dadj.col, dadj.val, order)
-            rowptr, col, val = dev.normalize_adj(rowptr, col, val, dadj.shape[0], r, alpha)
-        elif isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
+        if isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, adj.shape[0], r, alpha)
         else:
             rowptr, col, val = adj_to_symmetric_norm_device(adj, r, alpha, device=self._opt("device"))
+        rowmap = None
+        if reorder:
+            # plan-time locality ordering (sgl_amd/reorder.py): the rows of A_hat are STORED in an order that keeps communities
+            # together and processed in that order, so a gathered row of X is re-used while it is still in L2 / the Infinity
+            # Cache.  Column ids, X, Y and the order of every row's terms stay the caller's: results are bit-identical.
+            from ..reorder import community_order
+            order, _ = community_order(rowptr, col, adj.shape[0])
+            rowmap = torch.argsort(order).to(torch.int32)           # rowmap[k] = node processed k-th
+            rowptr, col, val = dev.permute_rows(rowptr, col, val, rowmap)
         csr = dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
-        csr.order = order                                  # order[i] = position of node i in the relabelled problem
-        csr.perm = None
-        if order is not None:
-            csr.perm = torch.empty_like(order)
-            csr.perm[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
+        if rowmap is not None:
+            csr.set_rowmap(rowmap)
         self._adj_key = (AdjIdentity(adj), params) if self._opt("cache_adj") else None
         return csr
 
@@ -169,12 +163,6 @@ class GraphOp:
                 return None
         self._checked(adj, feature)
         cur = self._device_features(feature)
-        order = getattr(self._adj, "order", None)
-        if order is not None:
-            cur = dev.gather_rows(cur, self._adj.perm)         # features in the relabelled order
-
-        def home(t):                                           # results back in the caller's node order
-            return dev.gather_rows(t, order) if order is not None else t
         d = cur.shape[1]
         src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
         n = self._adj.shape[0]
@@ -200,10 +188,10 @@ class GraphOp:
                     acc = begin(y)
             x = y
         if kind == "last":
-            return home(x[:, :d] if x.shape[1] != d else x)
+            return x[:, :d] if x.shape[1] != d else x
         if kind == "mean" and e - s == 1:      # a single hop in range: the division has no SpMM to ride on
             acc = acc / torch.tensor(float(divisor if divisor is not None else 1), device=acc.device)   # true division
-        return home(acc[:, :d] if acc.shape[1] != d else acc)
+        return acc[:, :d] if acc.shape[1] != d else acc
 
     def propagate(self, adj, feature):
         self._checked(adj, feature)
@@ -213,14 +201,7 @@ class GraphOp:
         # are zeros and stay zeros under propagation)
         d = cur.shape[1]
         K = self._prop_steps
-        order = getattr(self._adj, "order", None)
-        if order is not None:
-            xp = dev.gather_rows(cur, self._adj.perm)
-            src = dev.padded_parent(xp) if xp.stride(0) % 4 == 0 else xp
-            hops = self._adj.spmm_chain(src, K)
-            prop_feat_list = [cur] + [dev.gather_rows(y[:, :d] if y.shape[1] != d else y, order) for y in hops]
-            del hops
-        elif self._opt("slab_hops") and d % 4 == 0 and K >= 1 and not self._opt("host_output"):
+        if self._opt("slab_hops") and d % 4 == 0 and K >= 1 and not self._opt("host_output"):
             # concat-as-layout: hop k is produced directly in column slice k of one [n, (K+1) d] slab (the kernel takes
             # leading dimensions), so ConcatMessageOp over consecutive hops is a view of it -- no copy of any hop
             slab = torch.empty((cur.shape[0], (K + 1) * d), dtype=torch.float32, device=device)
@@ -228,9 +209,8 @@ class GraphOp:
             views[0].copy_(cur)
             self._adj.spmm_chain(views[0], K, outs=views[1:])
             return views
-        if order is None:
-            src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
-            prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
+        src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
+        prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
 
         if self._opt("host_output"):
             # reference contract: CPU FloatTensors (ordinary pageable memory, like the reference's).  The download runs through

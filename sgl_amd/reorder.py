@@ -1,16 +1,19 @@
 """Plan-time node ordering for locality: real co-purchase / citation graphs have communities, and a
 gathered row of X that was fetched for one member of a community is fetched again for the next -- if the members are processed
-close together it is still in L2 / the Infinity Cache.  A node order that keeps communities contiguous turns that into
+close together it is still in L2 / the Infinity Cache.  A processing order that keeps communities together turns that into
 hits; ids as they come out of a dump carry no such order.
 
-    order, info = community_order(rowptr, col, n)      # order[i] = new id of node i (a permutation), found on the device
-    rowptr2, col2, val2 = permute_csr(rowptr, col, val, order)        # P A P^T, canonical (sorted columns)
+    order, info = community_order(rowptr, col, n)      # order[i] = position of node i (a permutation), found on the device
+
+GraphOp(reorder="community") applies it without relabelling anything: rowmap = argsort(order), the rows of A_hat are stored in
+that order (device.permute_rows) and the SpMM handle writes storage row i to output row rowmap[i] (DeviceCSR.set_rowmap) --
+bit-identical results.  permute_csr relabels the whole problem instead (P A P^T, canonical): the comparison point of
+tools/bench_reorder.py and a utility for callers who want the relabelled graph.
 
 The ordering is a few rounds of semi-synchronous label propagation (every node adopts the most frequent label among its
 neighbours, ties to the smaller label; half of the nodes move per round so two-coloured structures cannot oscillate), then a
 stable sort by label: sgl_reorder_community in the HIP library (one wavefront per node, the neighbours' labels counted in LDS).
-It is a heuristic that runs once per graph; nothing of the propagation path depends on it, results are the permuted results
-(GraphOp(reorder=...) permutes features in and hops out).  `community_order_reference` is the same algorithm in plain tensor
+It is a heuristic that runs once per graph; nothing of the propagation path depends on it.  `community_order_reference` is the same algorithm in plain tensor
 code -- the readable statement the tests pin the kernel to (identical labels when no node has more than 256 neighbours; the
 kernel samples longer rows)."""
 import ctypes

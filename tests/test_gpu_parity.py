@@ -870,10 +870,10 @@ def _planted_communities(n, bs, deg, p_in, seed):
 
 
 def test_community_reorder_is_transparent(cuda):
-    """GraphOp(reorder="community"): the plan-time locality ordering relabels the problem (P A P^T), propagate() and
-    propagate_reduce() permute features in and results out -- callers get the same hops as without it (different summation
-    order: tolerance, not bits), the order is a permutation that makes the planted communities contiguous, permute_csr is
-    scipy's P A P^T, and strict_order refuses the combination"""
+    """GraphOp(reorder="community"): the plan-time locality ordering only changes the order in which the rows of A_hat are
+    STORED and PROCESSED (sgl_csr_permute_rows + sgl_csr_set_rowmap) -- X, Y, the column ids and the order of every row's terms
+    stay the caller's, so hops and fused aggregates are bit-identical with and without it, in strict order too; the order is
+    a permutation that makes the planted communities contiguous; permute_csr (the relabelled P A P^T) is scipy's"""
     from sgl_amd import device as dev
     from sgl_amd.io import DeviceAdjacency
     from sgl_amd.operators import message_op as m
@@ -885,7 +885,7 @@ def test_community_reorder_is_transparent(cuda):
     P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
     adj = (P @ adj0 @ P.T).tocsr()
     adj.sort_indices()
-    x = hash_matrix(n, 20, seed=6)
+    x = hash_matrix(n, 128, seed=6)
     d_adj = DeviceAdjacency.from_scipy(adj, device=cuda)
     order, info = community_order(d_adj.rowptr, d_adj.col, n)
     o = order.cpu().numpy()
@@ -904,20 +904,50 @@ def test_community_reorder_is_transparent(cuda):
     coo0 = adj.tocoo()
     near_before = np.mean(np.abs(coo0.row - coo0.col) < 2 * bs)
     assert near_before < 0.2 and near_after > 0.8, (near_before, near_after, info)
+    from sgl_amd.tricks import label_propagation
     for plain, reord in ((LaplacianGraphOp(3, r=0.5), LaplacianGraphOp(3, r=0.5, reorder="community")),
-                         (PprGraphOp(2, r=0.3, alpha=0.2), PprGraphOp(2, r=0.3, alpha=0.2, reorder="community"))):
+                         (PprGraphOp(2, r=0.3, alpha=0.2), PprGraphOp(2, r=0.3, alpha=0.2, reorder="community")),
+                         (LaplacianGraphOp(3, r=0.5, strict_order=True), LaplacianGraphOp(3, r=0.5, strict_order=True, reorder="community"))):
         ha, hb = plain.propagate(adj, x), reord.propagate(adj, x)
-        assert len(ha) == len(hb) and torch.equal(ha[0], hb[0])
-        for a, b in zip(ha[1:], hb[1:]):
-            assert oracle.parity_ok(b.cpu().numpy(), a.cpu().numpy(), 1e-5)
-        for op in (m.LastMessageOp(), m.MeanMessageOp(0, 3), m.MaxMessageOp(1, 3)):
+        assert len(ha) == len(hb)
+        for a, b in zip(ha, hb):
+            assert torch.equal(a, b)        # rows are only PROCESSED in another order (x is 128 wide: one fmaf chain per row)
+        for op in (m.LastMessageOp(), m.MeanMessageOp(0, 3), m.MaxMessageOp(1, 3), m.SimpleWeightedMessageOp(0, 3, "alpha", 0.85)):
             spec = op.fused_spec(len(ha))
             fa, fb = plain.propagate_reduce(adj, x, **spec), reord.propagate_reduce(adj, x, **spec)
-            assert oracle.parity_ok(fb.cpu().numpy(), fa.cpu().numpy(), 1e-5), type(op).__name__
-        assert reord._adj.order is not None and plain._adj.order is None
+            assert torch.equal(fa, fb), type(op).__name__          # the running aggregate is addressed through the row map too
+        assert reord._adj.rowmap is not None and plain._adj.rowmap is None
+        assert np.array_equal(np.sort(reord._adj.rowmap.cpu().numpy()), np.arange(n))
         reord.propagate(adj, x)                                        # cached: the ordering is found once per adjacency
-    with pytest.raises(ValueError):
-        LaplacianGraphOp(2, reorder="community", strict_order=True).propagate(adj, x)
+    # long rows (split into pieces, summed by the fix-up kernel) under a row map; residual and running aggregate of the epilogues
+    big = long_row_graph(n=1600, seed=9)
+    big = (big + big.T).tocsr()
+    big.data[:] = 1.0
+    nb = big.shape[0]
+    b_adj = DeviceAdjacency.from_scipy(big, device=cuda)
+    rp, cc, vv = dev.normalize_adj(b_adj.rowptr, b_adj.col, b_adj.val, nb, 0.5, None)
+    rowmap = torch.from_numpy(np.random.default_rng(2).permutation(nb).astype(np.int32)).to(cuda)   # any permutation will do
+    rp2, c2, v2 = dev.permute_rows(rp, cc, vv, rowmap)
+    ca = dev.DeviceCSR(rp, cc, vv, (nb, nb), long_row_nnz=256)
+    cb = dev.DeviceCSR(rp2, c2, v2, (nb, nb), long_row_nnz=256).set_rowmap(rowmap)
+    assert cb.info()["n_long_rows"] > 0 and cb.info()["n_pieces"] > 0
+    for dd in (100, 36):
+        # d > 64 (one non-zero per step, a row = one fmaf chain): bit-identical.  d <= 64 packs several non-zeros per step and
+        # a row's partial sums depend on where it sits in its item (as they do between two plans of the same matrix): 1e-5
+        same = (lambda a, b: torch.equal(a, b)) if dd > 64 else (lambda a, b: oracle.parity_ok(b.cpu().numpy(), a.cpu().numpy(), 1e-5))
+        xa = dev.upload_rows(hash_matrix(nb, dd, seed=8), cuda)
+        assert same(ca.spmm(xa), cb.spmm(xa)), dd
+        res = dev.upload_rows(hash_matrix(nb, dd, seed=12), cuda)
+        assert same(ca.spmm_axpb_clamp(xa, 0.7, res, 0.0, 1.0), cb.spmm_axpb_clamp(xa, 0.7, res, 0.0, 1.0)), dd
+        acc_a, acc_b = res.clone(), res.clone()
+        ya, yb = torch.empty_like(xa), torch.empty_like(xa)
+        ca.spmm_acc(xa, ya, acc_a, w=0.3, mode="wsum")
+        cb.spmm_acc(xa, yb, acc_b, w=0.3, mode="wsum")
+        assert same(ya, yb) and same(acc_a, acc_b), dd
+    with pytest.raises(Exception):                                     # replicas / split layout refuse a mapped handle
+        cb.spmm_multi(xa, [ya.data_ptr(), yb.data_ptr()], ya.stride(0))
+    cb.set_rowmap(None)                                                # without the map the stored order is what it is
+    assert not torch.equal(ca.spmm(xa), cb.spmm(xa))
     with pytest.raises(ValueError):
         LaplacianGraphOp(2, reorder="rcm").propagate(adj, x)
 

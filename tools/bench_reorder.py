@@ -76,6 +76,17 @@ def main():
             nz = ccn.numel()
             alg = nz * d * 4 + nz * 8 + (n + 1) * 4 + n * d * 4
             print(f"EXP reorder community={bs} {name}: ms_per_hop={ms:.3f} frac={alg / (ms * 1e-3) / 8e12:.3f}", flush=True)
+            if name == "shuffled ids":
+                # what GraphOp(reorder="community") does: the same matrix, ids untouched, rows STORED and PROCESSED in the
+                # label-propagation order (sgl_csr_permute_rows + sgl_csr_set_rowmap) -- bit-identical results
+                y_plain = y.clone()
+                rowmap = torch.argsort(order).to(torch.int32)
+                rp2, c2, v2 = dev.permute_rows(rpn, ccn, vvn, rowmap)
+                cm = dev.DeviceCSR(rp2, c2, v2, (n, n)).set_rowmap(rowmap)
+                ms = time_ms(lambda: cm.spmm(x0, out=y))
+                print(f"EXP reorder community={bs} shuffled ids, rows processed in label-propagation order (row map, ids untouched): "
+                      f"ms_per_hop={ms:.3f} frac={alg / (ms * 1e-3) / 8e12:.3f} bit_identical={bool(torch.equal(y, y_plain))}", flush=True)
+                del cm, rp2, c2, v2, y_plain
             del csr, rpn, ccn, vvn
         print(f"EXP reorder community={bs} plan-time cost: ordering {t_order * 1e3:.0f} ms + permuting the CSR {t_perm * 1e3:.0f} ms", flush=True)
         # end to end through the operator (features permuted in, every hop permuted out), k = 3, adjacency cached
