@@ -21,9 +21,11 @@ _METHODS = ("mean", "max", "concat", "simple")
 
 @torch.no_grad()
 def nafs_ensemble_features(adj, x, hops, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), method="mean", device="cuda",
-                           strict_order=False):
+                           strict_order=False, reorder=None):
     """adj: scipy sparse adjacency (un-normalised); x: [N, d] ndarray / tensor.  Returns a CUDA tensor:
-    [N, d] for mean / max / simple, [N, len(r_list) * d] for concat."""
+    [N, d] for mean / max / simple, [N, len(r_list) * d] for concat.
+    reorder="community": the rows of every A_hat are processed in a plan-time locality order (sgl_amd/reorder.py; found once,
+    the structure does not depend on r) -- same results, fewer cache misses on graphs with communities."""
     method = method.lower()
     if method not in _METHODS:
         raise ValueError("Method not Suppoted! Choose 'mean', 'max' or 'concat' !")
@@ -36,13 +38,24 @@ def nafs_ensemble_features(adj, x, hops, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), me
     x0 = dev.upload_rows(x, device)
     d = x0.shape[1]
     hop_bufs = [dev.alloc_rows(n, d, device) for _ in range(hops)]                  # shared by all r
+    if reorder not in (None, "community"):
+        raise ValueError("reorder must be None or 'community'")
     csr = None
+    rowmap = None
     per_r = []
     prep = dev.PreparedAdjacency(dadj.rowptr, dadj.col, dadj.val, n)               # r-independent part, once
     for r in r_list:
         rowptr, col, val = prep.normalize(r, None)
+        if reorder and rowmap is None:
+            from ..reorder import community_order
+            order, _ = community_order(rowptr, col, n)
+            rowmap = torch.argsort(order).to(torch.int32)
+        if rowmap is not None:
+            rowptr, col, val = dev.permute_rows(rowptr, col, val, rowmap)          # rows stored in processing order
         if csr is None:
             csr = dev.DeviceCSR(rowptr, col, val, dadj.shape, strict=strict_order)  # one plan: the structure is r-independent
+            if rowmap is not None:
+                csr.set_rowmap(rowmap)
         else:
             csr.set_values(val)
         feats = [x0]

@@ -1290,6 +1290,12 @@ def test_nafs_task_feature_pipeline_matches_reference(goldens, cuda):
     dadj = DeviceAdjacency.from_scipy(g, device=cuda)
     y_host = nafs_ensemble_features(g, x, 3, [0.5, 0.3, 0], "mean")
     assert torch.equal(nafs_ensemble_features(dadj, torch.from_numpy(x).to(cuda), 3, [0.5, 0.3, 0], "mean"), y_host)
+    # rows processed in the plan-time community order (one order for all r): the same features (d = 8 uses a packed lane
+    # layout: to rounding; strict order: bit for bit)
+    y_re = nafs_ensemble_features(dadj, x, 3, [0.5, 0.3, 0], "mean", reorder="community")
+    assert oracle.parity_ok(y_re.cpu().numpy(), y_host.cpu().numpy(), 1e-5)
+    assert torch.equal(nafs_ensemble_features(dadj, x, 3, [0.5, 0.3, 0], "mean", strict_order=True, reorder="community"),
+                       nafs_ensemble_features(dadj, x, 3, [0.5, 0.3, 0], "mean", strict_order=True))
     n, ptr, col, val = norm_graph(goldens, "pl256", r=0.5)
     csr = device_csr(ptr, col, val, (n, n), cuda)
     xd = torch.from_numpy(x).to(cuda)
