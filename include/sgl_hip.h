@@ -310,6 +310,21 @@ int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, floa
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);
 
+/* ---- device allocations with a stated physical placement (the tables the SpMM gathers from) ------------------------ */
+/* A random gather of 512-byte rows from a table of tens of GB is one address translation per row; how many of them the
+ * translation caches hold depends on the size of the physically contiguous, equally aligned ranges behind the table.
+ *   SGL_MEM_DEFAULT     hipMalloc
+ *   SGL_MEM_CONTIGUOUS  one physically contiguous range (hipExtMallocWithFlags(hipDeviceMallocContiguous))
+ *   SGL_MEM_VMM         physical chunks of chunk_bytes (0 = one chunk; rounded to the recommended granularity) mapped into one
+ *                       virtual range aligned to the chunk size (hipMemCreate / hipMemAddressReserve / hipMemMap)
+ * The pointer is an ordinary device pointer for every kernel and copy; release it with sgl_mem_free (which synchronises the
+ * device for SGL_MEM_VMM). */
+#define SGL_MEM_DEFAULT 0
+#define SGL_MEM_CONTIGUOUS 1
+#define SGL_MEM_VMM 2
+int sgl_mem_alloc(void **d_out, int64_t bytes, int mode, int64_t chunk_bytes);
+int sgl_mem_free(void *d_ptr);
+
 /* ---- memory-system probes (measurement only: the ceilings bench.py / tools/mem_ceilings.py quote next to the SpMM) ---- */
 /* sequential read of n_floats floats (16 B per lane); nothing is written (d_sink: one float, untouched in practice) */
 int sgl_probe_stream_f32(const float *d_x, int64_t n_floats, float *d_sink, void *stream);

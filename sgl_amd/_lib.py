@@ -18,6 +18,7 @@ SGL_CSR_STRICT_ORDER = 0x1
 SGL_CSR_NO_XCD_REMAP = 0x2
 SGL_REDUCE_SUM, SGL_REDUCE_MEAN, SGL_REDUCE_MAX, SGL_REDUCE_MIN, SGL_REDUCE_WSUM = 0, 1, 2, 3, 4
 SGL_MAX_HOPS = 64
+SGL_MEM_DEFAULT, SGL_MEM_CONTIGUOUS, SGL_MEM_VMM = 0, 1, 2
 
 _lib = None
 
@@ -92,6 +93,8 @@ PROTOTYPES = {
     "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_fill": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_features": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sgl_mem_alloc": (c_int, [POINTER(c_void_p), c_int64, c_int, c_int64]),
+    "sgl_mem_free": (c_int, [c_void_p]),
     "sgl_probe_stream_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sgl_probe_gather_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
 }

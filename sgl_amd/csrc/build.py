@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libsgl_hip.so")
-SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_probe.hip", "sgl_synth.hip", "sgl_exchange.hip", "sgl_reorder.hip"]
+SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_probe.hip", "sgl_synth.hip", "sgl_exchange.hip", "sgl_reorder.hip", "sgl_mem.hip"]
 HEADERS = ["sgl_common.h", os.path.join(ROOT, "include", "sgl_hip.h")]
 ARCH = "gfx950"
 FLAGS = [

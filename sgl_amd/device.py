@@ -14,6 +14,7 @@ from ._lib import check, current_stream_ptr, lib, ptr
 __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency",
+    "placed_empty", "MEM_MODES",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
 ]
 
@@ -70,6 +71,43 @@ def padded_parent(t):
     if ld == d:
         return t
     return torch.as_strided(t, (n, ld), (ld, 1), t.storage_offset())
+
+
+MEM_MODES = {"default": _lib.SGL_MEM_DEFAULT, "contiguous": _lib.SGL_MEM_CONTIGUOUS, "vmm": _lib.SGL_MEM_VMM}
+
+
+class _PlacedBlock:
+    """device memory from sgl_mem_alloc, exported to torch through __cuda_array_interface__; freed with the last tensor"""
+
+    def __init__(self, n_floats, mode, chunk_bytes, device):
+        self.device = torch.device(device)
+        self.n = int(n_floats)
+        p = c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().sgl_mem_alloc(ctypes.byref(p), self.n * 4, MEM_MODES[mode], int(chunk_bytes)), f"sgl_mem_alloc({mode})")
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "<f4", "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p:
+            try:
+                with torch.cuda.device(self.device):
+                    lib().sgl_mem_free(c_void_p(p))
+            except Exception:
+                pass
+
+
+def placed_empty(shape, device, mode="contiguous", chunk_bytes=0):
+    """float32 tensor of `shape` whose memory comes from sgl_mem_alloc with a stated physical placement (MEM_MODES).  For the
+    multi-GB feature replicas the SpMM gathers from: a physically contiguous table is translated through far fewer TLB entries
+    than whatever hipMalloc found free (profiles/r03_papers_tlb.md).  The block is released when the last view dies."""
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    blk = _PlacedBlock(max(n, 1), mode, chunk_bytes, device)
+    flat = torch.as_tensor(blk, device=blk.device)
+    return flat[:n].view(*shape)
 
 
 _STAGED_MIN_BYTES = 8 << 20     # below this a plain copy is as fast as the staging team
@@ -714,8 +752,9 @@ def nafs_aggregate(feats, return_weights=False):
     return (out, w) if return_weights else out
 
 
-def gather_rows(x, idx):
-    """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60)"""
+def gather_rows(x, idx, out=None):
+    """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60).  `out`: optional
+    preallocated [len(idx), d] destination (the pack step of the need-aware exchange re-uses one send buffer per hop)."""
     _check_mat(x, "x")
     n_rows, d = x.shape
     if not (torch.is_tensor(idx) and idx.is_cuda):
@@ -731,11 +770,18 @@ def gather_rows(x, idx):
         idx = torch.from_numpy(np.ascontiguousarray(host))
     # device indices are range-checked inside the kernel (it traps on a bad index): no host round trip
     idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
-    out = alloc_rows(idx.numel(), d, x.device)
+    if out is None:
+        out = alloc_rows(idx.numel(), d, x.device)
+    else:
+        _check_mat(out, "out")
+        if out.shape != (idx.numel(), d):
+            raise ValueError("gather_rows: `out` must be [len(idx), d]")
+    if idx.numel() == 0:
+        return out
     # copy whole 16-byte lanes for any d: the source row's padding is readable and the destination's padding is ours
     dp = round_up(d, 4)
     d_copy = dp if (d != dp and n_rows > 1 and idx.numel() > 1 and x.stride(0) % 4 == 0 and x.stride(0) >= dp
-                    and out.stride(0) >= dp and x.data_ptr() % 16 == 0) else d
+                    and out.stride(0) >= dp and out.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0) else d
     with torch.cuda.device(x.device):
         check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d_copy,
                                         current_stream_ptr()), "sgl_gather_rows_f32")

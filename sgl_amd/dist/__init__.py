@@ -29,9 +29,10 @@ from .layout import (GridLayout, all_piece_bounds, balanced_bounds, column_chunk
 from .propagator import ShardedPropagator
 from .sharded_adj import (RowBlock, allgather_blocks, allgather_rows, balanced_bounds_device, block_piece_spmms, canonicalize_block,
                           exchange_checksums, gather_piece_bounds, local_piece_bounds, scatter_row_blocks)
+from .halo import HaloPlan, HaloPropagator, halo_checksums
 from .graph_op import ShardedGraphOp
 
 __all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "tapered_weights", "device_piece_spmms", "column_chunks",
            "column_slices", "GridLayout", "ShardedPropagator", "ShardedGraphOp", "RowBlock", "scatter_row_blocks",
            "block_piece_spmms", "gather_piece_bounds", "local_piece_bounds", "allgather_blocks", "allgather_rows",
-           "balanced_bounds_device", "exchange_checksums", "canonicalize_block"]
+           "balanced_bounds_device", "exchange_checksums", "canonicalize_block", "HaloPlan", "HaloPropagator", "halo_checksums"]

@@ -192,3 +192,85 @@ def test_grid_layout_arithmetic():
             sl = column_slices(d, parts)
             assert len(sl) == parts and sl[0][0] == 0 and sl[-1][1] == d and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
             assert max(-(-(b - a) // 32) for a, b in sl) == -(-(-(-d // parts)) // 32) or parts > -(-d // 32)
+
+
+def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
+    """need-aware exchange: compact tables [own rows | ghosts per peer], relabelled columns, packed sends.  Every hop must be
+    bit-equal to the single-process chain, ghosts must equal the owners' rows, and the exchanged volume must be what the
+    plan says (rows nobody gathers never travel)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle
+    from inputs import hash_matrix
+    from sgl_amd.dist import HaloPlan, HaloPropagator, balanced_bounds, halo_checksums
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "graphs.npz")))
+        indptr, indices, data = g[graph + "|indptr"], g[graph + "|indices"], g[graph + "|data"]
+        n = len(indptr) - 1
+        ptr, col, val = oracle.sym_norm_csr(indptr, indices, data, n, 0.5)
+        val = val.astype(np.float32)
+        bounds = np.asarray(bounds_override, dtype=np.int64) if bounds_override is not None else balanced_bounds(ptr, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        nb, ne = int(ptr[lo]), int(ptr[hi])
+        rp = (ptr[lo:hi + 1] - ptr[lo]).astype(np.int64)
+        c_glob = torch.from_numpy(col[nb:ne].astype(np.int32))
+        plan = HaloPlan(lo, hi, n, c_glob, bounds)
+        c_comp = plan.relabel(c_glob).numpy()
+        v = val[nb:ne]
+
+        def spmm(x, out):
+            out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c_comp, v, x.numpy(), n_rows=hi - lo)))
+
+        prop = HaloPropagator(plan, spmm)
+        x = torch.from_numpy(hash_matrix(n, d, seed=7))
+        ref = oracle.propagate((ptr, col, val), x.numpy(), K)
+        ok = plan.n_compact == plan.n_own + plan.n_ghost and plan.n_ghost <= n - plan.n_own
+        # the plan is exact: ghosts == the distinct foreign columns of my block
+        foreign = np.unique(col[nb:ne][(col[nb:ne] < lo) | (col[nb:ne] >= hi)])
+        ok = ok and plan.n_ghost == len(foreign) and np.array_equal(plan.global_ids.numpy()[plan.n_own:], foreign)
+        # hop 0 from my OWN rows only (ghosts fetched) == cut out of the full matrix
+        t_own = prop.table_from_own(x[lo:hi].contiguous())
+        t_full = prop.table_from_full(x)
+        ok = ok and torch.equal(t_own, t_full) and torch.equal(t_full, x[plan.global_ids])
+        for in_place in (False, True):
+            hops = prop.propagate(t_own.clone(), K, in_place=in_place)
+            ok = ok and len(hops) == K + 1 and np.array_equal(hops[K].numpy(), ref[K][lo:hi])
+            if not in_place:
+                ok = ok and all(np.array_equal(hops[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        # column chunks, software-pipelined, with caller-owned tables: the ghosts of the last exchanged hop are the owners' rows
+        chunks = [(0, 3), (3, d)]
+        tabs = [t_own[:, a:b].contiguous() for a, b in chunks]
+        bufs = [[torch.empty_like(t) for _ in range(2)] for t in tabs]
+        hc = prop.propagate_chunked(tabs, K, buffers=bufs)
+        for h in range(K + 1):
+            ok = ok and np.array_equal(torch.cat(hc[h], 1).numpy(), ref[h][lo:hi])
+        if K >= 2:
+            for ci, (a, b) in enumerate(chunks):
+                last_table = bufs[ci][(K - 2) % 2]
+                ok = ok and np.array_equal(last_table.numpy(), ref[K - 1][plan.global_ids.numpy(), a:b])
+                ok = ok and halo_checksums(plan, last_table, hc[K - 1][ci])
+            bad = bufs[0][(K - 2) % 2].clone()
+            if plan.n_ghost:
+                bad[plan.n_own, 0] += 1.0
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(halo_checksums(plan, bad, hc[K - 1][0])))
+            ok = ok and (flags[rank] == (plan.n_ghost == 0))
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write("ok" if ok else "mismatch")
+        with open(os.path.join(out_dir, f"skip{rank}.txt"), "w") as f:
+            f.write(repr(plan.describe()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,graph,bounds", [
+    (2, 3, "pl2000", None), (3, 2, "pl2000", None), (4, 3, "pl2000", None), (8, 2, "pl2000", None),
+    (3, 3, "dir40", [0, 0, 25, 40]),          # an empty block: its rank packs nothing, gathers nothing, still takes part
+    (4, 1, "dir40", None), (2, 0, "dir40", None)])
+def test_halo_exchange_matches_single_process(tmp_path, world, K, graph, bounds):
+    port = _free_port()
+    mp.spawn(_halo_worker, args=(world, port, K, 9, str(tmp_path), graph, bounds), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
