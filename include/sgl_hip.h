@@ -195,6 +195,13 @@ int sgl_csr_set_rowmap(sgl_csr_t *csr, const int32_t *d_rowmap, void *stream);
  * blocks, all xGMI links at once.  RCCL is resolved at run time from the host process (else librccl.so is loaded);
  * SGL_ERR_UNSUPPORTED if there is none.  world == 1 is a no-op.  sgl_exchange_backend() says which RCCL was found. */
 int sgl_allgather_rows(void *nccl_comm, int rank, int world, const int64_t *h_bounds, float *d_x, int64_t ldx, void *stream);
+/* Need-aware form (the plan: sgl_amd/dist/halo.py): a rank receives only the rows its block gathers, packed.  d_send holds the
+ * rows of this rank that the peers gather, peer q's share at rows [h_send_off[q], h_send_off[q+1]) (packed by
+ * sgl_gather_rows_f32 with the rank's send list); the rows of peer q that this rank gathers land at rows
+ * [h_recv_off[q], h_recv_off[q+1]) of d_recv (the ghost range of its compact table).  Offsets are host arrays of world + 1
+ * rows, a rank's own entry is empty, ld = floats per row of both buffers.  Same transport and error behaviour as above. */
+int sgl_exchange_rows(void *nccl_comm, int rank, int world, const float *d_send, const int64_t *h_send_off, float *d_recv,
+                      const int64_t *h_recv_off, int64_t ld, void *stream);
 const char *sgl_exchange_backend(void);
 
 /* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */

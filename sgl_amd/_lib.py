@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sgl_spmm_acc_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_int,
                                  c_float, c_void_p]),
     "sgl_allgather_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sgl_exchange_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_exchange_backend": (c_char_p, []),
     "FloatCSRMulDenseOMP": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "FloatCSRMulDense": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),

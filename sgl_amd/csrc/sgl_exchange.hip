@@ -87,6 +87,44 @@ SGL_EXPORT int sgl_allgather_rows(void *nccl_comm, int rank, int world, const in
     return SGL_OK;
 }
 
+// Need-aware form of the same exchange (sgl_amd/dist/halo.py is the plan that produces the offsets): the rows of this rank
+// that peer q gathers were packed into d_send (sgl_gather_rows_f32 with the rank's send list), q's share at rows
+// [h_send_off[q], h_send_off[q+1]); the rows of peer q this rank gathers land packed at rows [h_recv_off[q], h_recv_off[q+1])
+// of d_recv -- the ghost range of the rank's compact table.  One grouped batch, every link busy in both directions.
+SGL_EXPORT int sgl_exchange_rows(void *nccl_comm, int rank, int world, const float *d_send, const int64_t *h_send_off,
+                                 float *d_recv, const int64_t *h_recv_off, int64_t ld, void *stream) {
+    SGL_REQUIRE(world >= 1 && rank >= 0 && rank < world && h_send_off && h_recv_off, "sgl_exchange_rows: bad rank / world / offsets");
+    SGL_REQUIRE(ld >= 0, "sgl_exchange_rows: bad leading dimension");
+    for (int q = 0; q < world; ++q)
+        SGL_REQUIRE(h_send_off[q] <= h_send_off[q + 1] && h_recv_off[q] <= h_recv_off[q + 1] && h_send_off[0] >= 0 && h_recv_off[0] >= 0,
+                    "sgl_exchange_rows: offsets must not decrease");
+    SGL_REQUIRE(h_send_off[rank] == h_send_off[rank + 1] && h_recv_off[rank] == h_recv_off[rank + 1],
+                "sgl_exchange_rows: a rank exchanges nothing with itself");
+    if (world == 1 || ld == 0) return SGL_OK;
+    const bool any_send = h_send_off[world] > h_send_off[0], any_recv = h_recv_off[world] > h_recv_off[0];
+    SGL_REQUIRE(nccl_comm != nullptr && (!any_send || d_send) && (!any_recv || d_recv), "sgl_exchange_rows: NULL buffer or communicator");
+    Rccl &r = rccl();
+    if (!r.send || !r.recv || !r.group_start || !r.group_end)
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_exchange_rows: no RCCL in this process (ncclSend / ncclRecv not found)");
+    hipStream_t st = sgl::as_stream(stream);
+    auto fail = [&](int rc, const char *what) {
+        return sgl::fail(rc, "sgl_exchange_rows: %s failed: %s", what, r.errstr ? r.errstr(rc) : "RCCL error");
+    };
+    int rc = r.group_start();
+    if (rc != 0) return fail(rc, "ncclGroupStart");
+    for (int k = 1; k < world && rc == 0; ++k) {
+        const int dst = (rank + k) % world, src = (rank - k + world) % world;
+        const size_t out = (size_t)(h_send_off[dst + 1] - h_send_off[dst]) * (size_t)ld;
+        const size_t in = (size_t)(h_recv_off[src + 1] - h_recv_off[src]) * (size_t)ld;
+        if (out) rc = r.send(d_send + h_send_off[dst] * ld, out, kNcclFloat32, dst, nccl_comm, st);
+        if (rc == 0 && in) rc = r.recv(d_recv + h_recv_off[src] * ld, in, kNcclFloat32, src, nccl_comm, st);
+    }
+    const int rc_end = r.group_end();
+    if (rc != 0) return fail(rc, "ncclSend / ncclRecv");
+    if (rc_end != 0) return fail(rc_end, "ncclGroupEnd");
+    return SGL_OK;
+}
+
 // which RCCL the exchange resolved to: "process" (symbols the host already had), "librccl.so" (loaded here) or "" (none)
 SGL_EXPORT const char *sgl_exchange_backend(void) {
     Rccl &r = rccl();

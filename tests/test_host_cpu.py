@@ -327,6 +327,30 @@ def test_exchange_entry_point_argument_contract():
     assert lib.sgl_allgather_rows(None, 0, 2, b3, None, 16, None) != 0      # NULL matrix / communicator
     assert isinstance(lib.sgl_exchange_backend(), bytes)
 
+    # the need-aware form: same contract
+    so, ro = (ctypes.c_int64 * 2)(0, 0), (ctypes.c_int64 * 2)(5, 5)
+    assert lib.sgl_exchange_rows(None, 0, 1, None, so, None, ro, 16, None) == 0
+    so3, ro3 = (ctypes.c_int64 * 3)(0, 0, 4), (ctypes.c_int64 * 3)(5, 5, 9)
+    assert lib.sgl_exchange_rows(None, 0, 2, None, so3, None, ro3, 16, None) != 0      # NULL buffers / communicator
+    assert lib.sgl_exchange_rows(None, 2, 2, None, so3, None, ro3, 16, None) != 0 and "rank" in _lib.last_error()
+
+
+def test_multi_peer_exchange_against_a_mock_rccl(tmp_path):
+    """sgl_allgather_rows / sgl_exchange_rows with 2..8 ranks and no GPU: tests/native/exchange_mock.cpp exports a mock RCCL
+    (mailboxes + memcpy) that the library resolves through its dlsym(RTLD_DEFAULT) path, and drives one host thread per rank:
+    grouped send / recv loop, peer staggering, offsets, unequal and empty blocks, packed ghost ranges, error propagation."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path / "exchange_mock")
+    r = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-rdynamic", os.path.join(ROOT, "tests", "native", "exchange_mock.cpp"),
+                        "-ldl", "-pthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "exchange_mock: OK (42 multi-rank cases" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
 
 def test_community_order_on_cpu_tensors():
     """sgl_amd.reorder.community_order_reference (the tensor-code statement of sgl_reorder_community): on a small
