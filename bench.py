@@ -233,6 +233,20 @@ class GpuEngine:
         from sgl_amd.dist import block_piece_spmms
         return block_piece_spmms(blk, pieces, weights, strict=args.strict)
 
+    def block_halo(self, args, blk, bounds):
+        """need-aware exchange of the row-sharded layout (sgl_amd/dist/halo.py): plan, propagator on compact tables and the
+        block with its columns relabelled to the compact table (for the sampled-row check)"""
+        from sgl_amd.dist import RowBlock
+        from sgl_amd.dist.halo import block_halo
+        plan, prop, handle = block_halo(blk, bounds, strict=args.strict)
+        cblk = RowBlock(blk.lo, blk.hi, plan.n_compact, blk.rowptr, handle.col if handle is not None else blk.col, blk.val)
+        return plan, prop, cblk
+
+    def feature_rows(self, args, wl, lo, hi):
+        """rows [lo, hi) of a hashed workload's feature matrix (a rank of the need-aware layout generates only its own)"""
+        from sgl_amd import synthetic
+        return synthetic.hashed_features_torch(args.seed, lo, hi - lo, wl["d"], device=self.device)
+
     def gather_ceiling(self, col, x, d, max_idx=64 << 20):
         """What the memory system gives the bare access pattern of this workload (sgl_probe_gather_f32: whole-row gathers
         at the workload's own column ids, row width and pitch; no CSR stream, no arithmetic, no stores): the ceiling the
@@ -353,17 +367,19 @@ def parse_args(argv=None):
                     help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
-    ap.add_argument("--exchange", choices=("auto", "p2p", "allgather", "push"),
+    ap.add_argument("--exchange", choices=("auto", "halo", "p2p", "allgather", "push"),
                     default=os.environ.get("SGL_BENCH_EXCHANGE", "auto"),
-                    help="N>1 transport: grouped RCCL send/recv (p2p), RCCL all-gather on padded pieces (allgather), "
-                         "auto = time both during setup and keep the faster, or push = stores into peer replicas from "
-                         "the SpMM kernel through torch symmetric memory (opt-in; falls back to p2p if unavailable)")
-    ap.add_argument("--layout", choices=("auto", "rows", "cols", "grid", "all"), default=os.environ.get("SGL_BENCH_LAYOUT", "auto"),
-                    help="N>1: rows = A_hat row-sharded in storage + per-hop all-gather (the contract layout, always built "
-                         "and reported); cols = feature-sharded (A_hat replicated, each GPU runs the whole chain on d/N "
-                         "columns, no communication); grid = 2 row blocks x N/2 column slices, pair exchange relayed over "
-                         "all links; auto = rows + ONE alternative (cols up to 4 ranks, grid from 8), the faster runs; "
-                         "all = every layout")
+                    help="N>1 transport of the per-hop all-gather: halo = need-aware (a rank receives only the rows its block "
+                         "gathers, packed into a compact table; sgl_amd/dist/halo.py), p2p = every row to every rank by grouped "
+                         "RCCL send/recv, allgather = RCCL all-gather on padded pieces, auto = time one hop's exchange with each "
+                         "during setup and keep the fastest, push = stores into peer replicas from the SpMM kernel (opt-in)")
+    ap.add_argument("--layout", choices=("rows", "auto", "cols", "grid", "all"), default=os.environ.get("SGL_BENCH_LAYOUT", "rows"),
+                    help="N>1: rows (default) = A_hat row-sharded in storage + per-hop all-gather: the contract layout, the only "
+                         "one whose figure is `value` unless another is asked for.  Alternatives that REPLICATE A_hat, opt-in: "
+                         "cols = feature-sharded (each GPU runs the whole chain on d/N columns, no communication); grid = 2 row "
+                         "blocks x N/2 column slices, pair exchange relayed over all links; auto = rows + ONE alternative (cols "
+                         "up to 4 ranks, grid from 8), the faster runs and the other is listed under plan.alternatives; all = "
+                         "every layout")
     ap.add_argument("--grid-pieces", default="4",
                     help="row pieces per rank of the grid layout; a comma list is tried and the fastest count kept")
     ap.add_argument("--setup-budget", type=float, default=float(os.environ.get("SGL_BENCH_SETUP_BUDGET", "120")),
@@ -628,11 +644,16 @@ def _build_grid(job, ref, row_groups):
                         f"{job.world} ranks, {pieces} row pieces"}
 
 
-def _select_exchange(job, prop, handles, x_chunks, cbufs):
-    """row-sharded layout: pick the transport of the per-hop all-gather.  auto = time one hop's exchange with each
-    process-group transport (decision on the MAX over ranks, so every rank picks the same); the fused push transport is
-    an opt-in third candidate that must map all peers, reproduce the process-group result and be >= 3 % faster."""
+def _select_exchange(job, full, halo):
+    """row-sharded layout: pick the transport of the per-hop all-gather.  auto = time one hop's exchange with every candidate --
+    the need-aware packed exchange (halo: pack kernel + grouped send/recv of the rows each peer gathers) and the full-replica
+    process-group transports (p2p, allgather) -- and keep the fastest (decision on the MAX over ranks, so every rank picks the
+    same); the fused push transport is an opt-in further candidate that must map all peers, reproduce the process-group result
+    and be >= 3 % faster."""
     args, engine, info, K, device = job.args, job.engine, job.info, job.K, job.device
+    if full is None:
+        return "halo"
+    prop, handles, x_chunks, cbufs = full["prop"], full["handles"], full["x_chunks"], full["cbufs"]
 
     def setup_push():
         """collective; returns True iff every rank mapped every peer's replicas"""
@@ -659,11 +680,13 @@ def _select_exchange(job, prop, handles, x_chunks, cbufs):
     for tname in transports:
         prop.transport = tname
         cand[tname] = job.timed_s(lambda: prop.exchange_only(ys0, [b[0] for b in cbufs]))
+    if halo is not None:
+        hp = halo["prop"]
+        cand["halo"] = job.timed_s(lambda: hp.exchange_only(ys0, [b[0] for b in halo["bufs"]]))
     exchange = min(cand, key=cand.get)
     info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
-    # opt-in (SGL_BENCH_TRY_PUSH=1): a fault in a peer store would take the whole job down, and at every N the other
-    # layouts beat what a row-sharded exchange can reach over one link per peer
-    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles:
+    # opt-in (SGL_BENCH_TRY_PUSH=1): a fault in a peer store would take the whole job down
+    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles or exchange == "halo":
         return exchange
     prop.transport = exchange
     if not setup_push():
@@ -678,32 +701,102 @@ def _select_exchange(job, prop, handles, x_chunks, cbufs):
     if not prop.agree(same, device):
         info["push_rejected"] = "result mismatch"
         return exchange
-    full = {exchange: job.timed_s(lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
-            "push": job.timed_s(lambda: prop.propagate_push(x_chunks, K))}
-    info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in full.items()}
-    return "push" if full["push"] < 0.97 * full[exchange] else exchange
+    fullt = {exchange: job.timed_s(lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
+             "push": job.timed_s(lambda: prop.propagate_push(x_chunks, K))}
+    info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in fullt.items()}
+    return "push" if fullt["push"] < 0.97 * fullt[exchange] else exchange
 
 
-def _build_rows(job, ref=None):
-    """The contract layout: A_hat row-sharded IN STORAGE (every rank multiplies the block it alone holds) + per-hop
-    all-gather, row pieces x column chunks software-pipelined.  Validated without any replica of A_hat: the exchanged
-    feature replicas by exact bit-checksums, the local SpMM by sampled rows recomputed in fp64."""
-    from sgl_amd.dist import ShardedPropagator, column_chunks, exchange_checksums, gather_piece_bounds
+def _rows_full_replica(job, chunks):
+    """row-sharded layout on full feature replicas: every rank's new rows go to every rank"""
+    from sgl_amd.dist import ShardedPropagator, gather_piece_bounds
     args, K, x0, blk = job.args, job.K, job.x0, job.block
     pieces, handles, mine = job.engine.block_piece_spmms(args, blk, args.pieces)
     pb = gather_piece_bounds(mine) if job.world > 1 else np.asarray([[int(v) for v in mine]], dtype=np.int64)
     prop = ShardedPropagator(pieces, pb, job.rank, job.world, job.n)
-    chunks = column_chunks(job.d, args.col_chunks)
-    job.info.update({"row_pieces": args.pieces, "col_chunks": chunks})
     # column chunks live as separate contiguous matrices: whole cache lines per gathered chunk row
     x_chunks = [x0] if len(chunks) == 1 else [x0[:, a:b].contiguous() for a, b in chunks]
     cbufs = [[torch.empty_like(xc) for _ in range(job.nbuf)] for xc in x_chunks]
     ybufs = [[torch.empty((prop.hi - prop.lo, xc.shape[1]), dtype=xc.dtype, device=xc.device) for _ in range(K)]
              for xc in x_chunks]
-    exchange = _select_exchange(job, prop, handles, x_chunks, cbufs)
+    return {"prop": prop, "handles": handles, "x_chunks": x_chunks, "cbufs": cbufs, "ybufs": ybufs,
+            "bounds": [int(v) for v in pb[:, 0]] + [int(pb[-1, -1])]}
+
+
+def _rows_halo(job, chunks):
+    """row-sharded layout on compact tables: a rank holds its own rows and the rows of each peer its block gathers, and receives
+    only those between hops"""
+    K, x0, blk = job.K, job.x0, job.block
+    bounds = [int(v) for v in job.bounds]
+    plan, prop, cblk = job.engine.block_halo(job.args, blk, bounds)
+    t0 = prop.table_from_full(x0)                            # every rank of the bench holds x0; a real job passes its own rows
+    tables = [t0] if len(chunks) == 1 else [t0[:, a:b].contiguous() for a, b in chunks]
+    if len(chunks) > 1:
+        del t0
+    bufs = [[torch.empty_like(t) for _ in range(job.nbuf)] for t in tables]
+    ybufs = [[torch.empty((plan.n_own, t.shape[1]), dtype=t.dtype, device=t.device) for _ in range(K)] for t in tables]
+    return {"plan": plan, "prop": prop, "cblk": cblk, "tables": tables, "bufs": bufs, "ybufs": ybufs}
+
+
+def _build_rows(job, ref=None):
+    """The contract layout: A_hat row-sharded IN STORAGE (every rank multiplies the block it alone holds) + per-hop
+    all-gather -- need-aware (halo) or of the full replica --, column chunks software-pipelined across hops.  Validated
+    without any replica of A_hat: the exchanged rows by exact bit-checksums, the local SpMM by sampled rows recomputed in fp64."""
+    from sgl_amd.dist import column_chunks, exchange_checksums, halo_checksums
+    args, K, blk = job.args, job.K, job.block
+    chunks = column_chunks(job.d, args.col_chunks)
+    job.info.update({"row_pieces": args.pieces, "col_chunks": chunks})
+    can_halo = job.world > 1 and job.nbuf > 0 and getattr(job.engine, "block_halo", None) is not None
+    want = args.exchange
+    full = halo = None
+    if want != "halo" or not can_halo:
+        full = _rows_full_replica(job, chunks)
+    if can_halo and want in ("auto", "halo"):
+        halo = _rows_halo(job, chunks)
+    exchange = _select_exchange(job, full, halo)
+    job.info["exchange"] = exchange
+    check_fn = getattr(job.engine, "sampled_rows_check", None)
+    if exchange == "halo":
+        full = None                                           # the replicas of the other candidate are released
+        plan, prop, cblk, tables, hbufs, ybufs = (halo[k] for k in ("plan", "prop", "cblk", "tables", "bufs", "ybufs"))
+        frac = torch.tensor([plan.skipped_fraction, float(plan.n_ghost)], dtype=torch.float64, device=job.device)
+        if job.world > 1:
+            import torch.distributed as dist
+            mx = frac.clone()
+            dist.all_reduce(frac)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            frac /= job.world
+        else:
+            mx = frac
+        job.info["halo"] = dict(plan.describe(), exchange_skipped_fraction_mean=round(float(frac[0]), 4),
+                                ghost_rows_max_rank=int(mx[1]))
+        job.rows_inbound_bytes = float(mx[1]) * job.d * 4
+
+        def step():
+            return prop.propagate_chunked(tables, K, buffers=hbufs, y_buffers=ybufs)
+
+        def check():
+            hops = step()
+            job.engine.sync()
+            ok = True
+            for c in range(len(tables)):
+                t_prev = tables[c] if K == 1 else hbufs[c][(K - 2) % job.nbuf]
+                if K >= 2:                                    # the ghosts of hop K-1 are the owners' rows, bit for bit
+                    ok = ok and halo_checksums(plan, t_prev, hops[K - 1][c])
+                if check_fn is not None:
+                    ok = ok and check_fn(cblk, t_prev, hops[K][c])
+            if ref is not None:
+                ok = ok and all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(hops[K], chunks))
+            return ok
+        return {"step": step, "check": check, "halves": (prop, tables, hbufs),
+                "describe": f"row-sharded x{job.world} (A_hat stored as one row block per GPU) + per-hop need-aware all-gather "
+                            f"(halo: {plan.n_ghost} of {plan.rows_in_full} foreign rows gathered on rank 0, packed), "
+                            f"{len(chunks)} column chunks pipelined across hops"}
+    halo = None
+    prop, x_chunks, cbufs, ybufs, bounds = (full[k] for k in ("prop", "x_chunks", "cbufs", "ybufs", "bounds"))
+    x0 = job.x0
     if exchange in ("p2p", "allgather", "staged"):
         prop.transport = exchange
-    job.info["exchange"] = exchange
     if exchange == "push":
         def step():
             return prop.propagate_push(x_chunks, K)
@@ -713,9 +806,6 @@ def _build_rows(job, ref=None):
     else:
         def step():
             return prop.propagate_chunked(x_chunks, K, buffers=cbufs, y_buffers=ybufs)
-
-    bounds = [int(v) for v in pb[:, 0]] + [int(pb[-1, -1])]
-    check_fn = getattr(job.engine, "sampled_rows_check", None)
 
     def check():
         hops = step()
@@ -817,7 +907,9 @@ def _select_layout(job):
     if "rows" in timing:
         info["rows"] = {"ms_per_step": round(timing["rows"] * 1e3, 3),
                         "value": job.nnz * job.d * job.K / timing["rows"], "unit": "edge\u00b7featdim/s",
-                        "parallelism": cands["rows"]["describe"]}
+                        "parallelism": cands["rows"]["describe"], "exchange": info.get("exchange"),
+                        "exchange_skipped_fraction": (info.get("halo") or {}).get("exchange_skipped_fraction_mean", 0.0)}
+    info["alternatives"] = {k: round(v * 1e3, 3) for k, v in timing.items() if k != "rows"}
     info["parallelism"] = cands[chosen]["describe"] + ("" if chosen == "rows" else " [contract layout rows: see plan.rows]")
     halves = {name: c["halves"] for name, c in cands.items() if "halves" in c}
     if chosen == "rows":
@@ -875,10 +967,14 @@ def _diagnostics(job, halves):
     achieved rate per link; grid layout: the same two halves of the relayed exchange (every byte crosses two links)."""
     diag = None
     if "rows" in halves and job.nbuf > 0:
-        inbound = (job.world - 1) / job.world * job.n * job.d * 4
+        inbound = getattr(job, "rows_inbound_bytes", None) or (job.world - 1) / job.world * job.n * job.d * 4
         diag = _hop_halves(job, *halves["rows"], inbound)
         ms = diag["exchange_only_ms_per_hop_max_rank"]
-        diag["exchange_GBps_per_link"] = (inbound / (job.world - 1) / (ms * 1e-3) / 1e9) if ms > 0 else None
+        diag["exchange_GBps_per_link"] = (inbound / max(job.world - 1, 1) / (ms * 1e-3) / 1e9) if ms > 0 else None
+        prop = halves["rows"][0]
+        if hasattr(prop, "pack_only"):                        # need-aware exchange: the pack kernel alone (inside exchange_only too)
+            ys = prop.spmm_only(halves["rows"][1])
+            diag["pack_only_ms_per_hop_max_rank"] = job.timed_s(lambda: prop.pack_only(ys), reps=3) * 1e3
     if "grid" in halves and job.nbuf > 0:
         prop, x_chunks, cbufs = halves["grid"]
         inbound = (prop.world - 1) / prop.world * job.n * x_chunks[0].shape[1] * 4
@@ -936,6 +1032,8 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
     t0 = time.perf_counter()
     bounds, nnz = engine.hashed_bounds(args, wl, world)
     blk = engine.hashed_block(args, wl, int(bounds[rank]), int(bounds[rank + 1]))
+    if exchange == "halo" and world > 1 and getattr(engine, "block_halo", None) is not None:
+        return _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0)
     x0 = engine.features(args, wl)
     pieces, handles, mine = engine.block_piece_spmms(args, blk, args.pieces)
     pb = gather_piece_bounds(mine) if world > 1 else np.asarray([[int(v) for v in mine]], dtype=np.int64)
@@ -1004,6 +1102,75 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
                            f"{args.pieces} row pieces x {len(x_chunks)} column chunks pipelined across hops, "
                            f"{inbound / 1e9:.1f} GB in-bound per rank per hop",
             "hops_retained": "last only (hop shards are written into the next replica in place)",
+            "setup_s": round(time.perf_counter() - t0 - elapsed * (steps + 1) / steps, 2)}
+
+
+def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0):
+    """papers100M-shaped section with the need-aware exchange: no rank ever holds the 57 GB feature matrix -- it generates its
+    OWN feature rows, fetches the rows its block gathers from their owners (the same exchange that runs between hops) and keeps
+    compact tables [own rows | ghosts per peer]; k hops in place, only the last retained."""
+    import torch.distributed as dist
+    from sgl_amd.dist import column_chunks, halo_checksums
+    n, d, K = wl["n"], wl["d"], wl["k"]
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    plan, prop, cblk = engine.block_halo(args, blk, [int(b) for b in bounds])
+    x_own = engine.feature_rows(args, wl, lo, hi)
+    chunks = column_chunks(d, args.col_chunks)
+    tables = [prop.table_from_own(x_own if len(chunks) == 1 else x_own[:, a:b].contiguous(), key=("init", c))
+              for c, (a, b) in enumerate(chunks)]
+    del x_own
+    prop._send.clear()
+    bufs = [[torch.empty_like(t) for _ in range(2)] for t in tables]
+    ylast = [b[(K - 1) % 2][:plan.n_own] for b in bufs]
+
+    def step():
+        return prop.propagate_chunked(tables, K, buffers=bufs, y_buffers=[[None] * (K - 1) + [yl] for yl in ylast], in_place=True)
+
+    def sync_all():
+        engine.sync()
+        dist.barrier()
+        engine.sync()
+
+    hops = step()                                             # warm-up + validation
+    sync_all()
+    ok = True
+    for c in range(len(tables)):
+        t_prev = bufs[c][(K - 2) % 2] if K >= 2 else tables[c]
+        if K >= 2:
+            ok = ok and halo_checksums(plan, t_prev, t_prev[:plan.n_own])
+        ok = ok and engine.sampled_rows_check(cblk, t_prev, hops[K][c])
+    dev_ = tables[0].device
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev_)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    stats = torch.tensor([float(plan.n_ghost), plan.skipped_fraction], dtype=torch.float64, device=dev_)
+    mx = stats.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(stats)
+    steps = 2
+    sync_all()
+    t_a = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    el = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev_)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    hop_s = elapsed / (K * steps)
+    alg = algorithmic_bytes_per_hop(n, nnz, d) / world
+    inbound = float(mx[0]) * d * 4
+    return {"workload": workload_text("S3_papers", K), "n_nodes": n, "nnz": nnz, "feat_dim": d, "prop_steps": K,
+            "n_gpus": world, "steps": steps, "validated": bool(flag.item()),
+            "value": nnz * d * K * steps / elapsed, "unit": "edge\u00b7featdim/s", "ms_per_step": elapsed * 1e3 / steps,
+            "ms_per_hop": hop_s * 1e3,
+            "roofline": {"bound": "hbm", "achieved": alg / hop_s / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
+                         "frac": alg / hop_s / HBM_PEAK_BYTES, "algorithmic_bytes_per_launch": alg,
+                         "note": "per-GPU share of one hop / wall time per hop (pack kernel and exchange are inside that time)"},
+            "parallelism": f"row-sharded x{world} (A_hat stored as one row block per GPU) + per-hop need-aware all-gather (halo), "
+                           f"{len(chunks)} column chunks pipelined across hops, {inbound / 1e9:.1f} GB in-bound per rank per hop "
+                           f"(a full all-gather: {(world - 1) / world * n * d * 4 / 1e9:.1f} GB)",
+            "halo": dict(plan.describe(), exchange_skipped_fraction_mean=round(float(stats[1]) / world, 4),
+                         ghost_rows_max_rank=int(mx[0])),
+            "hops_retained": "last only (hop shards are written into the next table in place)",
             "setup_s": round(time.perf_counter() - t0 - elapsed * (steps + 1) / steps, 2)}
 
 

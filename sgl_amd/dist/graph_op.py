@@ -61,21 +61,28 @@ class ShardedGraphOp:
             rowptr, col, val = dev.normalize_block(blk.rowptr, blk.col, blk.val, blk.lo, blk.n, self.r, self.alpha,
                                                    symmetric=self.symmetric, group=self.group)
             nblk = RowBlock(blk.lo, blk.hi, blk.n, rowptr, col, val)
-            fns, handles, mine = block_piece_spmms(nblk, self.pieces, strict=self.strict_order)
-            pb = gather_piece_bounds(mine, self.group)
-            self._cache = (key, fns, pb, handles)
+            self._cache = [key, None, None, None]
             self._cache_ident = AdjIdentity(blk)
             self._props = {}
             self.a_hat_block = nblk
-        _, fns, pb, handles = self._cache
         n = blk.n
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
         x = x.to(device=blk.device, dtype=torch.float32)
+        transport = self.transport or ("halo" if world > 1 else "p2p")
+        if transport == "halo":
+            if self._cache[2] is None:                       # only the ranks' block boundaries are needed
+                self._cache[2] = gather_piece_bounds([blk.lo, blk.hi], self.group)
+            return self._propagate_halo(x, self._cache[2], rank, world)
+        if self._cache[1] is None:                           # full-replica transports: SpMM handles on global column ids
+            fns, handles, mine = block_piece_spmms(self.a_hat_block, self.pieces, strict=self.strict_order)
+            self._cache[1:] = [fns, gather_piece_bounds(mine, self.group), handles]
+        _, fns, pb, handles = self._cache
         if x.shape[0] == blk.n_local and x.shape[0] != n:
             x = allgather_rows(x.contiguous(), pb[:, 0].tolist() + [int(pb[-1, -1])], n, group=self.group)
         if x.shape[0] != n:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
-        transport = self.transport or ("staged" if world > 1 and self._gloo() and x.is_cuda else "p2p")
+        if transport == "p2p" and world > 1 and self._gloo() and x.is_cuda:
+            transport = "staged"
         prop = self._props.get(("rows", transport))
         if prop is None:
             prop = self._props[("rows", transport)] = ShardedPropagator(fns, pb, rank, world, n, group=self.group,
@@ -87,6 +94,32 @@ class ShardedGraphOp:
         if len(chunks) == 1:
             return prop.propagate(x, self.prop_steps)
         hops = prop.propagate_chunked([x[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+        return [torch.cat(h, dim=1) for h in hops]
+
+    def _propagate_halo(self, x, pb, rank, world):
+        """need-aware exchange (the default of the row-sharded storage path with several ranks): this rank gathers from a
+        compact table [own rows | the rows of each peer its block references] and receives only those rows between hops
+        (sgl_amd/dist/halo.py).  `x` may be the full matrix or just this rank's rows -- a rank never needs more than its own."""
+        from .halo import block_halo
+        blk = self.a_hat_block
+        halo = self._props.get("halo")
+        if halo is None:
+            bounds = pb[:, 0].tolist() + [int(pb[-1, -1])]
+            halo = self._props["halo"] = block_halo(blk, bounds, group=self.group, strict=self.strict_order)
+        plan, prop, _ = halo
+        self._prop = prop
+        self.halo_plan = plan
+        self.lo, self.hi, self.c0, self.c1 = blk.lo, blk.hi, 0, x.shape[1]
+        if x.shape[0] == blk.n and (blk.n_local != blk.n or world == 1):
+            table = prop.table_from_full(x.contiguous())
+        elif x.shape[0] == blk.n_local:
+            table = prop.table_from_own(x.contiguous())
+        else:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
+        if len(chunks) == 1:
+            return prop.propagate(table, self.prop_steps)
+        hops = prop.propagate_chunked([table[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
         return [torch.cat(h, dim=1) for h in hops]
 
     def propagate(self, adj, feature):

@@ -142,6 +142,8 @@ class HaloPropagator:
         self.staged = staged
         self.lo, self.hi, self.n = plan.lo, plan.hi, plan.n
         self.rank, self.world, self.group = plan.rank, plan.world, plan.group
+        self.layout = None                                   # what ShardedGraphOp.gather_full / over_smooth_aggregate look at
+        self.pb = np.stack([plan.bounds[:-1], plan.bounds[1:]], axis=1)
         self._send = {}
 
     # ---- building blocks -------------------------------------------------------------------------------------------
@@ -251,6 +253,9 @@ class HaloPropagator:
                                       None if y_buffers is None else [y_buffers], in_place)
         return [h[0] for h in hops]
 
+    def _exchanging(self):
+        return self.world > 1
+
     # ---- diagnostics: the halves of a hop in isolation -------------------------------------------------------------
     def spmm_only(self, tables):
         outs = []
@@ -269,6 +274,17 @@ class HaloPropagator:
     def pack_only(self, ys):
         for c, y in enumerate(ys):
             self._pack(y, c)
+
+
+def block_halo(block, bounds, group=None, strict=False):
+    """Plan, propagator and SpMM handle for a NORMALISED RowBlock (rows [lo, hi) of A_hat, global column ids): the columns are
+    relabelled to the rank's compact table and the handle multiplies [n_own x n_compact].  Collective."""
+    from ..device import DeviceCSR
+    plan = HaloPlan(block.lo, block.hi, block.n, block.col, bounds, group)
+    if block.n_local == 0:
+        return plan, HaloPropagator(plan, lambda x, out: None), None
+    handle = DeviceCSR(block.rowptr, plan.relabel(block.col), block.val, (block.n_local, plan.n_compact), strict=strict)
+    return plan, HaloPropagator(plan, lambda x, out: handle.spmm(x, out=out)), handle
 
 
 def halo_checksums(plan, table, y_own):

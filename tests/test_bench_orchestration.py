@@ -87,6 +87,15 @@ def _make_engine():
                            out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c, v, x.numpy(), n_rows=rows))))
             return fns, None, pb
 
+        def block_halo(self, args, blk, bounds):
+            from sgl_amd.dist import HaloPlan, HaloPropagator, RowBlock
+            plan = HaloPlan(blk.lo, blk.hi, blk.n, blk.col, bounds)
+            ccol = plan.relabel(blk.col)
+            rp, c, v = blk.rowptr.numpy(), ccol.numpy(), blk.val.numpy()
+            prop = HaloPropagator(plan, lambda x, out: out.copy_(
+                torch.from_numpy(oracle.oracle_spmm(rp, c, v, x.numpy(), n_rows=blk.n_local))))
+            return plan, prop, RowBlock(blk.lo, blk.hi, plan.n_compact, blk.rowptr, ccol, blk.val)
+
         def sampled_rows_check(self, blk, x_prev, y_local, samples=64, tol=1e-5):
             rows = np.random.default_rng(blk.lo).integers(0, max(blk.n_local, 1), size=min(samples, blk.n_local))
             rp, c, v = blk.rowptr.numpy(), blk.col.numpy(), blk.val.numpy()
@@ -146,7 +155,7 @@ def _worker(rank, world, port, out_dir, extra=()):
 
 def test_bench_two_ranks_gloo(tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto")), nprocs=world, join=True)
     r0 = json.load(open(tmp_path / "rank0.json"))
     r1 = json.load(open(tmp_path / "rank1.json"))
     assert len(r0["lines"]) == 1 and r1["lines"] == [] and not r0["initialized_after"]
@@ -158,7 +167,8 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge\u00b7featdim/s" and j["metric"].startswith("pre-prop SpMM throughput") and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] and j["cpu_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather") and len(j["config"]["plan"]["exchange_candidates_ms"]) >= 1
+    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather", "halo")
+    assert set(j["config"]["plan"]["exchange_candidates_ms"]) == {"p2p", "allgather", "halo"}
     dg = j["config"]["diagnostics"]
     assert dg["spmm_only_ms_per_hop_max_rank"] > 0 and dg["exchange_only_ms_per_hop_max_rank"] > 0
     assert dg["exchange_inbound_GBps_per_rank"] > 0
@@ -168,6 +178,8 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert j["config"]["parallelism"].startswith("feature-sharded" if plan["layout"] == "cols" else "row-sharded")
     # the contract layout is always reported, whatever runs; A_hat is stored as one row block per rank
     assert plan["contract_layout"] == "rows" and plan["rows"]["value"] > 0 and plan["rows"]["ms_per_step"] > 0
+    assert set(plan["alternatives"]) == {"cols"} and plan["rows"]["exchange"] == plan["exchange"]
+    assert 0.0 <= plan["rows"]["exchange_skipped_fraction"] < 1.0
     assert plan["rows"]["parallelism"].startswith("row-sharded x2 (A_hat stored as one row block per GPU)")
     assert plan["adjacency_storage"].startswith("row block per rank") and j["config"]["setup_s"] < 120
     assert j["config"]["workload"].startswith("T_tiny: prop_steps=3")
@@ -175,13 +187,29 @@ def test_bench_two_ranks_gloo(tmp_path):
 
 
 def test_bench_rows_only_keeps_no_replica_and_budget_skips(tmp_path):
-    """--layout rows: nothing replica-based is ever built; a zero setup budget skips the alternative and says so"""
+    """default (--layout rows): the contract layout is the headline, nothing replica-based is ever built; with --layout auto a
+    zero setup budget skips the alternative and says so; --exchange halo / p2p run exactly that transport"""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "rows")), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert list(plan["layout_candidates_ms"]) == ["rows"] and plan["layout"] == "rows" and "adjacency_replicated_for" not in plan
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--setup-budget", "0")), nprocs=world, join=True)
+    assert plan["alternatives"] == {} and j["config"]["parallelism"].startswith("row-sharded x2")
+    assert abs(j["value"] - plan["rows"]["value"]) / j["value"] < 0.9          # the headline IS the row-sharded job (separate timings)
+    for ex in ("halo", "p2p"):
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--exchange", ex)), nprocs=world, join=True)
+        j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+        plan = j["config"]["plan"]
+        assert plan["exchange"] == ex and "exchange_candidates_ms" not in plan and plan["layout"] == "rows"
+        assert ("halo" in plan) == (ex == "halo")
+        dg = j["config"]["diagnostics"]
+        assert dg["exchange_only_ms_per_hop_max_rank"] > 0 and ("pack_only_ms_per_hop_max_rank" in dg) == (ex == "halo")
+        if ex == "halo":
+            h = plan["halo"]
+            assert h["compact_rows"] == h["own_rows"] + h["ghost_rows"] and 0 <= h["exchange_skipped_fraction"] < 1
+            assert plan["rows"]["exchange_skipped_fraction"] == h["exchange_skipped_fraction_mean"]
+            assert "need-aware all-gather (halo" in j["config"]["parallelism"]
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto", "--setup-budget", "0")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert plan["layout"] == "rows" and plan["layout_skipped_setup_budget"] == ["cols"] and "adjacency_replicated_for" not in plan
@@ -198,7 +226,7 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
     assert j["n_gpus"] == 4 and j["value"] > 0 and plan["rows"]["value"] > 0
     assert plan["adjacency_replicated_for"].startswith("alternative layout candidates")
     assert set(plan["grid_pieces_candidates_ms"]) == {"2", "4", "8"} and plan["grid_pieces"] in (2, 4, 8)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     assert set(j["config"]["plan"]["layout_candidates_ms"]) == {"rows", "cols"}
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "grid", "--grid-pieces", "2")), nprocs=world, join=True)
@@ -210,10 +238,28 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
     assert "spmm_only_ms_per_hop_max_rank" not in j["config"]["diagnostics"]
 
 
-def test_bench_eight_ranks_gloo(tmp_path):
-    """the driver's largest launch shape: 8 ranks, default flags: the contract layout + the 2 x 4 grid"""
+def test_bench_eight_ranks_gloo_default_is_the_contract_layout(tmp_path):
+    """the driver's largest launch shape: 8 ranks, default flags: the headline is the row-sharded job (A_hat stored per rank,
+    per-hop all-gather), the transport is chosen among halo / p2p / allgather by their measured exchange time, and the
+    need-aware figures are in the line"""
     world = 8
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
+    assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
+    j = json.loads(lines[0][0])
+    plan = j["config"]["plan"]
+    assert j["n_gpus"] == 8 and plan["layout"] == "rows" and plan["contract_layout"] == "rows" and plan["alternatives"] == {}
+    assert list(plan["layout_candidates_ms"]) == ["rows"] and "adjacency_replicated_for" not in plan
+    assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo"} and plan["exchange"] in plan["exchange_candidates_ms"]
+    assert plan["rows"]["exchange"] == plan["exchange"] and 0.0 <= plan["rows"]["exchange_skipped_fraction"] < 1.0
+    assert j["config"]["parallelism"].startswith("row-sharded x8 (A_hat stored as one row block per GPU)")
+    assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0 and j["value"] > 0
+
+
+def test_bench_eight_ranks_gloo(tmp_path):
+    """8 ranks, --layout auto: the contract layout + the 2 x 4 grid as the opt-in alternative"""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto")), nprocs=world, join=True)
     lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])

@@ -1428,6 +1428,16 @@ def _two_rank_worker(rank, world, port, out_dir):
             ok = ok and np.array_equal(hs_[h].cpu().numpy(), ref[h][ops.lo:ops.hi])     # strict order: bit-exact from raw A
         rep_ = ops.gather_rows(hs_[3].contiguous())
         ok = ok and exchange_checksums(rep_, hs_[3], bnd) and np.array_equal(rep_.cpu().numpy(), ref[3])
+        # the default exchange of this path is need-aware (compact table, packed ghosts); the full-replica all-gather and the
+        # chunk-pipelined schedule give the same bits, and the plan moved no more rows than the block references
+        plan_ = ops.halo_plan
+        ok = ok and plan_.n_compact == (blk.hi - blk.lo) + plan_.n_ghost and 0 < plan_.n_ghost <= 2000 - (blk.hi - blk.lo)
+        for kw in (dict(transport="p2p", col_chunks=2), dict(transport="halo", col_chunks=2)):
+            opp = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, **kw)
+            hp_ = opp.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+            ok = ok and all(torch.equal(a_, b_) for a_, b_ in zip(hs_, hp_))
+        hf_ = ops.propagate(blk, torch.from_numpy(x).to(dv))                             # full X given: ghosts cut out locally
+        ok = ok and all(torch.equal(a_, b_) for a_, b_ in zip(hs_, hf_))
         open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     finally:
         dist.destroy_process_group()
@@ -1502,7 +1512,7 @@ def test_four_ranks_on_one_gpu_grid_layout(cuda, tmp_path):
     assert [open(tmp_path / f"rank{r}.txt").read() for r in range(4)] == ["ok"] * 4
 
 
-def _bench_worker(rank, world, port, out_dir, extra=()):
+def _bench_worker(rank, world, port, out_dir, extra=(), halo=True):
     import json as _json
     import os as _os
     import sys as _sys
@@ -1522,6 +1532,8 @@ def _bench_worker(rank, world, port, out_dir, extra=()):
         def init_kwargs(self):
             return {}
 
+    if not halo:
+        OneGpuGlooEngine.block_halo = None    # keep the need-aware exchange out of the candidates (the push test)
     tiny = {"T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3)}
     args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_small", "--no-cpu-baseline",
                              *extra])
@@ -1540,7 +1552,7 @@ def test_bench_auto_selects_validated_push_with_two_ranks_on_one_gpu(cuda, tmp_p
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path), ("--layout", "auto"), False), nprocs=2, join=True)
     lines = json.load(open(tmp_path / "rank0.json"))
     assert len(lines) == 1 and json.load(open(tmp_path / "rank1.json")) == []
     j = json.loads(lines[0])
@@ -1555,7 +1567,34 @@ def test_bench_auto_selects_validated_push_with_two_ranks_on_one_gpu(cuda, tmp_p
     assert plan["layout"] == "cols" and j["config"]["parallelism"].startswith("feature-sharded x2")
 
 
-def _papers_worker(rank, world, port, out_dir):
+def test_bench_need_aware_exchange_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """bench.py's default N>1 path with REAL HIP kernels and two processes: the contract layout (rows) is the headline, the
+    need-aware exchange (compact tables, pack kernel, packed ghost ranges; host-staged here) is built, validated by exact
+    bit-checksums + sampled rows, timed against the full-replica transport, and its figures are in the line"""
+    import socket
+    import torch.multiprocessing as mp
+    for extra in ((), ("--exchange", "halo", "--col-chunks", "1")):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_bench_worker, args=(2, port, str(tmp_path), extra), nprocs=2, join=True)
+        j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
+        plan = j["config"]["plan"]
+        assert j["n_gpus"] == 2 and j["value"] > 0 and plan["layout"] == "rows" and plan["alternatives"] == {}
+        assert "layout_rejected" not in plan and "adjacency_replicated_for" not in plan
+        if extra:
+            assert plan["exchange"] == "halo"
+        else:
+            assert set(plan["exchange_candidates_ms"]) == {"staged", "halo"} and plan["exchange"] in ("staged", "halo")
+        if plan["exchange"] == "halo":
+            h = plan["halo"]
+            assert h["compact_rows"] == h["own_rows"] + h["ghost_rows"] and 0 < h["ghost_rows"] <= 20_000 - h["own_rows"]
+            assert plan["rows"]["exchange_skipped_fraction"] == h["exchange_skipped_fraction_mean"]
+            assert j["config"]["diagnostics"]["pack_only_ms_per_hop_max_rank"] > 0
+
+
+def _papers_worker(rank, world, port, out_dir, exchange="staged"):
     import json as _json
     import os as _os
     import sys as _sys
@@ -1570,7 +1609,7 @@ def _papers_worker(rank, world, port, out_dir):
         engine = bench.GpuEngine(0)
         args = bench.parse_args(["--gpus", str(world), "--pieces", "2", "--col-chunks", "2"])
         wl = dict(n=300_000, d=128, k=3, hashed=True, mean_deg=20.0, d_max=3000)
-        out = bench.papers_section(args, engine, rank, world, "staged", wl=wl)
+        out = bench.papers_section(args, engine, rank, world, exchange, wl=wl)
         with open(_os.path.join(out_dir, f"papers{rank}.json"), "w") as f:
             _json.dump(out, f)
     finally:
@@ -1592,6 +1631,16 @@ def test_bench_papers_section_with_two_ranks_on_one_gpu(cuda, tmp_path):
         assert o["validated"] is True and o["n_gpus"] == 2 and o["value"] > 0 and o["nnz"] > 5_000_000
         assert "2 column chunks pipelined" in o["parallelism"] and o["roofline"]["frac"] > 0
     assert outs[0]["nnz"] == outs[1]["nnz"]
+    # the same section with the need-aware exchange: own feature rows only, ghosts fetched, compact tables
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_papers_worker, args=(2, port, str(tmp_path), "halo"), nprocs=2, join=True)
+    halo = [json.load(open(tmp_path / f"papers{r}.json")) for r in range(2)]
+    for o, full in zip(halo, outs):
+        assert o["validated"] is True and o["nnz"] == full["nnz"] and o["value"] > 0
+        assert "need-aware all-gather (halo)" in o["parallelism"] and o["halo"]["ghost_rows"] < 300_000 - o["halo"]["own_rows"]
 
 
 def test_bench_grid_layout_with_four_ranks_on_one_gpu(cuda, tmp_path):
