@@ -49,9 +49,7 @@ class HaloPlan:
         dev = col.device
         self.n_own = self.hi - self.lo
         # 1. which columns does my block touch?  one byte per node, marked in bounded chunks
-        mark = torch.zeros(self.n, dtype=torch.bool, device=dev)
-        for part in col.split(1 << 26):
-            mark[part.long()] = True
+        mark = self._marks(self.n, col)
         self.need = []
         for q in range(world):
             a, b = int(self.bounds[q]), int(self.bounds[q + 1])
@@ -81,6 +79,52 @@ class HaloPlan:
             w.wait()
             if col.is_cuda:
                 torch.cuda.current_stream(dev).synchronize()
+        self._finish(dev)
+
+    @staticmethod
+    def _marks(n, col):
+        mark = torch.zeros(n, dtype=torch.bool, device=col.device)
+        for part in col.split(1 << 26):
+            mark[part.long()] = True
+        return mark
+
+    @classmethod
+    def offline(cls, rank, bounds, n, block_cols):
+        """The plan of `rank` computed WITHOUT a process group, from the column ids of every rank's block (block_cols(q) ->
+        int32 tensor; called once per rank, so blocks can be generated one at a time).  For cost models and tests on one
+        device: identical to what the collective constructor produces on rank `rank`."""
+        self = cls.__new__(cls)
+        world = len(bounds) - 1
+        self.rank, self.world, self.group = int(rank), world, None
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.lo, self.hi, self.n = int(self.bounds[rank]), int(self.bounds[rank + 1]), int(n)
+        self.n_own = self.hi - self.lo
+        self.need, self.send_rows = [None] * world, [None] * world
+        counts = np.zeros((world, world), dtype=np.int64)
+        dev = None
+        for q in range(world):
+            col = block_cols(q)
+            dev = col.device
+            mark = cls._marks(self.n, col)
+            del col
+            if q == rank:
+                for p in range(world):
+                    a, b = int(self.bounds[p]), int(self.bounds[p + 1])
+                    self.need[p] = torch.empty(0, dtype=torch.int64, device=dev) if (p == rank or b <= a) else \
+                        torch.nonzero(mark[a:b]).flatten() + a
+                    counts[rank, p] = self.need[p].numel()
+                self.send_rows[q] = torch.empty(0, dtype=torch.int32, device=dev)
+            else:
+                self.send_rows[q] = torch.nonzero(mark[self.lo:self.hi]).flatten().to(torch.int32)
+                counts[q, rank] = self.send_rows[q].numel()
+            del mark
+        self.counts = counts
+        self._finish(dev)
+        return self
+
+    def _finish(self, dev):
+        world, rank = self.world, self.rank
+        my_counts = [int(t.numel()) for t in self.need]
         # 3. the compact table: [own rows | ghosts of peer 0 | ghosts of peer 1 | ...]
         off = [self.n_own]
         for q in range(world):

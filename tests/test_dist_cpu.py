@@ -219,6 +219,12 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
         plan = HaloPlan(lo, hi, n, c_glob, bounds)
         c_comp = plan.relabel(c_glob).numpy()
         v = val[nb:ne]
+        # the offline planner (cost models on one device) reproduces the collective plan of this rank exactly
+        off = HaloPlan.offline(rank, bounds, n, lambda q: torch.from_numpy(col[int(ptr[bounds[q]]):int(ptr[bounds[q + 1]])].astype(np.int32)))
+        same_plan = all(torch.equal(a, b) for a, b in zip(off.need, plan.need)) and off.ghost_off == plan.ghost_off and \
+            all(torch.equal(a, b) for a, b in zip(off.send_rows, plan.send_rows)) and torch.equal(off.send_idx, plan.send_idx) and \
+            off.send_off == plan.send_off and np.array_equal(off.counts[rank], plan.counts[rank]) and \
+            np.array_equal(off.counts[:, rank], plan.counts[:, rank])
 
         def spmm(x, out):
             out.copy_(torch.from_numpy(oracle.oracle_spmm(rp, c_comp, v, x.numpy(), n_rows=hi - lo)))
@@ -226,7 +232,7 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
         prop = HaloPropagator(plan, spmm)
         x = torch.from_numpy(hash_matrix(n, d, seed=7))
         ref = oracle.propagate((ptr, col, val), x.numpy(), K)
-        ok = plan.n_compact == plan.n_own + plan.n_ghost and plan.n_ghost <= n - plan.n_own
+        ok = same_plan and plan.n_compact == plan.n_own + plan.n_ghost and plan.n_ghost <= n - plan.n_own
         # the plan is exact: ghosts == the distinct foreign columns of my block
         foreign = np.unique(col[nb:ne][(col[nb:ne] < lo) | (col[nb:ne] >= hi)])
         ok = ok and plan.n_ghost == len(foreign) and np.array_equal(plan.global_ids.numpy()[plan.n_own:], foreign)

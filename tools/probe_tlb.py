@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 from sgl_amd import device as dev  # noqa: E402
 from sgl_amd._lib import check, current_stream_ptr, lib, ptr  # noqa: E402
 
-ROWS = {1: 2_449_029, 8: 16 << 20, 57: 111_059_956}
+ROWS = {1: 2_449_029, 57: 111_059_956}     # the two benchmark tables; any other size (GB, may be fractional) is size * 2^30 / 512 rows
 CHUNK = {"vmm": 0, "vmm1g": 1 << 30, "vmm2m": 2 << 20, "vmm64m": 64 << 20}
 
 
@@ -49,8 +49,8 @@ def main():
     sink = torch.zeros(4, device=device)
     g = torch.Generator(device=device).manual_seed(3)
     n_idx = 96 << 20
-    for size in [int(s) for s in a.sizes.split(",")]:
-        rows = ROWS[size]
+    for size in [float(s) if "." in s else int(s) for s in a.sizes.split(",")]:
+        rows = ROWS.get(size) or int(size * (1 << 30) / 512)
         idx = torch.randint(0, rows, (n_idx,), generator=g, device=device, dtype=torch.int32)
         for mode in a.modes.split(","):
             for rep in range(1 if a.pmc else a.reps):
