@@ -313,6 +313,19 @@ int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx
  * d_w_out (optional, [n, n_hops] leading dimension ldw) receives W. */
 int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
                  float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
+/* Learnable gate in one pass (LearnableWeightedMessageOp 'gate', message_op/learnable_weighted_messahe_op.py:67-71 followed by
+ * two_dim_weighted_add, operators/utils.py:105-116):  G[n,h] = sigmoid(<X_h[n], vec> + bias),  W[n,:] = softmax_h(G[n,:]),
+ * out[n] = sum_h W[n,h] X_h[n].  Every hop element is read once.  d_vec: round_up(d, 4) floats, 16-byte aligned, zero beyond d.
+ * d_w_out / d_g_out (optional, [n, n_hops]) receive W and G (the backward needs both).  Register-resident rows: n_hops <= 16,
+ * d <= 512, 16-byte aligned rows -- otherwise SGL_ERR_UNSUPPORTED (callers then use sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32). */
+int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
+                     int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n, int64_t d, void *stream);
+/* Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in one pass over the hop list:
+ *   P[n, h - h0] = <X_h[n], vec>  for h in [h0, h1);   A[n] = sum over the hops j with bit j of u_mask set of <X_j[n], U[j, :]>
+ * (the reference concatenates [ref || x_h] with ref = feat_list[0] or hstack(feat_list) and applies one Linear: the ref part is
+ * the same for every adopted hop of a node).  U: [n_hops, ldu] on device, vec as above.  Same limits as sgl_hop_gate_f32. */
+int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_u, int64_t ldu, uint64_t u_mask,
+                        const float *d_vec, int h0, int h1, float *d_p, int64_t ldp, float *d_a, int64_t n, int64_t d, void *stream);
 /* out[i, :] = X[idx[i], :]   (idx: int64 on device; negative indices are NOT wrapped) */
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);

@@ -83,6 +83,10 @@ PROTOTYPES = {
     "sgl_hop_wsum2d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                        c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "sgl_hop_rowdot_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_hop_gate_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                 c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_hop_rowdot2_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_int, c_int, c_void_p,
+                                    c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "sgl_hop_wsum1d_bwd_scratch": (c_int64, [c_int]),
     "sgl_hop_wsum1d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                        c_int64, c_void_p]),

@@ -407,6 +407,150 @@ __global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void nafs_fused_ker
         }
 }
 
+// Fused learnable gate (LearnableWeightedMessageOp 'gate', learnable_weighted_messahe_op.py:67-71 + two_dim_weighted_add): one
+// pass over the H hop rows held in registers -> score_h = <X_h[n], v> + b -> sigmoid -> softmax over the hops -> weighted sum.
+// Each hop element is read ONCE (the two-pass form reads every hop for the scores and again for the sum).  The dot products use
+// the lane layout and order of hop_rowdot_reg_kernel and the sum the FMA chain of hop_wsum2d_kernel, so the result equals the
+// two-pass path up to the rounding of expf.  wout [n, H] = the softmax weights, gout [n, H] = the sigmoid outputs (what the
+// backward needs besides the hops).
+template <int LPR, int CH, int HMAX>
+__global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
+                                                         const float bias, float *__restrict__ out, const int64_t ldo,
+                                                         float *__restrict__ wout, const int64_t ldw, float *__restrict__ gout,
+                                                         const int64_t ldg, const int64_t n, const int d) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    f4 x[HMAX][CH], vv[CH];
+    bool on[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 4;
+        on[c] = live && col < d;
+        vv[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
+    float score[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        score[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) score[h] = __builtin_fmaf(vv[c][e], x[h][c][e], score[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) score[h] = group_sum<LPR>(score[h]);   // independent chains: interleaved by the scheduler
+    float run_max = -INFINITY;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+        if (h < n_hops) {
+            score[h] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-__fadd_rn(score[h], bias))));     // sigmoid(Linear(x))
+            run_max = fmaxf(run_max, score[h]);
+            if (gout && live && l == 0) gout[r * ldg + h] = score[h];
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        if (h < n_hops) {
+            score[h] = expf(score[h] - run_max);
+            sum += score[h];
+        }
+    }
+    f4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+        if (h < n_hops) {
+            const float w = __fdiv_rn(score[h], sum);
+            if (wout && live && l == 0) wout[r * ldw + h] = w;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
+        }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (on[c]) {
+            const int col = (c * LPR + l) * 4;
+            if (col + 4 <= d) {
+                __builtin_nontemporal_store(acc[c], reinterpret_cast<f4 *>(out + r * ldo + col));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < d) out[r * ldo + col + e] = acc[c][e];
+            }
+        }
+}
+
+// Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in ONE pass over the hop list:
+//   P[n, h - h0] = <X_h[n], v>                 for the adopted hops h in [h0, h1)        (the per-hop part of Linear([ref || x_h]))
+//   A[n]         = sum_j <X_j[n], U[j, :]>     over the hops j with bit j of u_mask set  (the shared reference part: the
+//                                              reference builds hstack(feat_list) -- or feat_list[0] -- and repeats it H times)
+// Every hop row is read once for both; U ([n_hops, ldu], a few KB) is read through the caches.
+template <int LPR, int CH, int HMAX>
+__global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, const int n_hops, const float *__restrict__ u,
+                                                              const int64_t ldu, const unsigned long long u_mask,
+                                                              const float *__restrict__ vec, const int h0, const int h1,
+                                                              float *__restrict__ p, const int64_t ldp, float *__restrict__ a,
+                                                              const int64_t n, const int d) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    f4 x[HMAX][CH], vv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 4;
+        const bool on = live && col < d;
+        vv[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            x[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    float acc[HMAX];
+    float shared = 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        acc[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[h] = __builtin_fmaf(vv[c][e], x[h][c][e], acc[h]);
+        if (h < n_hops && ((u_mask >> h) & 1ull)) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int col = (c * LPR + l) * 4;
+                if (col < d) {
+                    const f4 uv = load_masked<4>(u + (int64_t)h * ldu, col, d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) shared = __builtin_fmaf(uv[e], x[h][c][e], shared);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) acc[h] = group_sum<LPR>(acc[h]);
+    shared = group_sum<LPR>(shared);
+    if (live && l == 0) {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h >= h0 && h < h1) p[r * ldp + (h - h0)] = acc[h];
+        if (a) a[r] = shared;
+    }
+}
+
 // out[i,:] = X[idx[i],:]
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int64_t ldx,
@@ -1073,5 +1217,99 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
     }
 #undef SGL_GR
     SGL_LAUNCH_CHECK("sgl_gather_rows_f32");
+    return SGL_OK;
+}
+
+// ---- learnable gates -------------------------------------------------------------------------------------------------------
+// register-resident row kernels: H <= 16, d <= 512, 16-byte aligned rows.  Anything else -> SGL_ERR_UNSUPPORTED and the caller
+// takes the two-pass route (sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32).
+#define SGL_ROWREG_DISPATCH(KERNEL_H, lpr, ch, two_rows) \
+    do {                                                  \
+        if (two_rows) KERNEL_H(32, 2);                    \
+        else if (ch == 2) KERNEL_H(64, 2);                \
+        else if (lpr == 8) KERNEL_H(8, 1);                \
+        else if (lpr == 16) KERNEL_H(16, 1);              \
+        else if (lpr == 32) KERNEL_H(32, 1);              \
+        else KERNEL_H(64, 1);                             \
+    } while (0)
+
+SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
+                                float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
+                                int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_gate_f32: bad sizes");
+    Hops hx;
+    bool vec4 = aligned_to(d_vec, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_vec && d_out && ldo >= d, "sgl_hop_gate_f32: bad arguments");
+    SGL_REQUIRE((!d_w_out || ldw >= n_hops) && (!d_g_out || ldg >= n_hops), "sgl_hop_gate_f32: bad weight / gate buffers");
+    if (!(vec4 && n_hops <= 16 && d <= 512 && ldo % 4 == 0 && aligned_to(d_out, 16)))
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: needs <= 16 hops, d <= 512 and 16-byte aligned rows (use the two-pass route)");
+    hipStream_t st = sgl::as_stream(stream);
+    const int lpr = pick_lpr(d, 4);
+    const int ch = (d > lpr * 4) ? 2 : 1;
+    const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;
+    const int64_t blocks = two_rows ? (n + 7) / 8 : (n + (256 / lpr) - 1) / (256 / lpr);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: too many rows for one launch (shard the matrix)");
+#define SGL_GF(L, C, HM) \
+    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d)
+#define SGL_GF_H(L, C)                                 \
+    do {                                               \
+        if (n_hops <= 2) SGL_GF(L, C, 2);              \
+        else if (n_hops <= 4) SGL_GF(L, C, 4);         \
+        else if (n_hops <= 6) SGL_GF(L, C, 6);         \
+        else if (n_hops <= 8) SGL_GF(L, C, 8);         \
+        else if (n_hops <= 10) SGL_GF(L, C, 10);       \
+        else if (n_hops <= 12) SGL_GF(L, C, 12);       \
+        else if (n_hops <= 14) SGL_GF(L, C, 14);       \
+        else SGL_GF(L, C, 16);                         \
+    } while (0)
+    SGL_ROWREG_DISPATCH(SGL_GF_H, lpr, ch, two_rows);
+#undef SGL_GF_H
+#undef SGL_GF
+    SGL_LAUNCH_CHECK("sgl_hop_gate_f32");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_u, int64_t ldu,
+                                   uint64_t u_mask, const float *d_vec, int h0, int h1, float *d_p, int64_t ldp, float *d_a,
+                                   int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_rowdot2_f32: bad sizes");
+    Hops hx;
+    bool vec4 = aligned_to(d_vec, 16) && (!d_u || (aligned_to(d_u, 16) && ldu % 4 == 0));
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    SGL_REQUIRE(h0 >= 0 && h0 <= h1 && h1 <= n_hops, "sgl_hop_rowdot2_f32: bad hop range");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_vec && d_p && ldp >= h1 - h0, "sgl_hop_rowdot2_f32: bad arguments");
+    SGL_REQUIRE(u_mask == 0 || (d_u && d_a && ldu >= d), "sgl_hop_rowdot2_f32: the reference part needs U [n_hops, ldu] and A [n]");
+    if (n_hops < 64) SGL_REQUIRE((u_mask >> n_hops) == 0, "sgl_hop_rowdot2_f32: u_mask names a hop beyond n_hops");
+    if (!(vec4 && n_hops <= 16 && d <= 512 && d > 0))
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_rowdot2_f32: needs <= 16 hops, 0 < d <= 512 and 16-byte aligned rows");
+    hipStream_t st = sgl::as_stream(stream);
+    const int lpr = pick_lpr(d, 4);
+    const int ch = (d > lpr * 4) ? 2 : 1;
+    const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;
+    const int64_t blocks = two_rows ? (n + 7) / 8 : (n + (256 / lpr) - 1) / (256 / lpr);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_rowdot2_f32: too many rows for one launch (shard the matrix)");
+    float *a_out = u_mask ? d_a : nullptr;
+#define SGL_R2(L, C, HM) \
+    hipLaunchKernelGGL((hop_rowdot2_reg_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_u, ldu, (unsigned long long)u_mask, d_vec, h0, h1, d_p, ldp, a_out, n, (int)d)
+#define SGL_R2_H(L, C)                                 \
+    do {                                               \
+        if (n_hops <= 2) SGL_R2(L, C, 2);              \
+        else if (n_hops <= 4) SGL_R2(L, C, 4);         \
+        else if (n_hops <= 6) SGL_R2(L, C, 6);         \
+        else if (n_hops <= 8) SGL_R2(L, C, 8);         \
+        else if (n_hops <= 10) SGL_R2(L, C, 10);       \
+        else if (n_hops <= 12) SGL_R2(L, C, 12);       \
+        else if (n_hops <= 14) SGL_R2(L, C, 14);       \
+        else SGL_R2(L, C, 16);                         \
+    } while (0)
+    SGL_ROWREG_DISPATCH(SGL_R2_H, lpr, ch, two_rows);
+#undef SGL_R2_H
+#undef SGL_R2
+    SGL_LAUNCH_CHECK("sgl_hop_rowdot2_f32");
     return SGL_OK;
 }

@@ -15,7 +15,8 @@ __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency",
     "placed_empty", "MEM_MODES",
-    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "nafs_aggregate", "gather_rows",
+    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate",
+    "gather_rows",
 ]
 
 
@@ -633,33 +634,38 @@ class _WSum2D(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         wd, *feats = ctx.saved_tensors
-        n, d = feats[0].shape
         H = len(feats)
-        g = gout.detach().to(torch.float32)
-        if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
-            g = g.contiguous()
-        need_w = ctx.needs_input_grad[0]
-        need_x = [ctx.needs_input_grad[1 + h] for h in range(H)]
-        if n > 1 and d > 4 and (g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0) and (any(need_x) or H > 16 or d > 512):
-            # autograd hands over a dense [n, d] gradient: for d % 4 != 0 its rows are not 16-byte aligned.  The dW row-dot
-            # reads such a gradient directly (dword-aligned vector loads, sgl_hop_wsum2d_bwd_f32); the element-wise dX
-            # kernel and the wide / many-hop fallback would drop to 4-byte lanes (0.36 of peak at d = 147), so for those
-            # one copy into a padded buffer restores the 16-byte path
-            gp = alloc_rows(n, d, g.device)
-            gp.copy_(g)
-            g = gp
-        dw = torch.empty((n, H), dtype=torch.float32, device=g.device) if need_w else None
-        dxs = [alloc_rows(n, d, g.device) if need_x[h] else None for h in range(H)]
-        ptrs, lds = _lib.hop_arrays(feats)
-        dx_ptrs = dx_lds = None
-        if any(need_x):
-            dx_ptrs = (c_void_p * H)(*[(t.data_ptr() if t is not None else None) for t in dxs])
-            dx_lds = (c_int64 * H)(*[(_ld(t) if t is not None else 0) for t in dxs])
-        with torch.cuda.device(g.device):
-            check(lib().sgl_hop_wsum2d_bwd_f32(H, ptrs, lds, ptr(wd), _ld(wd), ptr(g), _ld(g),
-                                               ptr(dw) if need_w else None, H, dx_ptrs, dx_lds, n, d,
-                                               current_stream_ptr()), "sgl_hop_wsum2d_bwd_f32")
+        dw, dxs = _wsum2d_backward(wd, feats, gout, ctx.needs_input_grad[0], [ctx.needs_input_grad[1 + h] for h in range(H)])
         return (dw, *dxs)
+
+
+def _wsum2d_backward(wd, feats, gout, need_w, need_x):
+    """gradients of out = sum_h W[:, h] X_h: dW[n, h] = <dOut[n], X_h[n]> (register row-dot kernel) and dX_h = W[:, h] dOut"""
+    n, d = feats[0].shape
+    H = len(feats)
+    g = gout.detach().to(torch.float32)
+    if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
+        g = g.contiguous()
+    if n > 1 and d > 4 and (g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0) and (any(need_x) or H > 16 or d > 512):
+        # autograd hands over a dense [n, d] gradient: for d % 4 != 0 its rows are not 16-byte aligned.  The dW row-dot
+        # reads such a gradient directly (dword-aligned vector loads, sgl_hop_wsum2d_bwd_f32); the element-wise dX
+        # kernel and the wide / many-hop fallback would drop to 4-byte lanes (0.36 of peak at d = 147), so for those
+        # one copy into a padded buffer restores the 16-byte path
+        gp = alloc_rows(n, d, g.device)
+        gp.copy_(g)
+        g = gp
+    dw = torch.empty((n, H), dtype=torch.float32, device=g.device) if need_w else None
+    dxs = [alloc_rows(n, d, g.device) if need_x[h] else None for h in range(H)]
+    ptrs, lds = _lib.hop_arrays(feats)
+    dx_ptrs = dx_lds = None
+    if any(need_x):
+        dx_ptrs = (c_void_p * H)(*[(t.data_ptr() if t is not None else None) for t in dxs])
+        dx_lds = (c_int64 * H)(*[(_ld(t) if t is not None else 0) for t in dxs])
+    with torch.cuda.device(g.device):
+        check(lib().sgl_hop_wsum2d_bwd_f32(H, ptrs, lds, ptr(wd), _ld(wd), ptr(g), _ld(g),
+                                           ptr(dw) if need_w else None, H, dx_ptrs, dx_lds, n, d,
+                                           current_stream_ptr()), "sgl_hop_wsum2d_bwd_f32")
+    return dw, dxs
 
 
 def hop_wsum2d(feats, w):
@@ -737,6 +743,134 @@ class _HopScores(torch.autograd.Function):
 def hop_scores(feats, v):
     """[n, H] matrix of <X_h[n, :], v> (differentiable w.r.t. v and the hops)"""
     return _HopScores.apply(v, *feats)
+
+
+def _padded_vec(v, d, device):
+    vp = torch.zeros(round_up(max(d, 1), 4), dtype=torch.float32, device=device)
+    vp[:d] = v.detach().to(torch.float32).view(-1)
+    return vp
+
+
+class _GateFused(torch.autograd.Function):
+    """out = sum_h softmax_h(sigmoid(<X_h, v> + b)) X_h in ONE pass over the hops (sgl_hop_gate_f32); the backward re-uses the
+    dW row-dot kernel and finishes the [n, H]-sized softmax / sigmoid chain in torch."""
+
+    @staticmethod
+    def forward(ctx, v, b, *feats):
+        feats_d = [f.detach() for f in feats]
+        _check_hops(feats_d)
+        n, d = feats_d[0].shape
+        H = len(feats_d)
+        dev_ = feats_d[0].device
+        vp = _padded_vec(v, d, dev_)
+        result = alloc_rows(n, d, dev_)
+        w = torch.empty((n, H), dtype=torch.float32, device=dev_)
+        g = torch.empty((n, H), dtype=torch.float32, device=dev_)
+        ptrs, lds = _lib.hop_arrays(feats_d)
+        with torch.cuda.device(dev_):
+            check(lib().sgl_hop_gate_f32(H, ptrs, lds, ptr(vp), float(b.detach().reshape(-1)[0]), ptr(result), _ld(result), ptr(w), H,
+                                         ptr(g), H, n, d, current_stream_ptr()), "sgl_hop_gate_f32")
+        ctx.save_for_backward(v.detach(), w, g, *feats_d)
+        ctx.b_shape = tuple(b.shape)
+        ctx.mark_non_differentiable(w)
+        return result, w
+
+    @staticmethod
+    def backward(ctx, gout, _gw):
+        v, w, g, *feats = ctx.saved_tensors
+        H = len(feats)
+        need_x = [ctx.needs_input_grad[2 + h] for h in range(H)]
+        dwt, dxs = _wsum2d_backward(w, feats, gout, True, need_x)                 # dL/dW and the W-part of dL/dX_h
+        dg = w * (dwt - (w * dwt).sum(dim=1, keepdim=True))                       # softmax
+        ds = dg * g * (1.0 - g)                                                   # sigmoid
+        dv = db = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.zeros(v.numel(), dtype=torch.float32, device=ds.device)
+            for h, f in enumerate(feats):
+                dv += f.t() @ ds[:, h]
+            dv = dv.view_as(v)
+        if ctx.needs_input_grad[1]:
+            db = ds.sum().reshape(ctx.b_shape)
+        for h in range(H):
+            if need_x[h]:
+                dxs[h] = dxs[h] + ds[:, h:h + 1] * v.view(1, -1)
+        return (dv, db, *dxs)
+
+
+def gate_fusable(feats):
+    """can sgl_hop_gate_f32 / sgl_hop_rowdot2_f32 take these hops? (register-resident rows: <= 16 hops, d <= 512, 16-byte rows)"""
+    f0 = feats[0]
+    return (len(feats) <= 16 and f0.is_cuda and f0.dtype == torch.float32 and 0 < f0.shape[1] <= 512 and f0.shape[0] > 0 and
+            all(f.stride(1) == 1 and f.data_ptr() % 16 == 0 and (f.shape[0] == 1 or f.stride(0) % 4 == 0) for f in feats))
+
+
+def hop_gate(feats, v, b, return_weights=False):
+    """LearnableWeightedMessageOp 'gate' in one pass: (out, W) with W = softmax_h(sigmoid(Linear(X_h))) [n, H]"""
+    out, w = _GateFused.apply(v, b, *feats)
+    return (out, w) if return_weights else out
+
+
+class _HopScores2(torch.autograd.Function):
+    """P[n, h - h0] = <X_h[n], v> for h in [h0, h1) and A[n] = sum_{j in ref} <X_j[n], U[j]>: the two parts of the 'ori_ref' /
+    'jk' Linear([ref || x_h]) in one pass over the hop list (sgl_hop_rowdot2_f32).  Backward in plain torch (mini-batch sized)."""
+
+    @staticmethod
+    def forward(ctx, v, u, mask, h0, h1, *feats):
+        feats_d = [f.detach() for f in feats]
+        _check_hops(feats_d)
+        n, d = feats_d[0].shape
+        L = len(feats_d)
+        dev_ = feats_d[0].device
+        vp = _padded_vec(v, d, dev_)
+        ldu = round_up(d, 4)
+        up = torch.zeros((L, ldu), dtype=torch.float32, device=dev_)
+        up[:, :d] = u.detach().to(torch.float32).view(L, d)
+        p = torch.empty((n, h1 - h0), dtype=torch.float32, device=dev_)
+        a = torch.empty(n, dtype=torch.float32, device=dev_)
+        ptrs, lds = _lib.hop_arrays(feats_d)
+        with torch.cuda.device(dev_):
+            check(lib().sgl_hop_rowdot2_f32(L, ptrs, lds, ptr(up), ldu, ctypes.c_uint64(mask), ptr(vp), h0, h1, ptr(p), h1 - h0,
+                                            ptr(a), n, d, current_stream_ptr()), "sgl_hop_rowdot2_f32")
+        ctx.save_for_backward(v.detach(), u.detach(), *feats_d)
+        ctx.meta = (mask, h0, h1)
+        return p, a
+
+    @staticmethod
+    def backward(ctx, gp, ga):
+        v, u, *feats = ctx.saved_tensors
+        mask, h0, h1 = ctx.meta
+        L = len(feats)
+        d = feats[0].shape[1]
+        dv = du = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.zeros(d, dtype=torch.float32, device=gp.device)
+            for h in range(h0, h1):
+                dv += feats[h].t() @ gp[:, h - h0]
+            dv = dv.view_as(v)
+        if ctx.needs_input_grad[1]:
+            du = torch.zeros((L, d), dtype=torch.float32, device=gp.device)
+            for j in range(L):
+                if (mask >> j) & 1:
+                    du[j] = feats[j].t() @ ga
+            du = du.view_as(u)
+        dxs = []
+        uu = u.view(L, d)
+        for j in range(L):
+            if not ctx.needs_input_grad[5 + j]:
+                dxs.append(None)
+                continue
+            gx = torch.zeros_like(feats[j])
+            if h0 <= j < h1:
+                gx = gx + gp[:, j - h0:j - h0 + 1] * v.view(1, -1)
+            if (mask >> j) & 1:
+                gx = gx + ga.view(-1, 1) * uu[j].view(1, -1)
+            dxs.append(gx)
+        return (dv, du, None, None, None, *dxs)
+
+
+def hop_scores2(feats, v, u, mask, h0, h1):
+    """(P [n, h1 - h0], A [n]): per-hop scores <X_h, v> of the adopted hops and the shared reference term sum_j <X_j, U[j]>"""
+    return _HopScores2.apply(v, u, int(mask), int(h0), int(h1), *feats)
 
 
 def nafs_aggregate(feats, return_weights=False):

@@ -1001,6 +1001,64 @@ def test_aggregators_fuzz_random_shapes(cuda):
         sc = dev.hop_scores(feats, torch.from_numpy(v).to(cuda)).cpu().numpy()
         ref = np.stack([x.astype(np.float64) @ v for x in host], 1)
         assert np.allclose(sc, ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max())), tag
+        if dev.gate_fusable(feats):
+            # the single-pass learnable gate and the one-pass 'jk' / 'ori_ref' scores (register-resident row kernels)
+            bias = float(rng.standard_normal())
+            yg, wg = dev.hop_gate(feats, torch.from_numpy(v).to(cuda), torch.tensor([bias], device=cuda), return_weights=True)
+            sg = 1.0 / (1.0 + np.exp(-(ref + bias)))
+            wref = np.exp(sg - sg.max(1, keepdims=True))
+            wref /= wref.sum(1, keepdims=True)
+            assert np.allclose(wg.cpu().numpy(), wref, rtol=2e-4, atol=2e-5), tag
+            want = sum(wref[:, h:h + 1] * host[h].astype(np.float64) for h in range(H))
+            assert oracle.parity_ok(yg.cpu().numpy(), want.astype(np.float32), 2e-5, rowwise=False), tag
+            u = rng.standard_normal((H, d)).astype(np.float32)
+            mask = int(rng.integers(0, 1 << H))
+            h0 = int(rng.integers(0, H))
+            h1 = int(rng.integers(h0, H + 1))
+            pp, aa = dev.hop_scores2(feats, torch.from_numpy(v).to(cuda), torch.from_numpy(u).to(cuda), mask, h0, h1)
+            assert np.allclose(pp.cpu().numpy(), ref[:, h0:h1], rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max())), tag
+            aref = sum((host[j].astype(np.float64) @ u[j]) for j in range(H) if (mask >> j) & 1) if mask else np.zeros(n)
+            if mask:
+                assert np.allclose(aa.cpu().numpy(), aref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(aref).max())), tag
+
+
+@pytest.mark.parametrize("n,d,H", [(3000, 128, 11), (2500, 100, 4), (700, 147, 6), (64, 16, 16), (1, 500, 2), (900, 260, 5)])
+def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
+    """sgl_hop_gate_f32 (scores, sigmoid, softmax, weighted sum with the rows in registers) against (a) the two-pass route it
+    replaces (row-dot pass + torch sigmoid / softmax + weighted-sum pass) and (b) a float64 torch statement of the reference
+    expression (learnable_weighted_messahe_op.py:67-71), values and gradients w.r.t. the Linear's weight, bias and the hops"""
+    from sgl_amd import device as dev
+    g = torch.Generator(device="cpu").manual_seed(n + d + H)
+    feats = [dev.alloc_rows(n, d, cuda) for _ in range(H)]
+    for f in feats:
+        f.copy_(torch.randn(n, d, generator=g))
+    v = (torch.randn(d, generator=g) * 0.3).to(cuda).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(cuda).requires_grad_(True)
+    gout = torch.randn(n, d, generator=g).to(cuda)
+    assert dev.gate_fusable(feats)
+    fx = [f.clone().requires_grad_(True) for f in feats]
+    y, w = dev.hop_gate(fx, v, b, return_weights=True)
+    # (a) two-pass route, same kernels' arithmetic for the dots and the FMA sum
+    sc = dev.hop_scores(feats, v.detach()) + b.detach()
+    w2 = torch.softmax(torch.sigmoid(sc), dim=1)
+    y2 = dev.hop_wsum2d(feats, w2)
+    assert torch.allclose(w, w2, rtol=1e-5, atol=1e-6)
+    assert oracle.parity_ok(y.detach().cpu().numpy(), y2.cpu().numpy(), 2e-6, rowwise=False)
+    # (b) float64 reference expression with autograd
+    v64, b64 = v.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    f64 = [f.detach().double().requires_grad_(True) for f in feats]
+    s64 = torch.stack([f @ v64 + b64 for f in f64], dim=1)
+    w64 = torch.softmax(torch.sigmoid(s64), dim=1)
+    y64 = sum(w64[:, h:h + 1] * f64[h] for h in range(H))
+    assert oracle.parity_ok(y.detach().cpu().numpy(), y64.detach().float().cpu().numpy(), 1e-5, rowwise=False)
+    (y * gout).sum().backward()
+    (y64 * gout.double()).sum().backward()
+    for got, want, tol in ((v.grad, v64.grad, 2e-4), (b.grad, b64.grad, 2e-3)):
+        scale = float(want.abs().max().clamp_min(1e-12))
+        assert float((got.double() - want).abs().max()) <= tol * max(scale, 1.0), (float((got.double() - want).abs().max()), scale)
+    for h in range(H):
+        scale = float(f64[h].grad.abs().max().clamp_min(1e-12))
+        assert float((fx[h].grad.double() - f64[h].grad).abs().max()) <= 1e-4 * scale
 
 
 @pytest.mark.parametrize("d", [100, 13])

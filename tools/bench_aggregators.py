@@ -61,6 +61,13 @@ def main():
         del out1
         v = torch.randn(d, device=device)
         rep("gate scores (rowdot)", timeit(lambda: dev.hop_scores(feats, v)), H * nb + n * H * 4)
+        bb = torch.zeros(1, device=device)
+        rep("gate (single pass)", timeit(lambda: dev.hop_gate(feats, v, bb)), (H + 1) * nb + 2 * n * H * 4)
+        rep("gate (two-pass route)", timeit(lambda: dev.hop_wsum2d(feats, torch.softmax(torch.sigmoid(dev.hop_scores(feats, v) + bb), 1))),
+            (H + 1) * nb + 2 * n * H * 4)
+        uu = torch.randn(H, d, device=device)
+        rep("jk scores (one pass)", timeit(lambda: dev.hop_scores2(feats, v, uu, (1 << H) - 1, 0, H)), H * nb + n * (H + 1) * 4)
+        rep("jk scores (hstack+GEMV)", timeit(lambda: (torch.hstack(feats) @ uu.view(-1), dev.hop_scores(feats, v))), H * nb + n * (H + 1) * 4)
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)

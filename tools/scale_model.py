@@ -31,6 +31,7 @@ from sgl_amd import synthetic  # noqa: E402
 from sgl_amd.dist import HaloPlan, balanced_bounds, column_chunks  # noqa: E402
 
 K = 3
+ALT_CHUNKS = (1, 3, 4)     # other column-chunk counts of the pipelined schedule, modelled next to the default 2
 
 
 def timed(fn, reps=5, warm=2):
@@ -81,13 +82,19 @@ def rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, de
            "spmm": [], "pack": []}
     y_full = torch.empty((hi - lo, d), device=device)
     out["spmm_whole"] = timed(lambda: csr.spmm(t0, out=y_full))
-    for a, b in chunks:
-        t = t0[:, a:b].contiguous()
-        y = torch.empty((hi - lo, b - a), device=device)
-        out["spmm"].append(timed(lambda: csr.spmm(t, out=y)))
-        buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
-        out["pack"].append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf)) if buf.shape[0] else 0.0)
-        del t, y, buf
+
+    def per_chunk(chs):
+        sp, pk = [], []
+        for a, b in chs:
+            t = t0[:, a:b].contiguous()
+            y = torch.empty((hi - lo, b - a), device=device)
+            sp.append(timed(lambda: csr.spmm(t, out=y)))
+            buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
+            pk.append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf)) if buf.shape[0] else 0.0)
+            del t, y, buf
+        return sp, pk
+    out["spmm"], out["pack"] = per_chunk(chunks)
+    out["alt"] = {nc: per_chunk(column_chunks(d, nc)) for nc in ALT_CHUNKS}
     # the same block against the FULL replica (global column ids): what the plain all-gather layout multiplies
     csr_g = dev.DeviceCSR(rp_local, col[nb:ne], val[nb:ne], (hi - lo, n))
     out["spmm_whole_full_replica"] = timed(lambda: csr_g.spmm(x0, out=y_full))
@@ -166,6 +173,26 @@ def main():
                 cells.append(f"{t:.2f} ms ({t1 / t:.2f}x)")
             t_inf = step_ms(G, 1e9, kind)
             print(f"| {G} | {kind} | " + " | ".join(cells) + f" | {t_inf:.2f} ms ({t1 / t_inf:.2f}x) |")
+    print()
+    print("### Pipelining granularity: the need-aware exchange with 1 / 3 / 4 column chunks instead of 2\n")
+    print("More chunks shorten the un-overlapped head (first chunk's SpMM + pack) and tail (last chunk's last SpMM) of the step; every chunk still "
+          "gathers whole 128-byte lines (d = 100 -> 32 + 32 + 32 + 4), so the SpMM total barely moves.\n")
+    print("| G | chunks | spmm per chunk ms (slowest rank) | " + " | ".join(f"B = {b} GB/s" for b in rates) + " |")
+    print("|---|---|---|" + "---|" * len(rates))
+    for G in (2, 4, 8):
+        for nc in ALT_CHUNKS:
+            chs = column_chunks(d, nc)
+            cells, slow = [], None
+            for B in rates:
+                worst = 0.0
+                for m in model[G]:
+                    link = max(m["in_peer_max"], m["out_peer_max"])
+                    xfer = [link * (b - a) / d / (B * 1e9) * 1e3 for a, b in chs]
+                    t = simulate(m["alt"][nc][0], m["alt"][nc][1], xfer)
+                    if t > worst:
+                        worst, slow = t, m
+                cells.append(f"{worst:.2f} ms ({t1 / worst:.2f}x)")
+            print(f"| {G} | {len(chs)} {chs} | {' + '.join(f'{v:.3f}' for v in slow['alt'][nc][0])} | " + " | ".join(cells) + " |")
     print()
     for kind in ("halo", "full"):
         lo_b, hi_b = 1.0, 2000.0
