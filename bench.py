@@ -363,8 +363,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SGL_BENCH_WORKLOAD", "S1_products"))
     ap.add_argument("--pieces", type=int, default=2, help="row pieces per rank (N>1): transfers start per piece")
-    ap.add_argument("--col-chunks", type=int, default=2,
-                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain")
+    ap.add_argument("--col-chunks", default="auto",
+                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain; auto = 2 and 4 "
+                         "are both built, validated and timed during setup and the faster runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
     ap.add_argument("--exchange", choices=("auto", "halo", "p2p", "allgather", "push"),
@@ -739,21 +740,70 @@ def _rows_halo(job, chunks):
 
 
 def _build_rows(job, ref=None):
-    """The contract layout: A_hat row-sharded IN STORAGE (every rank multiplies the block it alone holds) + per-hop
+    """The contract layout.  --col-chunks auto (default): how finely the feature block is cut for the pipelined exchange trades
+    the un-overlapped head and tail of a step against per-chunk launch / issue cost (profiles/r03_scale_model.md: 4 chunks win
+    in the model when the links are the bound, 2 when compute is), and that depends on what the links deliver -- so both are
+    built, validated and timed (untimed setup; the exchange is selected once, with the first) and the faster is kept."""
+    args = job.args
+    auto = str(args.col_chunks) == "auto"
+    counts = [2, 4] if (auto and job.world > 1 and job.nbuf > 0) else [2 if auto else int(args.col_chunks)]
+    base_info = dict(job.info)
+    best, timing, exchange = None, {}, None
+    live = job.info                                       # callers hold a reference to this dict: it is edited in place
+
+    def set_info(d_):
+        live.clear()
+        live.update(d_)
+    for nc in counts:
+        set_info(base_info)
+        if getattr(job, "rows_inbound_bytes", None) is not None:
+            job.rows_inbound_bytes = None
+        cand = _build_rows_for(job, ref, nc, exchange)
+        exchange = job.info["exchange"]
+        if len(counts) > 1:
+            good = True
+            try:
+                cand["step"]()
+                job.sync_all()
+                good = bool(cand["check"]())
+            except Exception as e:  # noqa: BLE001
+                good = False
+                sys.stderr.write(f"[bench] rows with {nc} column chunks failed on rank {job.rank}: {e!r}\n")
+            if not job.agree(good):
+                continue
+            timing[nc] = job.timed_s(cand["step"], reps=2, warm=0)
+        if best is None or (len(counts) > 1 and timing[nc] < timing[best[0]]):
+            best = (nc, cand, dict(job.info), getattr(job, "rows_inbound_bytes", None))
+        del cand
+    if best is None:
+        raise RuntimeError("no column chunking of the row-sharded layout passed validation")
+    nc, cand, info, inbound = best
+    set_info(info)
+    job.rows_inbound_bytes = inbound
+    if timing:
+        job.info["col_chunks_candidates_ms"] = {str(k): round(v * 1e3, 3) for k, v in timing.items()}
+    job.col_chunks_chosen = nc
+    return cand
+
+
+def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
+    """A_hat row-sharded IN STORAGE (every rank multiplies the block it alone holds) + per-hop
     all-gather -- need-aware (halo) or of the full replica --, column chunks software-pipelined across hops.  Validated
     without any replica of A_hat: the exchanged rows by exact bit-checksums, the local SpMM by sampled rows recomputed in fp64."""
     from sgl_amd.dist import column_chunks, exchange_checksums, halo_checksums
     args, K, blk = job.args, job.K, job.block
-    chunks = column_chunks(job.d, args.col_chunks)
+    chunks = column_chunks(job.d, n_chunks)
     job.info.update({"row_pieces": args.pieces, "col_chunks": chunks})
     can_halo = job.world > 1 and job.nbuf > 0 and getattr(job.engine, "block_halo", None) is not None
-    want = args.exchange
+    want = exchange_fixed or args.exchange
+    if want == "staged":
+        want = "p2p"
     full = halo = None
     if want != "halo" or not can_halo:
         full = _rows_full_replica(job, chunks)
     if can_halo and want in ("auto", "halo"):
         halo = _rows_halo(job, chunks)
-    exchange = _select_exchange(job, full, halo)
+    exchange = exchange_fixed if exchange_fixed in ("halo", "p2p", "allgather", "staged") else _select_exchange(job, full, halo)
     job.info["exchange"] = exchange
     check_fn = getattr(job.engine, "sampled_rows_check", None)
     if exchange == "halo":
@@ -1019,6 +1069,12 @@ def _replayed_profile(workload, world):
     return tj.get(workload) if world == 1 else None
 
 
+def _n_chunks(args):
+    """column chunks of the papers100M-shaped section: the count the S1 job settled on (--col-chunks auto), else the flag"""
+    v = getattr(args, "col_chunks_chosen", None) or args.col_chunks
+    return 2 if str(v) == "auto" else int(v)
+
+
 def papers_section(args, engine, rank, world, exchange, wl=None):
     """The same measurement on an ogbn-papers100M-shaped graph, row-sharded in storage over the same
     ranks: every rank generates ITS nnz-balanced row block and the feature replica on its own GPU (hash keyed by
@@ -1042,7 +1098,7 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
     # flight while chunk B is multiplied and hop h+1 of chunk A only waits for A's own exchange): the job is communication
     # bound there (49.8 GB in-bound per rank per hop at 8 ranks) and this hides the SpMM behind the transfers.
     from sgl_amd.dist import column_chunks
-    chunks = column_chunks(d, args.col_chunks if world > 1 else 1)
+    chunks = column_chunks(d, _n_chunks(args) if world > 1 else 1)
     if len(chunks) > 1:
         x_chunks = [x0[:, a:b].contiguous() for a, b in chunks]
         del x0
@@ -1115,7 +1171,7 @@ def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     plan, prop, cblk = engine.block_halo(args, blk, [int(b) for b in bounds])
     x_own = engine.feature_rows(args, wl, lo, hi)
-    chunks = column_chunks(d, args.col_chunks)
+    chunks = column_chunks(d, _n_chunks(args))
     tables = [prop.table_from_own(x_own if len(chunks) == 1 else x_own[:, a:b].contiguous(), key=("init", c))
               for c, (a, b) in enumerate(chunks)]
     del x_own
@@ -1338,6 +1394,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         timer.start()
         try:
             exchange = info.get("exchange", "p2p")
+            args.col_chunks_chosen = getattr(job, "col_chunks_chosen", None)
             del step, halves
             job.drop_full()
             job.block = job.x0 = None

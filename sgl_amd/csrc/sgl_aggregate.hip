@@ -1282,7 +1282,7 @@ SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const in
     if (rc != SGL_OK) return rc;
     SGL_REQUIRE(h0 >= 0 && h0 <= h1 && h1 <= n_hops, "sgl_hop_rowdot2_f32: bad hop range");
     if (n == 0) return SGL_OK;
-    SGL_REQUIRE(d_vec && d_p && ldp >= h1 - h0, "sgl_hop_rowdot2_f32: bad arguments");
+    SGL_REQUIRE(d_vec && (h1 == h0 || (d_p && ldp >= h1 - h0)), "sgl_hop_rowdot2_f32: bad arguments");
     SGL_REQUIRE(u_mask == 0 || (d_u && d_a && ldu >= d), "sgl_hop_rowdot2_f32: the reference part needs U [n_hops, ldu] and A [n]");
     if (n_hops < 64) SGL_REQUIRE((u_mask >> n_hops) == 0, "sgl_hop_rowdot2_f32: u_mask names a hop beyond n_hops");
     if (!(vec4 && n_hops <= 16 && d <= 512 && d > 0))

@@ -243,11 +243,16 @@ def test_bench_eight_ranks_gloo_default_is_the_contract_layout(tmp_path):
     per-hop all-gather), the transport is chosen among halo / p2p / allgather by their measured exchange time, and the
     need-aware figures are in the line"""
     world = 8
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto")), nprocs=world, join=True)
     lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])
     plan = j["config"]["plan"]
+    # the pipelining granularity is measured, not assumed: 2 and 4 column chunks both validated and timed, the faster kept
+    assert set(plan["col_chunks_candidates_ms"]) == {"2", "4"}
+    from sgl_amd.dist import column_chunks
+    chosen = int(min(plan["col_chunks_candidates_ms"], key=plan["col_chunks_candidates_ms"].get))
+    assert plan["col_chunks"] == [list(c) for c in column_chunks(40, chosen)]
     assert j["n_gpus"] == 8 and plan["layout"] == "rows" and plan["contract_layout"] == "rows" and plan["alternatives"] == {}
     assert list(plan["layout_candidates_ms"]) == ["rows"] and "adjacency_replicated_for" not in plan
     assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo"} and plan["exchange"] in plan["exchange_candidates_ms"]
