@@ -760,6 +760,9 @@ def _build_rows(job, ref=None):
             job.rows_inbound_bytes = None
         cand = _build_rows_for(job, ref, nc, exchange)
         exchange = job.info["exchange"]
+        for k in ("exchange_candidates_ms", "push_peer_rows_skipped", "full_step_candidates_ms", "push_rejected"):
+            if k in live:
+                base_info[k] = live[k]                    # the selection happens once: its record goes with every candidate
         if len(counts) > 1:
             good = True
             try:
