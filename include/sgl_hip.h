@@ -330,6 +330,10 @@ int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ld
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);
 
+/* order-sensitive 64-bit hash of a HOST buffer, multi-threaded (what the reference-signature shims key their cached adjacency
+ * on; the operator layer fingerprints scipy index / value arrays with it).  Host-only: works without a GPU. */
+int sgl_content_hash(const void *h_ptr, int64_t bytes, uint64_t *out);
+
 /* ---- device allocations with a stated physical placement (the tables the SpMM gathers from) ------------------------ */
 /* A random gather of 512-byte rows from a table of tens of GB is one address translation per row; how many of them the
  * translation caches hold depends on the size of the physically contiguous, equally aligned ranges behind the table.

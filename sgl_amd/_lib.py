@@ -98,6 +98,7 @@ PROTOTYPES = {
     "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_fill": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_features": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "sgl_content_hash": (c_int, [c_void_p, c_int64, POINTER(c_uint64)]),
     "sgl_mem_alloc": (c_int, [POINTER(c_void_p), c_int64, c_int, c_int64]),
     "sgl_mem_free": (c_int, [c_void_p]),
     "sgl_probe_stream_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -171,3 +172,12 @@ def hop_arrays(tensors):
     ptrs = (c_void_p * n)(*[t.data_ptr() for t in tensors])
     lds = (c_int64 * n)(*[t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)) for t in tensors])
     return ptrs, lds
+
+
+def content_hash(arr):
+    """64-bit content hash of a C-contiguous numpy array, computed by the library's team of host threads (no GPU needed)"""
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    h = c_uint64(0)
+    check(lib().sgl_content_hash(c_void_p(a.ctypes.data), a.nbytes, ctypes.byref(h)), "sgl_content_hash")
+    return int(h.value)

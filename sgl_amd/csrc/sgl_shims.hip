@@ -78,13 +78,28 @@ void want_huge_pages(void *p, size_t bytes) {
     if (b > a) (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
 }
 
+// A team of host threads; the caller's thread is member 0.  The members are joined on every path out (an exception thrown by
+// member 0 -- bad_alloc in a hash -- must not leave joinable threads behind: std::terminate).
 template <typename F>
 void run_team(int threads, F fn) {
     std::vector<std::thread> team;
+    struct Join {
+        std::vector<std::thread> &t;
+        ~Join() {
+            for (auto &th : t)
+                if (th.joinable()) th.join();
+        }
+    } join{team};
     for (int t = 1; t < threads; ++t) team.emplace_back(fn, t);
     fn(0);
-    for (auto &th : team) th.join();
 }
+
+struct JoinThread {   // RAII join of one helper thread
+    std::thread &t;
+    ~JoinThread() {
+        if (t.joinable()) t.join();
+    }
+};
 
 // order-sensitive 64-bit content hash, computed by a team of threads over fixed 1 MiB blocks (so the result does not
 // depend on the number of threads)
@@ -147,6 +162,7 @@ bool all_zero(const void *p, size_t bytes, int threads) {
 
 struct Shim {
     std::mutex mu;
+    int device = 0;                        // every buffer, stream and handle below lives on this device (one Shim per device)
     // cached adjacency
     const void *indptr_p = nullptr, *indices_p = nullptr;
     int64_t n = -1, nnz = -1;
@@ -226,6 +242,10 @@ struct Shim {
         const size_t chunks = (bytes + kChunk - 1) / kChunk;
         std::atomic<int> err((int)hipSuccess);
         run_team(std::min<size_t>(threads, chunks), [&](int t) {
+            if (t != 0 && hipSetDevice(device) != hipSuccess) {   // a new thread starts on device 0: bind it to the shim's device
+                err.store((int)hipErrorInvalidDevice);
+                return;
+            }
             for (size_t c = t; c < chunks; c += threads) {
                 const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
                 hipError_t e;
@@ -250,9 +270,25 @@ struct Shim {
     }
 };
 
-Shim &shim() {
-    static Shim s;   // lives for the process: the cached device memory is released with the context
-    return s;
+// One Shim per device, created on first use with that device current and kept for the life of the process (the cached device
+// memory is released with the context): a process that drives several GPUs never sends one device's memory through another
+// device's streams.
+Shim &shim(int device) {
+    static std::mutex mu;
+    static std::vector<Shim *> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1, nullptr);
+    if (!per_device[device]) {
+        per_device[device] = new Shim();
+        per_device[device]->device = device;
+    }
+    return *per_device[device];
+}
+
+int current_device(int *device) {
+    SGL_HIP_CHECK(hipGetDevice(device));
+    SGL_REQUIRE(*device >= 0, "no current HIP device");
+    return SGL_OK;
 }
 
 int host_spmm(float *answer, const float *data, const int *indices, const int *indptr, const float *mat,
@@ -269,10 +305,11 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
     const int64_t nnz = indptr[n];
     SGL_REQUIRE(nnz >= 0 && indptr[0] == 0, "FloatCSRMulDense*: bad indptr");
     SGL_REQUIRE(nnz == 0 || (data && indices), "FloatCSRMulDense*: NULL data/indices");
-    Shim &S = shim();
+    int device = 0, rc;
+    if ((rc = current_device(&device)) != SGL_OK) return rc;
+    Shim &S = shim(device);
     std::lock_guard<std::mutex> lk(S.mu);
     const int threads = team_size();
-    int rc;
     Phases ph;
 
     // ---- the dense input starts travelling at once: it does not depend on whether the adjacency is cached -----------------
@@ -281,10 +318,17 @@ int host_spmm(float *answer, const float *data, const int *indices, const int *i
     if ((rc = S.d_y.reserve(dense)) != SGL_OK) return rc;
     int rc_x = SGL_OK;
     std::string err_x;
+    if ((rc = S.ensure_staging(threads)) != SGL_OK) return rc;   // pinned buffers and streams are created by THIS thread, on `device`
     std::thread up_x([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            rc_x = sgl::fail(SGL_ERR_NO_DEVICE, "FloatCSRMulDense*: the upload thread could not select device %d", device);
+            err_x = sgl::get_error();
+            return;
+        }
         rc_x = S.copy(S.d_x.p, const_cast<float *>(mat), dense, true, threads);
         if (rc_x != SGL_OK) err_x = sgl::get_error();     // the error text is thread-local: carry it over
     });
+    JoinThread join_up_x{up_x};                            // joined on every path out, also when a hash below throws
 
     // ---- meanwhile: is the adjacency bit-for-bit the previous call's?  is `answer` all zeros? -----------------------------
     const uint64_t hp = content_hash(indptr, ((size_t)n + 1) * sizeof(int), threads);
@@ -379,15 +423,32 @@ SGL_EXPORT int sgl_download(void *h_dst, const void *d_src, int64_t bytes, void 
     SGL_REQUIRE(bytes >= 0 && (bytes == 0 || (h_dst && d_src)), "sgl_download: bad arguments");
     SGL_HIP_CHECK(hipStreamSynchronize(sgl::as_stream(stream)));   // the producer's work is complete before the copy starts
     want_huge_pages(h_dst, (size_t)bytes);
-    Shim &S = shim();
+    int device = 0, rc;
+    if ((rc = current_device(&device)) != SGL_OK) return rc;
+    Shim &S = shim(device);
     std::lock_guard<std::mutex> lk(S.mu);
     return S.copy(const_cast<void *>(d_src), h_dst, (size_t)bytes, false, team_size());
 }
 
 SGL_EXPORT int sgl_shim_cache_stats(int64_t *hits, int64_t *misses) {
-    Shim &S = shim();
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0) device = 0;    // no GPU: the (empty) statistics of device 0
+    Shim &S = shim(device);
     std::lock_guard<std::mutex> lk(S.mu);
     if (hits) *hits = S.hits;
     if (misses) *misses = S.misses;
+    return SGL_OK;
+}
+
+// Order-sensitive 64-bit hash of a HOST buffer, computed by the shims' team of threads (the one they key their cached adjacency
+// on): lets the Python operator layer fingerprint a scipy matrix's index / value arrays in full at memory speed, without an
+// optional dependency.  Host-only: needs no GPU.
+SGL_EXPORT int sgl_content_hash(const void *h_ptr, int64_t bytes, uint64_t *out) {
+    SGL_REQUIRE(out && bytes >= 0 && (bytes == 0 || h_ptr), "sgl_content_hash: bad arguments");
+    try {
+        *out = content_hash(h_ptr, (size_t)bytes, team_size());
+    } catch (const std::exception &e) {
+        return sgl::fail(SGL_ERR_ALLOC, "sgl_content_hash: %s", e.what());
+    }
     return SGL_OK;
 }

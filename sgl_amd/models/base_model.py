@@ -42,6 +42,22 @@ class BaseSGAPModel(nn.Module):
         self._processed_feature = None
         self._pre_msg_learnable = False
 
+    # `_processed_feat_list` is part of the de-facto interface (the reference's distributed tasks and search code read it:
+    # sgl/tasks/node_classification_dist.py:69, sgl/search/auto_search_dist.py:80).  When preprocess() folded the aggregation into
+    # the SpMM epilogue no hop list was kept; it is then produced ON DEMAND, the first time somebody asks for it.
+    @property
+    def _processed_feat_list(self):
+        hops = self.__dict__.get("_hop_list")
+        src = self.__dict__.get("_hop_source")
+        if hops is None and src is not None:
+            hops = self._pre_graph_op.propagate(*src)
+            self.__dict__["_hop_list"], self.__dict__["_hop_source"] = hops, None
+        return hops
+
+    @_processed_feat_list.setter
+    def _processed_feat_list(self, hops):
+        self.__dict__["_hop_list"], self.__dict__["_hop_source"] = hops, None
+
     def preprocess(self, adj, feature):
         if self._pre_graph_op is None:
             self._pre_msg_learnable = False
@@ -58,6 +74,7 @@ class BaseSGAPModel(nn.Module):
                     fused = gop.propagate_reduce(adj, feature, **spec)
                 if fused is not None:
                     self._processed_feat_list = None
+                    self.__dict__["_hop_source"] = (adj, feature)     # the hop list stays available, lazily
                     self._processed_feature = fused
                     return
         self._processed_feat_list = self._pre_graph_op.propagate(adj, feature)
@@ -70,9 +87,9 @@ class BaseSGAPModel(nn.Module):
         try:
             n, d = feature.shape
             need = (self._pre_graph_op._prop_steps + 1) * n * dev.row_pitch(d) * 4
-            free, _ = torch.cuda.mem_get_info()
+            free, _ = torch.cuda.mem_get_info(torch.device(self._pre_graph_op._opt("device")))
             return need > free // 4
-        except Exception:  # noqa: BLE001
+        except (RuntimeError, AssertionError, ValueError):   # no usable device to ask: keep the hop list (the small-job default)
             return False
 
     def postprocess(self, adj, output):

@@ -16,10 +16,9 @@ from .. import device as dev
 class AdjIdentity:
     """Identity of an adjacency for the normalised-adjacency caches: the cache hits only for the SAME object (held by
     weak reference and compared with `is`, so a recycled id() of a freed temporary can never match) whose contents
-    still look the same -- full hash of the row pointers, strided samples of indices and values, buffer addresses --
-    so in-place edits of a cached matrix are noticed too (up to the sampling of indices / values)."""
-
-    _SAMPLE = 1 << 16
+    are still the same -- FULL hashes of the row pointers, indices and values (sgl_content_hash: the library's team of host
+    threads, about a gigabyte in a few tens of milliseconds, no optional dependency), buffer addresses -- so any in-place edit
+    of a cached matrix is noticed."""
 
     def __init__(self, adj):
         import weakref
@@ -32,15 +31,13 @@ class AdjIdentity:
 
     @classmethod
     def fingerprint(cls, adj):
-        import xxhash
         if sp.issparse(adj):                # any scipy format (the reference normalises coo / csc input too before it
-            def sample(a):                  # rejects it, base_op.py:20-23)
+            from .._lib import content_hash  # rejects it, base_op.py:20-23)
+
+            def whole(a):
                 a = np.asarray(a)
-                step = max(1, a.size // cls._SAMPLE)
-                return (a.ctypes.data, a.size, str(a.dtype), xxhash.xxh64_intdigest(np.ascontiguousarray(a[::step]).tobytes()))
-            parts = [sample(getattr(adj, nm)) for nm in ("indices", "data", "row", "col", "offsets") if hasattr(adj, nm)]
-            if hasattr(adj, "indptr"):
-                parts.append(xxhash.xxh64_intdigest(np.ascontiguousarray(adj.indptr).tobytes()))
+                return (a.ctypes.data, a.size, str(a.dtype), content_hash(a))
+            parts = [whole(getattr(adj, nm)) for nm in ("indices", "data", "row", "col", "offsets", "indptr") if hasattr(adj, nm)]
             return ("scipy", adj.format, adj.shape, int(adj.nnz), tuple(parts))
         # sgl_amd.io.DeviceAdjacency: device buffers; torch bumps _version on every in-place write
         return ("device", tuple(adj.shape), int(adj.nnz), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr(),

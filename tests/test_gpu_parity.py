@@ -720,12 +720,16 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
         mu = cls(*args)
         mu.preprocess(a, x)
         config.fuse_aggregate = "auto"
-        assert mf._processed_feat_list is None and len(mu._processed_feat_list) == 4
+        # folded: no hop list is held ... until somebody asks (the reference's dist tasks read the attribute): then it is produced
+        assert mf.__dict__["_hop_list"] is None and len(mu._processed_feat_list) == 4
         assert torch.equal(mf._processed_feature, mu._processed_feature), cls.__name__
+        lazy = mf._processed_feat_list
+        assert len(lazy) == 4 and all(torch.equal(p_, q_) for p_, q_ in zip(lazy, mu._processed_feat_list))
+        assert mf._processed_feat_list is lazy                         # computed once
     # "auto": `last` is always folded (it is free); sum-like aggregates only when the hop list would be heavy
     ma = SGC(3, d, 5)
     ma.preprocess(a, x)
-    assert ma._processed_feat_list is None
+    assert ma.__dict__["_hop_list"] is None and len(ma._processed_feat_list) == 4
     mb = SSGC(3, d, 5)
     mb.preprocess(a, x)
     assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)

@@ -352,6 +352,37 @@ def test_multi_peer_exchange_against_a_mock_rccl(tmp_path):
     assert r.returncode == 0 and "exchange_mock: OK (42 multi-rank cases" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+
+def test_adjacency_fingerprint_hashes_every_entry():
+    """the operator-level cache key hashes indptr, indices AND data in full (sgl_content_hash, the library's host
+    thread team; no optional module) -- an in-place edit of ANY single value or index of a cached scipy matrix is noticed,
+    a recycled temporary never matches"""
+    import scipy.sparse as sp
+    from sgl_amd.operators.base_op import AdjIdentity
+    rng = np.random.default_rng(0)
+    n, nnz = 4000, 900_000
+    m = sp.csr_matrix((rng.random(nnz).astype(np.float32), (rng.integers(0, n, nnz), rng.integers(0, n, nnz))), shape=(n, n))
+    ident = AdjIdentity(m)
+    assert ident.matches(m) and not ident.matches(m.copy())
+    for pos in (1, m.nnz // 2 + 7, m.nnz - 3):           # positions a strided 65 536-sample never looks at
+        old = m.data[pos]
+        m.data[pos] = old + 1.0
+        assert not ident.matches(m)
+        m.data[pos] = old
+        assert ident.matches(m)
+    j = m.nnz // 3 + 11
+    old = m.indices[j]
+    m.indices[j] = (old + 1) % n
+    assert not ident.matches(m)
+    m.indices[j] = old
+    assert ident.matches(m)
+    a = np.arange(3_000_001, dtype=np.int32)             # several 1 MiB blocks + a ragged tail
+    h = _lib.content_hash(a)
+    assert h == _lib.content_hash(a.copy()) and h != _lib.content_hash(a[::-1]) and _lib.content_hash(a[:0]) != h
+    a[2_999_999] ^= 1
+    assert _lib.content_hash(a) != h
+
+
 def test_community_order_on_cpu_tensors():
     """sgl_amd.reorder.community_order_reference (the tensor-code statement of sgl_reorder_community): on a small
     planted-partition graph with shuffled ids it returns a permutation under which most edges join nodes of the same (now
