@@ -20,6 +20,9 @@
 //     share neighbours (and the CSR stream) stay in one XCD's L2.
 #include "sgl_common.h"
 
+#include <atomic>
+#include <memory>
+
 namespace {
 
 template <int VEC>
@@ -583,7 +586,24 @@ struct sgl_csr {
     int device = 0;
     const int32_t *d_rowmap = nullptr;   // caller's [n_rows] storage row -> output row (sgl_csr_set_rowmap), not owned
     int32_t *d_long_out = nullptr;       // output rows of the split rows under the row map
+    // bumped by sgl_csr_set_values / sgl_csr_set_rowmap, set to ~0 by sgl_csr_destroy: a captured chain graph has the value and
+    // row-map pointers of its capture baked in and refuses to replay once they changed (shared: outlives the handle)
+    std::shared_ptr<std::atomic<uint64_t>> epoch = std::make_shared<std::atomic<uint64_t>>(0);
 };
+
+// permutation check of a row map on the device: every entry in range, no output row named twice
+__global__ __launch_bounds__(256) void rowmap_check_kernel(const int32_t *__restrict__ map, const int64_t n, unsigned *__restrict__ seen,
+                                                           int *__restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = map[i];
+    if (m < 0 || m >= n) {
+        atomicOr(bad, 1);
+        return;
+    }
+    const unsigned bit = 1u << (m & 31);
+    if (atomicOr(&seen[m >> 5], bit) & bit) atomicOr(bad, 2);
+}
 
 SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
                               const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
@@ -650,6 +670,7 @@ SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, i
 
 SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
     if (!h) return SGL_OK;
+    h->epoch->store(~0ull);                // a chain graph captured on this handle refuses to replay from now on
     (void)hipFree(h->d_items);
     (void)hipFree(h->d_pieces);
     (void)hipFree(h->d_long_row);
@@ -669,9 +690,28 @@ SGL_EXPORT int sgl_csr_destroy(sgl_csr_t *h) {
 SGL_EXPORT int sgl_csr_set_rowmap(sgl_csr_t *h, const int32_t *d_rowmap, void *stream) {
     if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_set_rowmap: NULL handle");
     h->d_rowmap = nullptr;
+    h->epoch->fetch_add(1);
     if (!d_rowmap || h->n_rows == 0) return SGL_OK;
+    hipStream_t st = sgl::as_stream(stream);
+    {   // a map that is not a permutation would make every SpMM write rows out of bounds or leave rows unwritten: checked once
+        const size_t words = (size_t)(h->n_rows + 31) / 32;
+        unsigned *d_seen = nullptr;
+        SGL_HIP_CHECK(hipMalloc(&d_seen, (words + 1) * sizeof(unsigned)));
+        int *d_bad = reinterpret_cast<int *>(d_seen + words);
+        hipError_t e = hipMemsetAsync(d_seen, 0, (words + 1) * sizeof(unsigned), st);
+        int bad = 0;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rowmap_check_kernel, dim3((unsigned)((h->n_rows + 255) / 256)), dim3(256), 0, st, d_rowmap, h->n_rows, d_seen, d_bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_seen);
+        if (e != hipSuccess) return sgl::fail((int)e, "sgl_csr_set_rowmap: validation failed: %s", hipGetErrorString(e));
+        SGL_REQUIRE(!(bad & 1), "sgl_csr_set_rowmap: map entry outside [0, n_rows)");
+        SGL_REQUIRE(!(bad & 2), "sgl_csr_set_rowmap: the map names an output row twice (it must be a permutation)");
+    }
     if (h->n_long > 0) {   // the split rows' fix-up writes whole output rows: give it their mapped ids
-        hipStream_t st = sgl::as_stream(stream);
         std::vector<int32_t> map((size_t)h->n_rows), rows((size_t)h->n_long);
         SGL_HIP_CHECK(hipMemcpyAsync(map.data(), d_rowmap, map.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         SGL_HIP_CHECK(hipMemcpyAsync(rows.data(), h->d_long_row, rows.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -693,6 +733,7 @@ SGL_EXPORT int sgl_csr_set_rowmap(sgl_csr_t *h, const int32_t *d_rowmap, void *s
 SGL_EXPORT int sgl_csr_set_values(sgl_csr_t *h, const float *d_val) {
     if (!h) return sgl::fail(SGL_ERR_INVALID, "sgl_csr_set_values: NULL handle");
     SGL_REQUIRE(h->nnz == 0 || d_val, "sgl_csr_set_values: NULL values");
+    if (d_val != h->d_val) h->epoch->fetch_add(1);
     h->d_val = d_val;
     return SGL_OK;
 }
@@ -1008,6 +1049,8 @@ SGL_EXPORT int sgl_spmm_chain_f32(sgl_csr_t *h, int n_hops, const float *d_x0, i
 struct sgl_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    std::shared_ptr<std::atomic<uint64_t>> epoch;   // the handle's change counter and its value at capture time
+    uint64_t captured = 0;
 };
 
 SGL_EXPORT int sgl_chain_graph_create(sgl_graph_t **out, sgl_csr_t *h, int n_hops, const float *d_x0, int64_t ldx0,
@@ -1040,12 +1083,17 @@ SGL_EXPORT int sgl_chain_graph_create(sgl_graph_t **out, sgl_csr_t *h, int n_hop
         delete g;
         return sgl::fail((int)e, "sgl_chain_graph_create: capture/instantiate failed: %s", hipGetErrorString(e));
     }
+    g->epoch = h->epoch;
+    g->captured = h->epoch->load();
     *out = g;
     return SGL_OK;
 }
 
 SGL_EXPORT int sgl_chain_graph_launch(sgl_graph_t *g, void *stream) {
     if (!g || !g->exec) return sgl::fail(SGL_ERR_INVALID, "sgl_chain_graph_launch: NULL graph");
+    if (g->epoch && g->epoch->load() != g->captured)
+        return sgl::fail(SGL_ERR_INVALID, "sgl_chain_graph_launch: the adjacency handle changed after the capture (new values / row map, "
+                                          "or it was destroyed): capture the chain again");
     SGL_HIP_CHECK(hipGraphLaunch(g->exec, sgl::as_stream(stream)));
     return SGL_OK;
 }

@@ -287,7 +287,18 @@ def test_hip_graph_replay_of_a_propagation(goldens, cuda):
         graph.replay()
     side.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(outs, ref2))
+    # the capture bakes the value / row-map pointers in -- once they change the graph refuses to replay (it would
+    # silently compute with the old ones) and a fresh capture works
+    from sgl_amd._lib import SglHipError
+    csr.set_values(csr.val.clone() * 2.0)
+    with pytest.raises(SglHipError, match="changed after the capture"):
+        graph.replay()
     graph.close()
+    graph2 = csr.capture_chain(x, outs)
+    got2 = graph2.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b * 2.0 ** (h + 1)) for h, (a, b) in enumerate(zip(got2, ref2)))   # doubling is exact in fp32
+    graph2.close()
 
 
 def test_spmm_multi_writes_every_replica(goldens, cuda):
@@ -952,6 +963,17 @@ def test_community_reorder_is_transparent(cuda):
         cb.spmm_multi(xa, [ya.data_ptr(), yb.data_ptr()], ya.stride(0))
     cb.set_rowmap(None)                                                # without the map the stored order is what it is
     assert not torch.equal(ca.spmm(xa), cb.spmm(xa))
+    # the whole map is validated on the device -- out of range or not a permutation is an error, not a stray write
+    bad = rowmap.clone()
+    bad[5] = nb + 3
+    with pytest.raises(Exception, match="outside"):
+        cb.set_rowmap(bad)
+    dup = rowmap.clone()
+    dup[7] = dup[8]
+    with pytest.raises(Exception, match="permutation"):
+        cb.set_rowmap(dup)
+    cb.set_rowmap(rowmap)
+    assert same(ca.spmm(xa), cb.spmm(xa))
     with pytest.raises(ValueError):
         LaplacianGraphOp(2, reorder="rcm").propagate(adj, x)
 
