@@ -207,6 +207,10 @@ class GraphOp:
             self._adj.spmm_chain(views[0], K, outs=views[1:])
             return views
         src = dev.padded_parent(cur) if cur.stride(0) % 4 == 0 else cur
+        if self._opt("host_output"):
+            pooled = self._propagate_to_pooled_host(feature, cur, src, d, K)
+            if pooled is not None:
+                return pooled
         prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
 
         if self._opt("host_output"):
@@ -221,6 +225,55 @@ class GraphOp:
                 out.append(dev.download_rows(f))
             return out
         return prop_feat_list
+
+
+    def _propagate_to_pooled_host(self, feature, cur, src, d, K):
+        """host_output=True with destinations from the pinned pool (sgl_amd/hostpool.py): the hops are launched one by one and
+        every finished hop travels to its page-locked destination on a side stream WHILE the next hop is being computed -- the
+        call costs about the PCIe time of the hop matrices instead of PCIe + first-touch page faults + compute.  Same kernels,
+        same bits as the chained path.  Returns None when the pool has nothing to offer (then the staged path runs)."""
+        from .. import hostpool
+        n = cur.shape[0]
+        alias0 = isinstance(feature, np.ndarray) and feature.dtype == np.float32
+        need = K + (0 if alias0 else 1)
+        hosts = []
+        for _ in range(need):
+            h_ = hostpool.take((n, d))
+            if h_ is None:
+                return None
+            hosts.append(h_)
+        device = cur.device
+        main = torch.cuda.current_stream(device)
+        side = getattr(self, "_download_stream", None)
+        if side is None or side.device != device:
+            side = self._download_stream = torch.cuda.Stream(device=device)
+        out, keep = [], []
+
+        def send(t, host):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                host.copy_(t, non_blocking=True)
+
+        if alias0:
+            out.append(torch.from_numpy(feature))        # the reference's first element aliases the caller's array
+        else:
+            send(cur, hosts[0])
+            out.append(hosts[0])
+        prev = src
+        for h in range(K):
+            ypad = torch.empty((n, src.shape[1]), dtype=torch.float32, device=device)
+            if src.shape[1] != d:
+                ypad[:, d:].zero_()
+            self._adj.spmm(prev, out=ypad)
+            host = hosts[h + (0 if alias0 else 1)]
+            send(ypad[:, :d] if src.shape[1] != d else ypad, host)
+            out.append(host)
+            keep.append(ypad)
+            prev = ypad
+        side.synchronize()                                # the results are complete when the call returns (reference contract)
+        return out
 
 
 class MessageOp(nn.Module):

@@ -746,6 +746,35 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)
 
 
+def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
+    """host_output=True through the pooled, overlapped download (hops launched one by one, each travelling to a page-locked pooled
+    destination while the next is computed): CPU FloatTensors bit-equal to the device-resident hops, hop 0 aliases the caller's
+    array, results of an earlier call are never touched by a later one, and buffers nobody holds any more are recycled"""
+    from sgl_amd import hostpool
+    g = goldens.graph("pl2000")
+    for d in (100, 37):
+        x = hash_matrix(2000, d, seed=d)
+        dev_hops = LaplacianGraphOp(3, strict_order=True).propagate(g, x)
+        op = LaplacianGraphOp(3, strict_order=True, host_output=True)
+        first = op.propagate(g, x)
+        assert all((not t.is_cuda) and t.dtype == torch.float32 and t.shape == (2000, d) for t in first)
+        assert first[0].data_ptr() == x.ctypes.data and all(t.is_pinned() for t in first[1:])
+        assert all(torch.equal(h, dh.cpu()) for h, dh in zip(first[1:], dev_hops[1:]))
+        keep = [t.clone() for t in first]
+        second = op.propagate(g, x * 2.0)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(first[1:], keep[1:]))            # the first call's results are intact
+        assert {t.data_ptr() for t in first[1:]}.isdisjoint({t.data_ptr() for t in second[1:]})
+        assert all(torch.equal(s_, dh.cpu() * 2.0) for s_, dh in zip(second[1:], dev_hops[1:]))
+        ptrs = {t.data_ptr() for t in first[1:]}
+        reused = hostpool.stats["reused"]
+        del first, keep
+        third = op.propagate(g, torch.from_numpy(x))                                         # tensor input: hop 0 is downloaded too
+        assert hostpool.stats["reused"] >= reused + 3 and ptrs <= {t.data_ptr() for t in third}
+        assert all(torch.equal(t_, dh.cpu()) for t_, dh in zip(third, dev_hops))
+        del second, third
+    hostpool.trim()
+
+
 def test_hop_ranges_match_reference_goldens(goldens, cuda):
     """G8 (recorded from the reference): Mean's divisor is (end - start) whatever the slice held, partial / single-hop
     ranges; aggregate(propagate()) and the fused propagate_reduce both reproduce the reference -- sum / mean / last bit for

@@ -383,6 +383,31 @@ def test_adjacency_fingerprint_hashes_every_entry():
     assert _lib.content_hash(a) != h
 
 
+
+def test_host_result_pool_recycles_only_unreferenced_buffers():
+    """sgl_amd.hostpool (the destinations of host_output=True): a buffer is handed out again only when no tensor, view or numpy
+    array derived from it is alive -- results of earlier calls are never overwritten behind the caller's back"""
+    from sgl_amd import hostpool
+    before = dict(hostpool.stats)
+    a = hostpool.take((5000, 64), pinned=False)
+    a.fill_(3.0)
+    p = a.data_ptr()
+    b = hostpool.take((5000, 64), pinned=False)
+    assert b.data_ptr() != p and b.shape == (5000, 64) and b.dtype == torch.float32 and b.is_contiguous()
+    arr = a[100:200].numpy()                      # a numpy view of a view keeps the buffer out of circulation
+    del a
+    c = hostpool.take((5000, 64), pinned=False)
+    assert c.data_ptr() != p and float(arr[0, 0]) == 3.0
+    del arr
+    d = hostpool.take((5000, 64), pinned=False)
+    assert d.data_ptr() == p                      # nothing references it any more: recycled
+    assert hostpool.stats["reused"] == before["reused"] + 1 and hostpool.stats["allocated"] == before["allocated"] + 3
+    e = hostpool.take((5000, 60), pinned=False)   # another shape in the same size class may take a free buffer too
+    assert e is not None and e.shape == (5000, 60)
+    del b, c, d, e
+    hostpool.trim()
+
+
 def test_community_order_on_cpu_tensors():
     """sgl_amd.reorder.community_order_reference (the tensor-code statement of sgl_reorder_community): on a small
     planted-partition graph with shuffled ids it returns a permutation under which most edges join nodes of the same (now

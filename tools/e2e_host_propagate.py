@@ -15,9 +15,19 @@ x = np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)
 torch.cuda.synchronize()
 for host_out in (False, True):
     op = LaplacianGraphOp(3, r=0.5, host_output=host_out)
-    for call in ("first", "second (normalised adjacency cached)"):
+    for call in ("first", "second (normalised adjacency cached)", "third (host result buffers recycled from the first)", "fourth"):
         t0 = time.perf_counter()
         hops = op.propagate(adj, x)
         torch.cuda.synchronize()
         print(f"E2E host_output={host_out} {call}: {time.perf_counter() - t0:.3f} s for k=3 on N={n}, nnz(A)={adj.nnz}, d={d}", flush=True)
+    if host_out:
+        from sgl_amd import hostpool
+        ref = LaplacianGraphOp(3, r=0.5).propagate(adj, x)
+        print(f"E2E host pool: {hostpool.stats}; pinned results: {[bool(h.is_pinned()) for h in hops[1:]]}; "
+              f"bit-equal to the device-resident hops: {all(torch.equal(h, r_.cpu()) for h, r_ in zip(hops[1:], ref[1:]))}", flush=True)
+        t0 = time.perf_counter()
+        from sgl_amd.operators.base_op import AdjIdentity
+        fp = AdjIdentity.fingerprint(adj)
+        print(f"E2E full fingerprint of the scipy matrix (indptr + indices + data, {(adj.indices.nbytes + adj.data.nbytes + adj.indptr.nbytes) / 1e9:.2f} GB): "
+              f"{(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
     del hops, op
