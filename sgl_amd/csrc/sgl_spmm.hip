@@ -258,6 +258,11 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
             const int lim = min(je, cbr + 64);
             const int o = j - cbr;
             const int cnt = lim - j;
+            // slot of a non-zero = its index WITHIN ITS ROW mod R, not its index within this chunk: the chunk boundaries are
+            // the 64-element slices of the item's stream, i.e. they depend on which rows share the item.  With the row-relative
+            // assignment every slot adds the same terms in the same order under any plan and any processing order of the rows
+            // (row maps, other item sizes): packed layouts (d <= 64) are bit-reproducible across plans like the R = 1 walk.
+            const int sh = (R == 1) ? 0 : ((s - (j - jb)) & (R - 1));
             int t = 0;
             for (; t + R * U <= cnt; t += R * U) {
                 int c[U];
@@ -265,7 +270,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                 V xv[U][NCH];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int idx = o + t + u * R + s;
+                    const int idx = o + t + u * R + sh;
                     c[u] = bcast_i<R>(my_c, idx);
                     v[u] = bcast_f<R>(my_v, idx);
                 }
@@ -296,8 +301,8 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                     for (int ch = 0; ch < NCH; ++ch) vfma<VEC>(acc[ch], v[u], xv[u][ch]);
             }
             for (; t < cnt; t += R) {
-                const int idx = (o + t + s) & 63;
-                const bool valid = (t + s) < cnt;
+                const int idx = (o + t + sh) & 63;
+                const bool valid = (t + sh) < cnt;
                 const int c = bcast_i<R>(my_c, idx);
                 const float v = bcast_f<R>(my_v, idx);
                 if (valid) {

@@ -805,8 +805,14 @@ def gate_fusable(feats):
 
 
 def hop_gate(feats, v, b, return_weights=False):
-    """LearnableWeightedMessageOp 'gate' in one pass: (out, W) with W = softmax_h(sigmoid(Linear(X_h))) [n, H]"""
-    out, w = _GateFused.apply(v, b, *feats)
+    """LearnableWeightedMessageOp 'gate': (out, W) with W = softmax_h(sigmoid(Linear(X_h))) [n, H].  One pass over the hops
+    (sgl_hop_gate_f32) when their rows fit the register-resident kernel (gate_fusable); otherwise the two-pass route -- one
+    row-dot pass for the scores, the [n, H] sigmoid / softmax in torch, one weighted-sum pass."""
+    if gate_fusable(feats):
+        out, w = _GateFused.apply(v, b, *feats)
+    else:
+        w = torch.softmax(torch.sigmoid(hop_scores(feats, v) + b.reshape(-1)[0]), dim=1)
+        out = hop_wsum2d(feats, w)
     return (out, w) if return_weights else out
 
 

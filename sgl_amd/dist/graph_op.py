@@ -31,12 +31,13 @@ class ShardedGraphOp:
     (row-sharded layout only: grid layouts address ranks of the default group)."""
 
     def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None,
-                 device=None, row_groups=None, transport=None, symmetric=True):
+                 device=None, row_groups=None, transport=None, symmetric=True, reorder=None):
         self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
         self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
         self.device = device
         self.row_groups, self.transport = row_groups, transport
         self.symmetric = symmetric
+        self.reorder = reorder                # None / "community" / "auto": RowBlock inputs only (rows ordered inside the rank's block)
         self.lo = self.hi = self.c0 = self.c1 = None
         self._cache = None
         self._props = {}
@@ -74,7 +75,7 @@ class ShardedGraphOp:
                 self._cache[2] = gather_piece_bounds([blk.lo, blk.hi], self.group)
             return self._propagate_halo(x, self._cache[2], rank, world)
         if self._cache[1] is None:                           # full-replica transports: SpMM handles on global column ids
-            fns, handles, mine = block_piece_spmms(self.a_hat_block, self.pieces, strict=self.strict_order)
+            fns, handles, mine = block_piece_spmms(self.a_hat_block, self.pieces, strict=self.strict_order, reorder=self.reorder)
             self._cache[1:] = [fns, gather_piece_bounds(mine, self.group), handles]
         _, fns, pb, handles = self._cache
         if x.shape[0] == blk.n_local and x.shape[0] != n:
@@ -105,7 +106,7 @@ class ShardedGraphOp:
         halo = self._props.get("halo")
         if halo is None:
             bounds = pb[:, 0].tolist() + [int(pb[-1, -1])]
-            halo = self._props["halo"] = block_halo(blk, bounds, group=self.group, strict=self.strict_order)
+            halo = self._props["halo"] = block_halo(blk, bounds, group=self.group, strict=self.strict_order, reorder=self.reorder)
         plan, prop, _ = halo
         self._prop = prop
         self.halo_plan = plan

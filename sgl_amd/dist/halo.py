@@ -320,14 +320,27 @@ class HaloPropagator:
             self._pack(y, c)
 
 
-def block_halo(block, bounds, group=None, strict=False):
+def block_halo(block, bounds, group=None, strict=False, reorder=None):
     """Plan, propagator and SpMM handle for a NORMALISED RowBlock (rows [lo, hi) of A_hat, global column ids): the columns are
-    relabelled to the rank's compact table and the handle multiplies [n_own x n_compact].  Collective."""
-    from ..device import DeviceCSR
+    relabelled to the rank's compact table and the handle multiplies [n_own x n_compact].  Collective.
+    reorder: None / "community" / "auto" -- the rank's rows are STORED and PROCESSED in a locality order found on the block's own
+    diagonal part (sgl_amd.reorder.local_rowmap; no communication) behind a row map: outputs, ids and every row's terms keep
+    their order, the hops are bit-identical (plan.reorder_info says what was decided)."""
+    from ..device import DeviceCSR, permute_rows
+    from ..reorder import local_rowmap
     plan = HaloPlan(block.lo, block.hi, block.n, block.col, bounds, group)
+    plan.reorder_info = {"reorder": reorder}
     if block.n_local == 0:
         return plan, HaloPropagator(plan, lambda x, out: None), None
-    handle = DeviceCSR(block.rowptr, plan.relabel(block.col), block.val, (block.n_local, plan.n_compact), strict=strict)
+    rowptr, ccol, val = block.rowptr, plan.relabel(block.col), block.val
+    rowmap = None
+    if reorder and ccol.is_cuda:
+        rowmap, plan.reorder_info = local_rowmap(rowptr, ccol, 0, plan.n_own, reorder)   # own nodes = compact columns [0, n_own)
+        if rowmap is not None:
+            rowptr, ccol, val = permute_rows(rowptr, ccol, val, rowmap)
+    handle = DeviceCSR(rowptr, ccol, val, (block.n_local, plan.n_compact), strict=strict)
+    if rowmap is not None:
+        handle.set_rowmap(rowmap)
     return plan, HaloPropagator(plan, lambda x, out: handle.spmm(x, out=out)), handle
 
 

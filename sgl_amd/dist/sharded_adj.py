@@ -151,17 +151,27 @@ def local_piece_bounds(block, pieces, weights=None):
     return piece_bounds(rp_host, 0, block.n_local, pieces, weights) + block.lo, rp_host
 
 
-def block_piece_spmms(block, pieces, weights=None, strict=False):
+def block_piece_spmms(block, pieces, weights=None, strict=False, reorder=None):
     """One DeviceCSR (rows of the piece x all n columns) per local row piece, built from the rank's OWN rows only.
-    Returns (callables f(x_full, out), handles, absolute piece boundaries [pieces+1])."""
-    from ..device import DeviceCSR
+    Returns (callables f(x_full, out), handles, absolute piece boundaries [pieces+1]).
+    reorder (None / "community" / "auto"): every piece's rows are stored and processed in a locality order found on the piece's
+    own diagonal part, behind a row map (sgl_amd.reorder.local_rowmap): bit-identical results."""
+    from ..device import DeviceCSR, permute_rows
     pb, rp_host = local_piece_bounds(block, pieces, weights)
     fns, handles = [], []
     for p in range(pieces):
         r0, r1 = int(pb[p]) - block.lo, int(pb[p + 1]) - block.lo
         nb, ne = int(rp_host[r0]), int(rp_host[r1])
         rp_local = (block.rowptr[r0:r1 + 1] - block.rowptr[r0]).contiguous()
-        h = DeviceCSR(rp_local, block.col[nb:ne], block.val[nb:ne], (r1 - r0, block.n), strict=strict)
+        cc, vv, rowmap = block.col[nb:ne], block.val[nb:ne], None
+        if reorder and r1 > r0 and cc.is_cuda:
+            from ..reorder import local_rowmap
+            rowmap, _ = local_rowmap(rp_local, cc, int(pb[p]), int(pb[p + 1]), reorder)
+            if rowmap is not None:
+                rp_local, cc, vv = permute_rows(rp_local, cc.contiguous(), vv.contiguous(), rowmap)
+        h = DeviceCSR(rp_local, cc, vv, (r1 - r0, block.n), strict=strict)
+        if rowmap is not None:
+            h.set_rowmap(rowmap)
         handles.append(h)
         fns.append(lambda x, out, h=h: h.spmm(x, out=out))
     return fns, handles, pb

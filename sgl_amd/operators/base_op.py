@@ -86,8 +86,8 @@ class GraphOp:
         from .utils import adj_to_symmetric_norm_device
         r, alpha = self._norm_params()
         reorder = self._opt("reorder") or None
-        if reorder not in (None, "community"):
-            raise ValueError("reorder must be None or 'community'")
+        if reorder not in (None, "community", "auto"):
+            raise ValueError("reorder must be None, 'community' or 'auto'")
         params = (r, alpha, bool(self._opt("strict_order")), str(self._opt("device")), reorder)
         if self._opt("cache_adj") and self._adj is not None and self._adj_key is not None:
             ident, cached_params = self._adj_key
@@ -102,10 +102,11 @@ class GraphOp:
             # plan-time locality ordering (sgl_amd/reorder.py): the rows of A_hat are STORED in an order that keeps communities
             # together and processed in that order, so a gathered row of X is re-used while it is still in L2 / the Infinity
             # Cache.  Column ids, X, Y and the order of every row's terms stay the caller's: results are bit-identical.
-            from ..reorder import community_order
-            order, _ = community_order(rowptr, col, adj.shape[0])
-            rowmap = torch.argsort(order).to(torch.int32)           # rowmap[k] = node processed k-th
-            rowptr, col, val = dev.permute_rows(rowptr, col, val, rowmap)
+            # "auto" keeps the order only when it makes the graph measurably more local than its own ids do.
+            from ..reorder import plan_rowmap
+            rowmap, self.reorder_info = plan_rowmap(rowptr, col, adj.shape[0], reorder)   # rowmap[k] = node processed k-th
+            if rowmap is not None:
+                rowptr, col, val = dev.permute_rows(rowptr, col, val, rowmap)
         csr = dev.DeviceCSR(rowptr, col, val, adj.shape, strict=bool(self._opt("strict_order")))
         if rowmap is not None:
             csr.set_rowmap(rowmap)

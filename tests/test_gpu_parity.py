@@ -751,6 +751,7 @@ def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
     destination while the next is computed): CPU FloatTensors bit-equal to the device-resident hops, hop 0 aliases the caller's
     array, results of an earlier call are never touched by a later one, and buffers nobody holds any more are recycled"""
     from sgl_amd import hostpool
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
     g = goldens.graph("pl2000")
     for d in (100, 37):
         x = hash_matrix(2000, d, seed=d)
@@ -975,10 +976,10 @@ def test_community_reorder_is_transparent(cuda):
     ca = dev.DeviceCSR(rp, cc, vv, (nb, nb), long_row_nnz=256)
     cb = dev.DeviceCSR(rp2, c2, v2, (nb, nb), long_row_nnz=256).set_rowmap(rowmap)
     assert cb.info()["n_long_rows"] > 0 and cb.info()["n_pieces"] > 0
-    for dd in (100, 36):
-        # d > 64 (one non-zero per step, a row = one fmaf chain): bit-identical.  d <= 64 packs several non-zeros per step and
-        # a row's partial sums depend on where it sits in its item (as they do between two plans of the same matrix): 1e-5
-        same = (lambda a, b: torch.equal(a, b)) if dd > 64 else (lambda a, b: oracle.parity_ok(b.cpu().numpy(), a.cpu().numpy(), 1e-5))
+    for dd in (100, 36, 16, 7):
+        # d > 64: one non-zero per step, a row = one fmaf chain.  d <= 64 packs several non-zeros per step; a non-zero's slot is
+        # its index WITHIN ITS ROW mod R, so the partial sums do not depend on where the row sits in its item: bit-identical too
+        same = torch.equal
         xa = dev.upload_rows(hash_matrix(nb, dd, seed=8), cuda)
         assert same(ca.spmm(xa), cb.spmm(xa)), dd
         res = dev.upload_rows(hash_matrix(nb, dd, seed=12), cuda)
@@ -1005,6 +1006,67 @@ def test_community_reorder_is_transparent(cuda):
     assert same(ca.spmm(xa), cb.spmm(xa))
     with pytest.raises(ValueError):
         LaplacianGraphOp(2, reorder="rcm").propagate(adj, x)
+
+
+@pytest.mark.parametrize("d", [4, 8, 16, 24, 36, 50, 64, 100])
+def test_two_plans_of_one_matrix_agree_bit_for_bit(goldens, cuda, d):
+    """item size, long-row threshold, XCD remap and gathers in flight only change HOW the rows are walked: every row's terms are
+    added in the same order and -- in the packed layouts of narrow matrices -- by the same slots, so the products are bit-equal
+    (pieces of split rows are cut relative to the row, so they agree as well)"""
+    from sgl_amd import _lib
+    from sgl_amd import device as dev
+    n, ptr, col, val = norm_graph(goldens, "pl2000")
+    x = dev.upload_rows(hash_matrix(n, d, seed=d), cuda)
+    base = device_csr(ptr, col, val, (n, n), cuda).spmm(x)
+    for kw in (dict(item_nnz=64), dict(item_nnz=2048), dict(item_nnz=200, xcd_remap=False)):
+        assert torch.equal(device_csr(ptr, col, val, (n, n), cuda, **kw).spmm(x), base), kw
+    for unroll in (1, 2, 3):
+        _lib.set_tuning("spmm_unroll", unroll)
+        try:
+            assert torch.equal(device_csr(ptr, col, val, (n, n), cuda, item_nnz=300).spmm(x), base), unroll
+        finally:
+            _lib.set_tuning("spmm_unroll", 0)
+
+
+def test_reorder_auto_and_row_sharded_blocks(cuda):
+    """reorder="auto": the label-propagation order is kept only when it makes the graph measurably more local than its own ids
+    (planted communities behind shuffled ids: applied; the same graph in its natural order or a random graph: left alone).
+    Row-sharded storage: ShardedGraphOp(reorder=...) orders the rows inside the rank's block (found on the block's diagonal part)
+    behind a row map, for the need-aware exchange and for the full-replica pieces alike -- hops bit-identical, any width."""
+    from sgl_amd import reorder
+    from sgl_amd.dist import RowBlock, ShardedGraphOp
+    from sgl_amd.io import DeviceAdjacency
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    n, bs = 6000, 150
+    adj0 = _planted_communities(n, bs, 14, 0.9, seed=11)
+    shuffle = np.random.default_rng(3).permutation(n)
+    P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
+    adj = (P @ adj0 @ P.T).tocsr()
+    adj.sort_indices()
+    rnd = _planted_communities(n, bs, 14, 0.0, seed=12)               # no community structure at all
+    for graph, expect in ((adj, True), (adj0, False), (rnd, False)):
+        for d in (100, 24):
+            x = hash_matrix(n, d, seed=d)
+            plain = LaplacianGraphOp(2, r=0.5).propagate(graph, x)
+            op = LaplacianGraphOp(2, r=0.5, reorder="auto")
+            got = op.propagate(graph, x)
+            assert all(torch.equal(a, b) for a, b in zip(plain, got))
+            info = op.reorder_info
+            assert info["applied"] is expect and (op._adj.rowmap is not None) == expect, info
+            assert (info["edge_locality_after"] >= info["edge_locality_before"] + reorder.AUTO_MIN_GAIN) == expect, info
+    # the rank's row block (world 1: the whole matrix) through both row-sharded code paths
+    da = DeviceAdjacency.from_scipy(adj, device=cuda)
+    blk = RowBlock(0, n, n, da.rowptr, da.col, da.val)
+    for d in (128, 36):
+        x = torch.from_numpy(hash_matrix(n, d, seed=d + 1)).to(cuda)
+        want = ShardedGraphOp(3, r=0.5, pieces=2, col_chunks=1).propagate(blk, x)
+        for kw in (dict(transport="halo"), dict(transport="p2p", pieces=3)):
+            for mode in ("community", "auto"):
+                op = ShardedGraphOp(3, r=0.5, col_chunks=1, reorder=mode, **{"pieces": 2, **kw})
+                got = op.propagate(blk, x)
+                assert all(torch.equal(a, b) for a, b in zip(want, got)), (d, kw, mode)
+                if kw["transport"] == "halo":
+                    assert op.halo_plan.reorder_info["applied"] is True and op._props["halo"][2].rowmap is not None
 
 
 def test_aggregators_fuzz_random_shapes(cuda):
@@ -1091,8 +1153,17 @@ def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
     b = torch.randn(1, generator=g).to(cuda).requires_grad_(True)
     gout = torch.randn(n, d, generator=g).to(cuda)
     assert dev.gate_fusable(feats)
-    fx = [f.clone().requires_grad_(True) for f in feats]
+    fx = []
+    for f in feats:                                           # row-padded like the hops GraphOp.propagate produces: the fused kernel
+        t = dev.alloc_rows(n, d, cuda)
+        t.copy_(f)
+        fx.append(t.requires_grad_(True))
     y, w = dev.hop_gate(fx, v, b, return_weights=True)
+    # hops whose rows are not 16-byte aligned (a dense [n, 147] tensor) take the two-pass route behind the same call
+    if d % 4:
+        yd, wd = dev.hop_gate([f.contiguous().clone() for f in feats], v.detach(), b.detach(), return_weights=True)
+        assert torch.allclose(wd, w.detach(), rtol=1e-5, atol=1e-6)
+        assert oracle.parity_ok(yd.cpu().numpy(), y.detach().cpu().numpy(), 2e-6, rowwise=False)
     # (a) two-pass route, same kernels' arithmetic for the dots and the FMA sum
     sc = dev.hop_scores(feats, v.detach()) + b.detach()
     w2 = torch.softmax(torch.sigmoid(sc), dim=1)
