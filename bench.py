@@ -91,17 +91,30 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
         if time.perf_counter() - t_all > budget_s:
             break
     t = float(np.median(times))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
-    cpu_model = "unknown CPU"
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    threads = int(os.environ.get("OMP_NUM_THREADS", len(cpus)))
+    cpu_model, physical = "unknown CPU", None
     try:
+        # hardware threads -> physical cores: distinct (package, core id) pairs among the CPUs this process may run on
+        seen, cur = set(), {}
         with open("/proc/cpuinfo") as f:
-            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+            for line in f:
+                if ":" in line:
+                    k, v = (p_.strip() for p_ in line.split(":", 1))
+                    cur[k] = v
+                    if k == "model name" and cpu_model == "unknown CPU":
+                        cpu_model = v
+                elif cur:
+                    if int(cur.get("processor", -1)) in cpus and "core id" in cur:
+                        seen.add((cur.get("physical id", "0"), cur["core id"]))
+                    cur = {}
+        physical = len(seen) or None
     except Exception:  # noqa: BLE001
         pass
-    out = {"value": nnz_s * d / t, "unit": "edge\u00b7featdim/s", "cores": threads, "kind": kind,
+    cores = min(threads, physical) if physical else threads
+    out = {"value": nnz_s * d / t, "unit": "edge\u00b7featdim/s", "cores": cores, "threads": threads, "kind": kind,
            "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}{compacted}, one hop, median of {len(times)} reps, "
-                     f"OpenMP static schedule, {threads} threads on {cpu_model}",
+                     f"OpenMP static schedule, {threads} threads on {cores} physical cores of {cpu_model}",
            "ms_per_hop_sample": t * 1e3}
     # B2 of BASELINE.md: the reference's non-Linux branch `adj.dot(x)` (base_op.py:34), scipy, single thread, on a
     # smaller slice of the same rows (bounded: a few seconds)

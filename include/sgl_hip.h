@@ -110,16 +110,6 @@ int sgl_csr_info(const sgl_csr_t *csr, int64_t info[8]);
 int sgl_spmm_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                  int accumulate, void *stream);
 
-/* Split feature layout for widths just above a multiple of 32 floats (d = 100: 96 + 4).  The gather is bound by the
- * number of 128-byte lines per row; columns [0, d_main) are read from the main matrix (rows 128-byte aligned, d_main a
- * multiple of 32 floats: exactly d_main/32 lines), the remaining <= 8 columns from a packed side table d_xt
- * [n_cols, ldxt] (ldxt = 4 or 8 floats: 8 or 4 rows per line).  Y is produced in the same layout: main columns in d_y,
- * tail columns in d_yt (may be NULL) and, if tail_full != 0, also in columns [d_main, d) of d_y.  Same arithmetic as
- * sgl_spmm_f32 (one fmaf chain per (row, column) in CSR order).  Pad columns of the tail tables must be zero. */
-int sgl_spmm_tail_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, const float *d_xt, int64_t ldxt, float *d_y,
-                      int64_t ldy, float *d_yt, int64_t ldyt, int64_t d, int64_t d_main, int tail_full, int accumulate,
-                      void *stream);
-
 /* Y_0 = Y_1 = ... = A . X stored into n_out (1..8) matrices with a common leading dimension.  h_y: HOST array of
  * device pointers; entries beyond the first may point into peer GPUs' memory (IPC / symmetric memory): the kernel
  * then pushes each finished row to every replica over xGMI (row-sharded multi-GPU propagation). */
@@ -185,7 +175,7 @@ int sgl_csr_permute_rows(const int64_t *d_rowptr, const int32_t *d_col, const fl
                          int64_t *d_out_rowptr, int32_t *d_out_col, float *d_out_val, void *stream);
 /* Storage row i of the handle is output row d_rowmap[i] (a permutation of 0..n_rows-1; NULL removes the map; the array must
  * outlive its use).  Applies to sgl_spmm_f32 / _chain / _acc / _axpb_clamp (outputs, residual and running aggregate are addressed
- * through the map); the split layout and sgl_spmm_multi_f32 refuse a mapped handle. */
+ * through the map); sgl_spmm_multi_f32 refuses a mapped handle. */
 int sgl_csr_set_rowmap(sgl_csr_t *csr, const int32_t *d_rowmap, void *stream);
 
 /* ---- multi-GPU exchange (row-sharded layout): the all-gather of the feature block between hops ---------------- */

@@ -129,23 +129,7 @@ struct SpmmArgs {
     float *y_more[7];
     int32_t n_more;
     const uint8_t *row_mask;   // optional [n_rows]: bit q set = replica q needs this row (NULL = every replica gets it)
-    // optional split feature layout (sgl_spmm_tail_f32): columns [d_main, d) of X are gathered from a packed side table
-    // xt [n_cols, ldxt] instead of from the 4th cache line of the main row; yt (optional) receives the same columns of Y
-    const float *xt;
-    float *yt;
-    int64_t ldxt, ldyt;
-    int32_t d_main, tail_full, tail_nt;
     const int32_t *rowmap;     // optional [n_rows]: storage row -> output row (sgl_csr_set_rowmap); NULL = identity
-};
-
-struct TailArgs {
-    const float *xt;   // packed tail columns of X
-    int64_t ldxt;
-    float *ot;         // tail table of the output, already offset to the item's first row (may be nullptr)
-    int64_t ldot;
-    int d_main;        // columns [0, d_main) come from / go to the main matrices
-    int full;          // also store the tail columns into the main output row
-    int nt_main;       // experiment: main-row gathers as separate non-temporal loads (keeps the tail table in L2)
 };
 
 struct MultiOut {
@@ -193,16 +177,15 @@ struct RowMap {
     bool on = false;
 };
 
-template <int VEC, int GROUP, int NCH, int U, bool NT, bool MULTI, bool TAIL = false>
+template <int VEC, int GROUP, int NCH, int U, bool NT, bool MULTI>
 __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const float *__restrict__ valb,
                                          const int my_rel, const int nrows, const int tot,
                                          const float *__restrict__ x, const int64_t ldx, float *__restrict__ out,
                                          const int64_t ldo, const int d, const bool accumulate, const int lane,
                                          const Epilogue epi, const int64_t ldres, const MultiOut mo,
-                                         const TailArgs ta = TailArgs(), const RowMap rm = RowMap()) {
+                                         const RowMap rm = RowMap()) {
     using V = typename VecT<VEC>::type;
     constexpr int R = 64 / GROUP;
-    static_assert(!TAIL || (R == 1 && NCH == 1 && VEC == 4 && !MULTI), "split layout: one 16-byte lane per 4 columns");
     const int s = (R == 1) ? 0 : (lane / GROUP);
     const int l = lane % GROUP;
     int colofs[NCH];
@@ -212,15 +195,6 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
         colofs[ch] = (ch * GROUP + l) * VEC;
         on[ch] = colofs[ch] < d;
     }
-    // split layout: every lane gathers from its own (base, row stride) -- the main rows or the packed tail table
-    const bool is_tail = TAIL && colofs[0] >= ta.d_main;
-    const float *gx = x + colofs[0];
-    int64_t gs = ldx;
-    if (TAIL && is_tail) {
-        gx = ta.xt + (colofs[0] - ta.d_main);
-        gs = ta.ldxt;
-    }
-
     // current / next 64-element slice of the (col,val) stream, one element per lane
     int cbr = 0;
     int my_c = 0, nx_c = 0;
@@ -243,15 +217,9 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) acc[ch] = vzero<VEC>();
         if (accumulate && s == 0) {
-            if constexpr (TAIL) {
-                if (on[0])
-                    acc[0] = (is_tail && ta.ot) ? *reinterpret_cast<const V *>(ta.ot + ro * ta.ldot + (colofs[0] - ta.d_main))
-                                                : *reinterpret_cast<const V *>(orow + colofs[0]);
-            } else {
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch)
-                    if (on[ch]) acc[ch] = *reinterpret_cast<const V *>(orow + colofs[ch]);
-            }
+            for (int ch = 0; ch < NCH; ++ch)
+                if (on[ch]) acc[ch] = *reinterpret_cast<const V *>(orow + colofs[ch]);
         }
         int j = jb;
         while (j < je) {
@@ -278,18 +246,8 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                 for (int ch = 0; ch < NCH; ++ch) {
                     if (on[ch]) {
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if constexpr (TAIL) {
-                                const V *gp = reinterpret_cast<const V *>(gx + (int64_t)c[u] * gs);
-                                if (ta.nt_main) {
-                                    if (is_tail) xv[u][ch] = *gp;
-                                    else xv[u][ch] = __builtin_nontemporal_load(gp);
-                                } else {
-                                    xv[u][ch] = *gp;
-                                }
-                            } else
-                                xv[u][ch] = *reinterpret_cast<const V *>(x + (int64_t)c[u] * ldx + colofs[ch]);
-                        }
+                        for (int u = 0; u < U; ++u)
+                            xv[u][ch] = *reinterpret_cast<const V *>(x + (int64_t)c[u] * ldx + colofs[ch]);
                     } else {
 #pragma unroll
                         for (int u = 0; u < U; ++u) xv[u][ch] = vzero<VEC>();
@@ -309,8 +267,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch)
                         if (on[ch]) {
-                            const V xv = TAIL ? *reinterpret_cast<const V *>(gx + (int64_t)c * gs)
-                                              : *reinterpret_cast<const V *>(x + (int64_t)c * ldx + colofs[ch]);
+                            const V xv = *reinterpret_cast<const V *>(x + (int64_t)c * ldx + colofs[ch]);
                             vfma<VEC>(acc[ch], v, xv);
                         }
                 }
@@ -359,13 +316,7 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                         }
                         *reinterpret_cast<V *>(ap) = a;   // (non-temporal hints on this stream measured slower: +4.4 vs +4.1 ms / 10 hops)
                     }
-                    if constexpr (TAIL) {
-                        if (!is_tail || ta.full) st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
-                        if (is_tail && ta.ot)
-                            *reinterpret_cast<V *>(ta.ot + ro * ta.ldot + (colofs[ch] - ta.d_main)) = v;
-                    } else {
-                        st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
-                    }
+                    st_stream<NT>(reinterpret_cast<V *>(orow + colofs[ch]), v);
                     if constexpr (MULTI) {
                         const int need = mo.mask ? (int)mo.mask[ri] : 0x7f;   // wave-uniform: one byte per row
 #pragma unroll
@@ -437,63 +388,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         for (int q = 0; q < 7; ++q) mo.p[q] = (MULTI && q < a.n_more) ? a.y_more[q] + (int64_t)row_begin * a.ldy : nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, MULTI>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
                                          a.y + first * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
-                                         a.ldres, mo, TailArgs(), rm);
-    }
-}
-
-// Split feature layout (sgl_spmm_tail_f32): same walk as spmm_kernel<4, 64, 1, U>, but the lanes beyond column d_main
-// gather from / store to the packed tail tables.  Long-row pieces write whole partial rows (main + tail columns).
-template <int U, bool NT>
-__global__ __launch_bounds__(256) void spmm_tail_kernel(const SpmmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x;
-    Epilogue none;
-    none.res = nullptr;
-    none.alpha = 1.f;
-    none.lo = none.hi = 0.f;
-    none.on = 0;
-    none.acc = nullptr;
-    none.ldacc = 0;
-    none.acc_w = none.acc_div = 1.f;
-    none.acc_mode = 0;
-    MultiOut solo;
-    solo.n = 0;
-    solo.mask = nullptr;
-    TailArgs ta;
-    ta.xt = a.xt;
-    ta.ldxt = a.ldxt;
-    ta.d_main = a.d_main;
-    ta.nt_main = a.tail_nt;
-    if (b < a.piece_blocks) {
-        const int p = b * a.waves + wave;
-        if (p >= a.n_pieces) return;
-        const sgl::Piece pc = a.pieces[p];
-        const int my_rel = (lane == 0) ? 0 : pc.len;
-        ta.ot = nullptr;
-        ta.ldot = 0;
-        ta.full = 1;
-        run_rows<4, 64, 1, U, NT, false, true>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
-                                               a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0, solo, ta);
-    } else {
-        int ib = b - a.piece_blocks;
-        if (a.xcd_remap) ib = (ib & 7) * a.item_blocks_per_xcd + (ib >> 3);
-        const int item = ib * a.waves + wave;
-        if (item >= a.n_items) return;
-        const int row_begin = a.items[2 * item], row_end = a.items[2 * item + 1];
-        const int nrows = row_end - row_begin;
-        const int64_t rp = a.rowptr[(int64_t)row_begin + min(lane, nrows)];
-        const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)rp);
-        const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)rp >> 32));
-        const int64_t base = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-        const int my_rel = (int)(rp - base);
-        const int tot = __builtin_amdgcn_readlane(my_rel, nrows);
-        ta.ot = a.yt ? a.yt + (int64_t)row_begin * a.ldyt : nullptr;
-        ta.ldot = a.ldyt;
-        ta.full = a.tail_full;
-        run_rows<4, 64, 1, U, NT, false, true>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
-                                               a.y + (int64_t)row_begin * a.ldy, a.ldy, a.d, a.accumulate != 0, lane,
-                                               none, 0, solo, ta);
+                                         a.ldres, mo, rm);
     }
 }
 
@@ -503,8 +398,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
                                                          const float *__restrict__ partial, int64_t ldp,
                                                          float *__restrict__ y, int64_t ldy, int d, int accumulate,
                                                          const float *__restrict__ res, int64_t ldres, Epilogue epi,
-                                                         MultiOut mo, float *__restrict__ yt, int64_t ldyt, int d_main,
-                                                         int tail_full) {
+                                                         MultiOut mo) {
     const int kblocks = (d + 255) / 256;
     const int lr = blockIdx.x / kblocks;
     const int k = (blockIdx.x % kblocks) * 256 + threadIdx.x;
@@ -512,17 +406,14 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     const int row = long_row[lr];
     const int p0 = long_first[lr], p1 = long_first[lr + 1];
     float *yp = y + (int64_t)row * ldy + k;
-    float *tp = (yt && k >= d_main) ? yt + (int64_t)row * ldyt + (k - d_main) : nullptr;   // split layout: tail table
-    const bool main_too = !(k >= d_main) || tail_full;
-    float acc = accumulate ? (tp ? *tp : *yp) : 0.f;
+    float acc = accumulate ? *yp : 0.f;
     for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * ldp + k];
     if (epi.on) acc = epi_apply(acc, res ? res[(int64_t)row * ldres + k] : 0.f, epi, res != nullptr);
     if (epi.acc) {   // here epi.acc is the matrix base (rows are absolute in the fix-up)
         float *ap = epi.acc + (int64_t)row * epi.ldacc + k;
         *ap = acc_apply(*ap, acc, epi);
     }
-    if (main_too) *yp = acc;
-    if (tp) *tp = acc;
+    *yp = acc;
     const int need = mo.mask ? (int)mo.mask[row] : 0x7f;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
@@ -778,11 +669,6 @@ struct EpiHost {
     int64_t ldacc = 0;
     float acc_w = 1.f, acc_div = 1.f;
     int acc_mode = 0;
-    // split layout (sgl_spmm_tail_f32)
-    const float *xt = nullptr;
-    float *yt = nullptr;
-    int64_t ldxt = 0, ldyt = 0;
-    int d_main = 0, tail_full = 1;
 };
 
 static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int d, int vec,
@@ -800,12 +686,8 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         group = 8;
         while (group < lanes) group <<= 1;
     }
-    if (eh.xt) {   // split layout: always the one-row-per-step lane layout
-        group = 64;
-        nch = 1;
-    }
     const int64_t forced = sgl::tuning("spmm_group", 0);
-    if ((forced == 8 || forced == 16 || forced == 32 || forced == 64) && !eh.xt) {
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64) {
         if (nch == 1 && forced >= lanes) group = (int)forced;
     }
     // gathers in flight per lane: 16 for the one-row-per-step layout, 8 for the packed ones (0 = this default).  A row's
@@ -858,13 +740,6 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.n_more = eh.n_more;
     a.row_mask = eh.row_mask;
     for (int q = 0; q < 7; ++q) a.y_more[q] = eh.y_more[q];
-    a.xt = eh.xt;
-    a.yt = eh.yt;
-    a.ldxt = eh.ldxt;
-    a.ldyt = eh.ldyt;
-    a.d_main = eh.xt ? eh.d_main : d;
-    a.tail_full = eh.xt ? eh.tail_full : 1;
-    a.tail_nt = sgl::tuning("spmm_tail_nt", 0) != 0 ? 1 : 0;
     a.rowmap = h->d_rowmap;
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
@@ -888,22 +763,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.partial = h->d_partial;
     if (grid64 == 0) return SGL_OK;
     hipError_t e;
-    if (eh.xt) {
-        // split layout: one 16-byte lane per 4 columns, the whole wavefront on one non-zero per step
-        if (!(vec == 4 && nch == 1 && group == 64 && eh.n_more == 0 && !eh.on))
-            return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_spmm_tail_f32: needs 16-byte aligned rows and d <= 256");
-        if (ulevel == 0) {
-            if (nt) hipLaunchKernelGGL((spmm_tail_kernel<8, true>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-            else hipLaunchKernelGGL((spmm_tail_kernel<8, false>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-        } else if (ulevel == 3) {
-            if (nt) hipLaunchKernelGGL((spmm_tail_kernel<32, true>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-            else hipLaunchKernelGGL((spmm_tail_kernel<32, false>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-        } else {
-            if (nt) hipLaunchKernelGGL((spmm_tail_kernel<16, true>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-            else hipLaunchKernelGGL((spmm_tail_kernel<16, false>), dim3((int)grid64), dim3(64 * a.waves), 0, st, a);
-        }
-        e = hipGetLastError();
-    } else if (vec == 4)
+    if (vec == 4)
         e = launch_group<4>(a, (int)grid64, st, nt, ulevel, group, nch);
     else if (vec == 2)
         e = launch_group<2>(a, (int)grid64, st, nt, ulevel, group, nch);
@@ -930,7 +790,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         for (int q = 0; q < 7; ++q) fmo.p[q] = eh.y_more[q];
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_rowmap ? h->d_long_out : h->d_long_row,
                            h->d_long_first, h->d_partial, a.ldp,
-                           d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo, a.yt, a.ldyt, a.d_main, a.tail_full);
+                           d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo);
         e = hipGetLastError();
         if (e != hipSuccess) return sgl::fail((int)e, "sgl_spmm_f32: fix-up launch failed: %s", hipGetErrorString(e));
     }
@@ -943,11 +803,8 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
     SGL_REQUIRE(d >= 0 && d < INT32_MAX, "%s: bad d", who);
     if (d == 0 || h->n_rows == 0) return SGL_OK;
     SGL_REQUIRE(d_x && d_y, "%s: NULL X or Y", who);
-    if (h->d_rowmap && (eh.xt || eh.n_more > 0))
-        return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: a row-mapped handle supports neither the split layout nor replicas", who);
-    if (eh.xt)   // split layout (validated by the caller): the kernel walks d_main + padded tail columns
-        return spmm_slice(h, d_x, ldx, d_y, ldy, eh.d_main + (int)((d - eh.d_main + 3) / 4 * 4), 4, accumulate,
-                          sgl::as_stream(stream), eh);
+    if (h->d_rowmap && eh.n_more > 0)
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: a row-mapped handle does not support replicas", who);
     SGL_REQUIRE(ldx >= d && ldy >= d, "%s: leading dimension smaller than d", who);
     SGL_REQUIRE(aligned_to(d_x, 4) && aligned_to(d_y, 4), "%s: X/Y not 4-byte aligned", who);
     hipStream_t st = sgl::as_stream(stream);
@@ -986,35 +843,6 @@ static int spmm_impl(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, in
 SGL_EXPORT int sgl_spmm_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d,
                             int accumulate, void *stream) {
     return spmm_impl(h, d_x, ldx, d_y, ldy, d, accumulate, stream, EpiHost(), "sgl_spmm_f32");
-}
-
-// Split feature layout.  The kernel is bound by the number of 128-byte lines it pulls per gathered row; a 400-byte row
-// (d = 100) touches four although 3.125 hold its data.  Here columns [0, d_main) (d_main a multiple of 32 floats, rows
-// 128-byte aligned: exactly d_main/32 lines) come from the main matrix and the remaining <= 8 columns from a packed side
-// table [n_cols, ldxt] in which 8 (4) rows share one line, gathered by otherwise idle lanes of the same instruction.
-// The product is written in the same layout: main columns to d_y, tail columns to d_yt (if not NULL) and, when
-// tail_full != 0, also to columns [d_main, d) of d_y so that d_y alone is the ordinary [n_rows, d] matrix.
-SGL_EXPORT int sgl_spmm_tail_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, const float *d_xt, int64_t ldxt, float *d_y,
-                                 int64_t ldy, float *d_yt, int64_t ldyt, int64_t d, int64_t d_main, int tail_full,
-                                 int accumulate, void *stream) {
-    SGL_REQUIRE(d_xt != nullptr, "sgl_spmm_tail_f32: NULL tail table");
-    SGL_REQUIRE(d_main > 0 && d_main % 4 == 0 && d_main < d && d - d_main <= 8 && d <= 256,
-                "sgl_spmm_tail_f32: need 0 < d_main < d <= 256, d_main %% 4 == 0, at most 8 tail columns");
-    const int64_t tw = (d - d_main + 3) / 4 * 4;
-    SGL_REQUIRE(ldxt >= tw && ldxt % 4 == 0 && aligned_to(d_xt, 16), "sgl_spmm_tail_f32: X tail table must be 16-byte aligned rows");
-    SGL_REQUIRE(!d_yt || (ldyt >= tw && ldyt % 4 == 0 && aligned_to(d_yt, 16)), "sgl_spmm_tail_f32: Y tail table must be 16-byte aligned rows");
-    SGL_REQUIRE(d_yt || tail_full, "sgl_spmm_tail_f32: the tail columns of Y need a destination");
-    SGL_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && aligned_to(d_x, 16) && aligned_to(d_y, 16) && ldx >= d_main &&
-                    ldy >= (tail_full ? d_main + tw : d_main),
-                "sgl_spmm_tail_f32: main matrices must have 16-byte aligned rows");
-    EpiHost eh;
-    eh.xt = d_xt;
-    eh.ldxt = ldxt;
-    eh.yt = d_yt;
-    eh.ldyt = ldyt;
-    eh.d_main = (int)d_main;
-    eh.tail_full = tail_full ? 1 : 0;
-    return spmm_impl(h, d_x, ldx, d_y, ldy, d, accumulate, stream, eh, "sgl_spmm_tail_f32");
 }
 
 // Y_0 = Y_1 = ... = A X: the product is stored into n_out matrices (same leading dimension).  Matrix 0 is normally

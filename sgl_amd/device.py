@@ -264,23 +264,6 @@ class DeviceCSR:
                   "sgl_spmm_acc_f32")
         return out
 
-    def spmm_tail(self, x_main, x_tail, y_main, y_tail, d, d_main, tail_full=False, accumulate=False):
-        """A @ X in the split layout (sgl_spmm_tail_f32): columns [0, d_main) live in the *_main matrices (128-byte
-        aligned rows), columns [d_main, d) in the packed *_tail tables [n, 4 or 8]."""
-        for t, nm in ((x_main, "x_main"), (x_tail, "x_tail"), (y_main, "y_main")):
-            _check_mat(t, nm)
-        if y_tail is not None:
-            _check_mat(y_tail, "y_tail")
-        if x_main.shape[0] != self.shape[1] or x_tail.shape[0] != self.shape[1] or y_main.shape[0] != self.shape[0]:
-            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
-        with torch.cuda.device(self.device):
-            check(lib().sgl_spmm_tail_f32(self._h, ptr(x_main), _ld(x_main), ptr(x_tail), _ld(x_tail), ptr(y_main),
-                                          _ld(y_main), ptr(y_tail) if y_tail is not None else None,
-                                          _ld(y_tail) if y_tail is not None else 0, int(d), int(d_main),
-                                          int(bool(tail_full)), int(bool(accumulate)), current_stream_ptr()),
-                  "sgl_spmm_tail_f32")
-        return y_main, y_tail
-
     def spmm_multi(self, x, out_ptrs, ld, row_mask=None):
         """A @ x stored into several [n_rows, d] matrices given as RAW device addresses (the first is normally local,
         the others peer-GPU replicas mapped through IPC) with leading dimension `ld`.  row_mask: optional uint8 CUDA

@@ -127,52 +127,6 @@ def test_spmm_long_rows_empty_rows_and_splitting(cuda, strict):
             assert np.array_equal(y, y2)
 
 
-@pytest.mark.parametrize("d", [100, 98, 132, 40, 36, 225])
-def test_spmm_split_layout_is_bit_exact(cuda, d):
-    """sgl_spmm_tail_f32 (main block of whole cache lines + packed tail table) = the same fmaf chains as the plain layout:
-    bit-exact vs the oracle in strict order, incl. empty rows, and equal to the plain kernel when long rows are split."""
-    a = long_row_graph()
-    n = a.shape[0]
-    dm = d // 32 * 32
-    tw = (d - dm + 3) // 4 * 4
-    x = hash_matrix(n, d, seed=d)
-    ref = oracle.oracle_spmm(a.indptr, a.indices, a.data, x)
-    xm = torch.zeros((n, dm), device=cuda)
-    xm.copy_(torch.from_numpy(np.ascontiguousarray(x[:, :dm])))
-    xt = torch.zeros((n, tw), device=cuda)
-    xt[:, :d - dm] = torch.from_numpy(np.ascontiguousarray(x[:, dm:])).to(cuda)
-    # narrow matrices (d <= 64) pack several non-zeros per step in the plain fast layout (another summation order), so
-    # there the comparison with the plain kernel is made in strict order only
-    for strict, long_nnz in (((True, 0), (False, 256), (False, 100)) if d > 64 else ((True, 0),)):
-        csr = device_csr(a.indptr, a.indices, a.data, (n, n), cuda, strict=strict, item_nnz=64, long_row_nnz=long_nnz)
-        plain = csr.spmm(torch.from_numpy(x).to(cuda))
-        # (a) split output: main [n, dm] + tail [n, tw]
-        ym = torch.full((n, dm), 7.0, device=cuda)
-        yt = torch.full((n, tw), 7.0, device=cuda)
-        csr.spmm_tail(xm, xt, ym, yt, d, dm)
-        got = torch.cat([ym, yt[:, :d - dm]], dim=1)
-        assert torch.equal(got, plain), (d, strict, long_nnz)
-        if strict:
-            assert np.array_equal(got.cpu().numpy(), ref)
-        assert not yt[:, d - dm:].any()                      # pad columns of the tail table stay zero
-        # (b) full rows at a line pitch (ordinary [n, d] view) + tail table, then a second hop from that layout
-        pitch = (dm + tw + 31) // 32 * 32
-        yp = torch.zeros((n, pitch), device=cuda)
-        csr.spmm_tail(xm, xt, yp, yt, d, dm, tail_full=True)
-        assert torch.equal(yp[:, :d], plain)
-        y2 = torch.zeros((n, pitch), device=cuda)
-        yt2 = torch.zeros_like(yt)
-        csr.spmm_tail(yp, yt, y2, yt2, d, dm, tail_full=True)
-        assert torch.equal(y2[:, :d], csr.spmm(plain.contiguous()))
-        # (c) accumulate into the split output
-        csr.spmm_tail(xm, xt, ym, yt, d, dm, accumulate=True)
-        acc = plain.clone()
-        csr.spmm(torch.from_numpy(x).to(cuda), out=acc, accumulate=True)
-        assert torch.equal(torch.cat([ym, yt[:, :d - dm]], dim=1), acc)
-    with pytest.raises(_lib.SglHipError):
-        csr.spmm_tail(xm, xt, ym, yt, d + 32, dm)           # more than 8 tail columns
-
-
 def test_spmm_accumulate_and_overwrite_semantics(goldens, cuda):
     n, ptr, col, val = norm_graph(goldens, "pl256")
     for strict in (True, False):
@@ -989,7 +943,7 @@ def test_community_reorder_is_transparent(cuda):
         ca.spmm_acc(xa, ya, acc_a, w=0.3, mode="wsum")
         cb.spmm_acc(xa, yb, acc_b, w=0.3, mode="wsum")
         assert same(ya, yb) and same(acc_a, acc_b), dd
-    with pytest.raises(Exception):                                     # replicas / split layout refuse a mapped handle
+    with pytest.raises(Exception):                                     # replicas refuse a mapped handle
         cb.spmm_multi(xa, [ya.data_ptr(), yb.data_ptr()], ya.stride(0))
     cb.set_rowmap(None)                                                # without the map the stored order is what it is
     assert not torch.equal(ca.spmm(xa), cb.spmm(xa))
