@@ -23,7 +23,11 @@ reorder       None -> the rows of A_hat are processed in the caller's node order
               with the adjacency) decides the order in which the rows are STORED and PROCESSED (sgl_csr_permute_rows +
               sgl_csr_set_rowmap); node ids, X, Y and every row's summation order are untouched, results are bit-identical.
               Pays on graphs that HAVE communities their ids do not show (-32 % per hop on the shuffled community graph of
-              tools/bench_reorder.py), neutral on the random benchmark graph
+              tools/bench_reorder.py), neutral on the random benchmark graph; "auto" -> run the ordering and keep it only
+              when it makes the graph measurably more local than its own ids do (sgl_amd.reorder.plan_rowmap)
+hop_cache_dir None -> every propagate() computes; a directory -> the hop matrices of propagate() are kept on disk under a key of
+              the CONTENT of adjacency + features + operator parameters and loaded on a hit (sgl_amd/hopcache.py; the reference
+              recomputes them in every run of every task)
 """
 import os
 
@@ -44,3 +48,4 @@ _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()
 fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)
 reorder = os.environ.get("SGL_AMD_REORDER") or None
+hop_cache_dir = os.environ.get("SGL_AMD_HOP_CACHE") or None

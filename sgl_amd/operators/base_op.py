@@ -56,7 +56,7 @@ def _lib_reduce(kind):
 
 class GraphOp:
     def __init__(self, prop_steps, device=None, host_output=None, strict_types=None, strict_order=None, cache_adj=None,
-                 slab_hops=None, reorder=None):
+                 slab_hops=None, reorder=None, hop_cache_dir=None):
         self._prop_steps = prop_steps
         self._reorder = reorder
         self._adj = None
@@ -66,6 +66,8 @@ class GraphOp:
         self._strict_order = strict_order
         self._cache_adj = cache_adj
         self._slab_hops = slab_hops
+        self._hop_cache_dir = hop_cache_dir
+        self._hop_cache = None
         self._adj_key = None
 
     # ---- effective settings (ctor kwarg, else sgl_amd.config) ------------------------------------
@@ -192,7 +194,25 @@ class GraphOp:
         return acc[:, :d] if acc.shape[1] != d else acc
 
     def propagate(self, adj, feature):
+        cache_dir = self._opt("hop_cache_dir")
+        if not cache_dir or self._opt("host_output") or self._opt("slab_hops"):
+            return self._propagate(adj, feature)
+        # on-disk hop cache (sgl_amd/hopcache.py): the reference's exceptions first, then content-keyed lookup
         self._checked(adj, feature)
+        from ..hopcache import HopCache
+        if self._hop_cache is None or self._hop_cache.dir != str(cache_dir):
+            self._hop_cache = HopCache(cache_dir)
+        desc = (type(self).__name__, self._norm_params(), self._prop_steps, bool(self._opt("strict_order")))
+        key = self._hop_cache.key(desc, adj, feature)
+        hops = self._hop_cache.load(key, self._prop_steps + 1, self._adj.device)
+        if hops is None:
+            hops = self._propagate(adj, feature, checked=True)
+            self._hop_cache.save(key, hops)
+        return hops
+
+    def _propagate(self, adj, feature, checked=False):
+        if not checked:
+            self._checked(adj, feature)
         device = self._adj.device
         cur = self._device_features(feature)
         # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns

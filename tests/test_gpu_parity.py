@@ -730,6 +730,45 @@ def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
     hostpool.trim()
 
 
+def test_on_disk_hop_cache_is_keyed_on_content(goldens, cuda, tmp_path):
+    """GraphOp(hop_cache_dir=...): a second operator (another process, another run) finds the hop matrices of the same adjacency
+    CONTENT + features + parameters on disk and loads them bit for bit; any change of a value, a feature entry, r, alpha or
+    prop_steps is another key; a half-written entry is a miss; the reference's exceptions still come first"""
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    g = goldens.graph("pl2000")
+    x = hash_matrix(2000, 36, seed=3)
+    plain = LaplacianGraphOp(3, r=0.5, strict_order=True).propagate(g, x)
+    a = LaplacianGraphOp(3, r=0.5, strict_order=True, hop_cache_dir=tmp_path)
+    first = a.propagate(g, x)
+    assert (a._hop_cache.hits, a._hop_cache.misses) == (0, 1) and all(torch.equal(p_, q_) for p_, q_ in zip(plain, first))
+    b = LaplacianGraphOp(3, r=0.5, strict_order=True, hop_cache_dir=tmp_path)
+    again = b.propagate(g.copy(), x.copy())                           # other objects, same content
+    assert (b._hop_cache.hits, b._hop_cache.misses) == (1, 0) and all(h.is_cuda for h in again)
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(plain, again))
+    again_t = b.propagate(g, torch.from_numpy(x).to(cuda))            # device features: digest of the same bits -> other key family
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(plain, again_t))
+    n_entries = len(os.listdir(tmp_path))
+    x2 = x.copy()
+    x2[1234, 5] += 1.0
+    g2 = g.copy()
+    g2.data[777] = 2.0
+    for op, adj_, feat_ in ((b, g, x2), (b, g2, x), (LaplacianGraphOp(2, r=0.5, strict_order=True, hop_cache_dir=tmp_path), g, x),
+                            (LaplacianGraphOp(3, r=0.3, strict_order=True, hop_cache_dir=tmp_path), g, x),
+                            (PprGraphOp(3, r=0.5, alpha=0.1, strict_order=True, hop_cache_dir=tmp_path), g, x)):
+        before = len(os.listdir(tmp_path))
+        op.propagate(adj_, feat_)
+        assert len(os.listdir(tmp_path)) == before + 1                # every variation is its own entry
+    assert len(os.listdir(tmp_path)) == n_entries + 5
+    # a half-written entry (no meta.json) is recomputed, not trusted
+    key = a._hop_cache.key((type(a).__name__, a._norm_params(), 3, True), g, x)
+    os.remove(os.path.join(tmp_path, key, "meta.json"))
+    c = LaplacianGraphOp(3, r=0.5, strict_order=True, hop_cache_dir=tmp_path)
+    redo = c.propagate(g, x)
+    assert (c._hop_cache.hits, c._hop_cache.misses) == (0, 1) and all(torch.equal(p_, q_) for p_, q_ in zip(plain, redo))
+    with pytest.raises(ValueError):
+        a.propagate(g, x[:10])
+
+
 def test_hop_ranges_match_reference_goldens(goldens, cuda):
     """G8 (recorded from the reference): Mean's divisor is (end - start) whatever the slice held, partial / single-hop
     ranges; aggregate(propagate()) and the fused propagate_reduce both reproduce the reference -- sum / mean / last bit for
