@@ -100,10 +100,10 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if ":" in line:
-                    k, v = (p_.strip() for p_ in line.split(":", 1))
-                    cur[k] = v
-                    if k == "model name" and cpu_model == "unknown CPU":
-                        cpu_model = v
+                    key_, text_ = (p_.strip() for p_ in line.split(":", 1))
+                    cur[key_] = text_
+                    if key_ == "model name" and cpu_model == "unknown CPU":
+                        cpu_model = text_
                 elif cur:
                     if int(cur.get("processor", -1)) in cpus and "core id" in cur:
                         seen.add((cur.get("physical id", "0"), cur["core id"]))

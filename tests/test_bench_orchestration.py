@@ -292,3 +292,22 @@ def test_bench_single_rank_contract(tmp_path, monkeypatch):
     # default CLI values finish quickly and match the documented contract
     d = bench.parse_args([])
     assert d.gpus == 1 and d.steps == 10 and d.warmup == 2 and d.workload == "S1_products"
+
+
+def test_cpu_baseline_leg_reports_reference_kernel_cores_and_scipy():
+    """bench.cpu_baseline on a small workload: the reference's own compiled kernel (oracle/_ref) when it is built, physical
+    cores AND threads stated, the scipy single-thread figure present (a regression here once went unnoticed: the leg is
+    reporting-only and swallows its own exceptions)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import bench
+    import oracle
+    from sgl_amd.synthetic import chung_lu_numpy
+    n = 30_000
+    ip, ix, dt = chung_lu_numpy(n, 200_000, 400, seed=1)
+    ptr, col, val = oracle.laplacian_adj(ip, ix, dt, n, 0.5)
+    out = bench.cpu_baseline(torch.from_numpy(ptr), torch.from_numpy(col.astype(np.int32)), torch.from_numpy(val.astype(np.float32)),
+                             torch.randn(n, 16), 16, budget_s=1.0)
+    assert out["value"] > 0 and out["kind"] in ("reference", "port") and out["unit"] == "edge\u00b7featdim/s"
+    assert 1 <= out["cores"] <= out["threads"] and "physical cores" in out["sample"]
+    assert out["scipy_dot"]["value"] and out["scipy_dot"]["cores"] == 1
