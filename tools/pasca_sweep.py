@@ -63,6 +63,8 @@ def main():
                ("simple_weighted a=.85", M.SimpleWeightedMessageOp(0, K + 1, "alpha", 0.85)),
                ("learnable simple", M.LearnableWeightedMessageOp(0, K + 1, "simple", K).to(device)),
                ("learnable gate", M.LearnableWeightedMessageOp(0, K + 1, "gate", d).to(device)),
+               ("learnable ori_ref", M.LearnableWeightedMessageOp(0, K + 1, "ori_ref", d).to(device)),
+               ("learnable jk", M.LearnableWeightedMessageOp(0, K + 1, "jk", K, d).to(device)),
                ("nafs over_smooth", M.OverSmoothDistanceWeightedOp())]
         for oname, op in ops:
             with torch.no_grad():
