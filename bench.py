@@ -164,6 +164,7 @@ class GpuEngine:
     (broadcast, shard bounds, exchange, barrier/MAX timing, JSON contract) without GPUs."""
     backend = "nccl"
     transports = ("p2p", "allgather")     # process-group transports the auto-selection may choose from
+    halo_collective = True                # RCCL has all_to_all_single with split sizes: the need-aware exchange in one call
 
     def __init__(self, local_rank):
         if not torch.cuda.is_available():
@@ -696,11 +697,31 @@ def _select_exchange(job, full, halo):
         cand[tname] = job.timed_s(lambda: prop.exchange_only(ys0, [b[0] for b in cbufs]))
     if halo is not None:
         hp = halo["prop"]
-        cand["halo"] = job.timed_s(lambda: hp.exchange_only(ys0, [b[0] for b in halo["bufs"]]))
+        first = [b[0] for b in halo["bufs"]]
+        cand["halo"] = job.timed_s(lambda: hp.exchange_only(ys0, first))
+        if getattr(engine, "halo_collective", False):
+            # the same exchange as ONE all_to_all_single with split sizes: a candidate only if it delivers the right rows (exact
+            # bit-checksums of every ghost range on random data) on every rank
+            from sgl_amd.dist import halo_checksums
+            good = True
+            try:
+                hp.collective = True
+                probe = [torch.rand_like(y) for y in ys0]
+                hp.exchange_only(probe, first)
+                engine.sync()
+                good = all(halo_checksums(halo["plan"], t, y) for t, y in zip(first, probe))
+            except Exception as e:  # noqa: BLE001
+                good = False
+                sys.stderr.write(f"[bench] all_to_all form of the need-aware exchange unavailable on rank {job.rank}: {e!r}\n")
+            if job.agree(good):
+                cand["halo_a2a"] = job.timed_s(lambda: hp.exchange_only(ys0, first))
+            else:
+                info["halo_a2a_rejected"] = True
+            hp.collective = False
     exchange = min(cand, key=cand.get)
     info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
     # opt-in (SGL_BENCH_TRY_PUSH=1): a fault in a peer store would take the whole job down
-    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles or exchange == "halo":
+    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles or exchange.startswith("halo"):
         return exchange
     prop.transport = exchange
     if not setup_push():
@@ -814,17 +835,21 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
     want = exchange_fixed or args.exchange
     if want == "staged":
         want = "p2p"
+    want_a2a = want == "halo_a2a"
+    if want_a2a:
+        want = "halo"
     full = halo = None
     if want != "halo" or not can_halo:
         full = _rows_full_replica(job, chunks)
     if can_halo and want in ("auto", "halo"):
         halo = _rows_halo(job, chunks)
-    exchange = exchange_fixed if exchange_fixed in ("halo", "p2p", "allgather", "staged") else _select_exchange(job, full, halo)
+    exchange = exchange_fixed if exchange_fixed in ("halo", "halo_a2a", "p2p", "allgather", "staged") else _select_exchange(job, full, halo)
     job.info["exchange"] = exchange
     check_fn = getattr(job.engine, "sampled_rows_check", None)
-    if exchange == "halo":
+    if exchange in ("halo", "halo_a2a"):
         full = None                                           # the replicas of the other candidate are released
         plan, prop, cblk, tables, hbufs, ybufs = (halo[k] for k in ("plan", "prop", "cblk", "tables", "bufs", "ybufs"))
+        prop.collective = exchange == "halo_a2a"
         frac = torch.tensor([plan.skipped_fraction, float(plan.n_ghost)], dtype=torch.float64, device=job.device)
         if job.world > 1:
             import torch.distributed as dist
@@ -856,7 +881,8 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
             return ok
         return {"step": step, "check": check, "halves": (prop, tables, hbufs),
                 "describe": f"row-sharded x{job.world} (A_hat stored as one row block per GPU) + per-hop need-aware all-gather "
-                            f"(halo: {plan.n_ghost} of {plan.rows_in_full} foreign rows gathered on rank 0, packed), "
+                            f"({'halo as one all_to_all_single' if prop.collective else 'halo'}: {plan.n_ghost} of {plan.rows_in_full} "
+                            f"foreign rows gathered on rank 0, packed), "
                             f"{len(chunks)} column chunks pipelined across hops"}
     halo = None
     prop, x_chunks, cbufs, ybufs, bounds = (full[k] for k in ("prop", "x_chunks", "cbufs", "ybufs", "bounds"))
@@ -1104,8 +1130,8 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
     t0 = time.perf_counter()
     bounds, nnz = engine.hashed_bounds(args, wl, world)
     blk = engine.hashed_block(args, wl, int(bounds[rank]), int(bounds[rank + 1]))
-    if exchange == "halo" and world > 1 and getattr(engine, "block_halo", None) is not None:
-        return _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0)
+    if exchange in ("halo", "halo_a2a") and world > 1 and getattr(engine, "block_halo", None) is not None:
+        return _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0, collective=exchange == "halo_a2a")
     x0 = engine.features(args, wl)
     pieces, handles, mine = engine.block_piece_spmms(args, blk, args.pieces)
     pb = gather_piece_bounds(mine) if world > 1 else np.asarray([[int(v) for v in mine]], dtype=np.int64)
@@ -1177,7 +1203,7 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
             "setup_s": round(time.perf_counter() - t0 - elapsed * (steps + 1) / steps, 2)}
 
 
-def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0):
+def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0, collective=False):
     """papers100M-shaped section with the need-aware exchange: no rank ever holds the 57 GB feature matrix -- it generates its
     OWN feature rows, fetches the rows its block gathers from their owners (the same exchange that runs between hops) and keeps
     compact tables [own rows | ghosts per peer]; k hops in place, only the last retained."""
@@ -1186,6 +1212,7 @@ def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0):
     n, d, K = wl["n"], wl["d"], wl["k"]
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     plan, prop, cblk = engine.block_halo(args, blk, [int(b) for b in bounds])
+    prop.collective = bool(collective)
     x_own = engine.feature_rows(args, wl, lo, hi)
     chunks = column_chunks(d, _n_chunks(args))
     tables = [prop.table_from_own(x_own if len(chunks) == 1 else x_own[:, a:b].contiguous(), key=("init", c))

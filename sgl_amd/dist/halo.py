@@ -189,6 +189,13 @@ class HaloPropagator:
         self.layout = None                                   # what ShardedGraphOp.gather_full / over_smooth_aggregate look at
         self.pb = np.stack([plan.bounds[:-1], plan.bounds[1:]], axis=1)
         self._send = {}
+        # The send buffer holds the peers' shares in rank order and so do the ghost ranges of a table: the whole exchange is ONE
+        # all_to_all_single with split sizes (an all-to-all-v) -- one call instead of 2 (G - 1) point-to-point operations, which is
+        # what bounds how finely a hop can be cut on the host side.  Off by default (gloo has no all_to_all; bench.py times it
+        # as a candidate on RCCL and keeps it only if it validates and wins).
+        self.collective = False
+        self._splits = ([int(plan.send_off[q + 1] - plan.send_off[q]) for q in range(plan.world)],
+                        [int(plan.ghost_off[q + 1] - plan.ghost_off[q]) for q in range(plan.world)])
 
     # ---- building blocks -------------------------------------------------------------------------------------------
     def _pack(self, y_own, key):
@@ -216,6 +223,11 @@ class HaloPropagator:
             return _post(self.group, [], [])
         buf = self._pack(y_own, key)
         staged = _is_staged(self.group, table_next) if self.staged is None else self.staged
+        if self.collective and not staged:
+            from .transports import _Works
+            work = dist.all_to_all_single(table_next[pl.n_own:], buf, output_split_sizes=self._splits[1],
+                                          input_split_sizes=self._splits[0], group=self.group, async_op=True)
+            return _Works([work])
         sends, recvs = [], []
         for k in range(1, self.world):                 # staggered peer order: every link busy in both directions
             dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world

@@ -245,6 +245,36 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
             ok = ok and len(hops) == K + 1 and np.array_equal(hops[K].numpy(), ref[K][lo:hi])
             if not in_place:
                 ok = ok and all(np.array_equal(hops[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        # the same exchange as ONE all_to_all_single with split sizes (the RCCL form; gloo has none, so its contract is emulated
+        # with point-to-point operations: rows [sum(in[:q]), +in[q]) of the input go to rank q, rows from rank q land at
+        # [sum(out[:q]), +out[q]) of the output)
+        def a2a_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+            ok_shapes = sum(output_split_sizes) == output.shape[0] and sum(input_split_sizes) == input.shape[0]
+            assert ok_shapes and output.is_contiguous() and input.is_contiguous()
+            oi, oo = np.concatenate([[0], np.cumsum(input_split_sizes)]), np.concatenate([[0], np.cumsum(output_split_sizes)])
+            ops = []
+            for k in range(1, world):
+                dst, src = (rank + k) % world, (rank - k) % world
+                if input_split_sizes[dst]:
+                    ops.append(dist.P2POp(dist.isend, input[oi[dst]:oi[dst + 1]], dst))
+                if output_split_sizes[src]:
+                    ops.append(dist.P2POp(dist.irecv, output[oo[src]:oo[src + 1]], src))
+            works = dist.batch_isend_irecv(ops) if ops else []
+
+            class Work:
+                def wait(self):
+                    for w_ in works:
+                        w_.wait()
+            return Work()
+        real_a2a = getattr(dist, "all_to_all_single")
+        dist.all_to_all_single = a2a_single
+        prop.collective = True
+        try:
+            hops_c = prop.propagate(t_own.clone(), K)
+            ok = ok and all(np.array_equal(hops_c[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        finally:
+            prop.collective = False
+            dist.all_to_all_single = real_a2a
         # column chunks, software-pipelined, with caller-owned tables: the ghosts of the last exchanged hop are the owners' rows
         chunks = [(0, 3), (3, d)]
         tabs = [t_own[:, a:b].contiguous() for a, b in chunks]

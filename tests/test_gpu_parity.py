@@ -1705,6 +1705,7 @@ def _bench_worker(rank, world, port, out_dir, extra=(), halo=True):
         transports = ("staged",)
         relay_transport = "relay_staged"
         probe_links = False                   # the link micro-benchmark moves device tensors through the process group
+        halo_collective = False               # gloo has no all_to_all_single
 
         def init_kwargs(self):
             return {}
