@@ -382,10 +382,10 @@ def parse_args(argv=None):
                          "are both built, validated and timed during setup and the faster runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
-    ap.add_argument("--exchange", choices=("auto", "halo", "p2p", "allgather", "push"),
+    ap.add_argument("--exchange", choices=("auto", "halo", "halo_a2a", "p2p", "allgather", "push"),
                     default=os.environ.get("SGL_BENCH_EXCHANGE", "auto"),
                     help="N>1 transport of the per-hop all-gather: halo = need-aware (a rank receives only the rows its block "
-                         "gathers, packed into a compact table; sgl_amd/dist/halo.py), p2p = every row to every rank by grouped "
+                         "gathers, packed into a compact table; sgl_amd/dist/halo.py), halo_a2a = the same as one all_to_all_single, p2p = every row to every rank by grouped "
                          "RCCL send/recv, allgather = RCCL all-gather on padded pieces, auto = time one hop's exchange with each "
                          "during setup and keep the fastest, push = stores into peer replicas from the SpMM kernel (opt-in)")
     ap.add_argument("--layout", choices=("rows", "auto", "cols", "grid", "all"), default=os.environ.get("SGL_BENCH_LAYOUT", "rows"),
@@ -843,6 +843,8 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
         full = _rows_full_replica(job, chunks)
     if can_halo and want in ("auto", "halo"):
         halo = _rows_halo(job, chunks)
+        if want_a2a:
+            exchange_fixed = "halo_a2a"
     exchange = exchange_fixed if exchange_fixed in ("halo", "halo_a2a", "p2p", "allgather", "staged") else _select_exchange(job, full, halo)
     job.info["exchange"] = exchange
     check_fn = getattr(job.engine, "sampled_rows_check", None)

@@ -139,16 +139,43 @@ def _make_engine():
     return CpuEngine
 
 
-def _worker(rank, world, port, out_dir, extra=()):
+def _emulate_all_to_all_single(rank, world):
+    """gloo has no all_to_all; give torch.distributed the contract of all_to_all_single with split sizes through point-to-point
+    operations so that the one-call form of the need-aware exchange runs in the CPU orchestration tests"""
+    def a2a_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        assert sum(output_split_sizes) == output.shape[0] and sum(input_split_sizes) == input.shape[0]
+        oi, oo = np.concatenate([[0], np.cumsum(input_split_sizes)]), np.concatenate([[0], np.cumsum(output_split_sizes)])
+        ops = []
+        for k in range(1, world):
+            dst, src = (rank + k) % world, (rank - k) % world
+            if input_split_sizes[dst]:
+                ops.append(dist.P2POp(dist.isend, input[oi[dst]:oi[dst + 1]], dst))
+            if output_split_sizes[src]:
+                ops.append(dist.P2POp(dist.irecv, output[oo[src]:oo[src + 1]], src))
+        works = dist.batch_isend_irecv(ops) if ops else []
+
+        class Work:
+            def wait(self):
+                for w_ in works:
+                    w_.wait()
+        return Work()
+    dist.all_to_all_single = a2a_single
+
+
+def _worker(rank, world, port, out_dir, extra=(), a2a=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import bench
+    if a2a:
+        _emulate_all_to_all_single(rank, world)
     args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_tiny",
                              "--pieces", "3", "--col-chunks", "2", "--no-cpu-baseline", *extra])
     lines = []
-    out = bench.run(args, engine_cls=_make_engine(), workloads=TINY, emit=lines.append)
+    engine_cls = _make_engine()
+    engine_cls.halo_collective = bool(a2a)
+    out = bench.run(args, engine_cls=engine_cls, workloads=TINY, emit=lines.append)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump({"lines": lines, "returned": out is not None, "initialized_after": dist.is_initialized()}, f)
 
@@ -311,3 +338,20 @@ def test_cpu_baseline_leg_reports_reference_kernel_cores_and_scipy():
     assert out["value"] > 0 and out["kind"] in ("reference", "port") and out["unit"] == "edge\u00b7featdim/s"
     assert 1 <= out["cores"] <= out["threads"] and "physical cores" in out["sample"]
     assert out["scipy_dot"]["value"] and out["scipy_dot"]["cores"] == 1
+
+
+def test_bench_need_aware_exchange_as_one_all_to_all(tmp_path):
+    """the one-call form of the need-aware exchange (all_to_all_single with split sizes; emulated over gloo): validated by exact
+    checksums on random data before it may be timed, a candidate of the selection, and runnable on request through both column
+    chunk candidates"""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto"), True), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo", "halo_a2a"} and "halo_a2a_rejected" not in plan
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto", "--exchange", "halo_a2a"), True),
+             nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert plan["exchange"] == "halo_a2a" and set(plan["col_chunks_candidates_ms"]) == {"2", "4"} and j["value"] > 0
+    assert "halo as one all_to_all_single" in j["config"]["parallelism"] and plan["rows"]["exchange"] == "halo_a2a"
