@@ -709,7 +709,7 @@ def _select_exchange(job, full, halo):
                 probe = [torch.rand_like(y) for y in ys0]
                 hp.exchange_only(probe, first)
                 engine.sync()
-                good = all(halo_checksums(halo["plan"], t, y) for t, y in zip(first, probe))
+                good = all([halo_checksums(halo["plan"], t, y) for t, y in zip(first, probe)])   # a list: every collective runs
             except Exception as e:  # noqa: BLE001
                 good = False
                 sys.stderr.write(f"[bench] all_to_all form of the need-aware exchange unavailable on rank {job.rank}: {e!r}\n")
@@ -782,36 +782,47 @@ def _build_rows(job, ref=None):
     auto = str(args.col_chunks) == "auto"
     counts = [2, 4] if (auto and job.world > 1 and job.nbuf > 0) else [2 if auto else int(args.col_chunks)]
     base_info = dict(job.info)
-    best, timing, exchange = None, {}, None
     live = job.info                                       # callers hold a reference to this dict: it is edited in place
 
     def set_info(d_):
         live.clear()
         live.update(d_)
-    for nc in counts:
-        set_info(base_info)
-        if getattr(job, "rows_inbound_bytes", None) is not None:
-            job.rows_inbound_bytes = None
-        cand = _build_rows_for(job, ref, nc, exchange)
-        exchange = job.info["exchange"]
-        for k in ("exchange_candidates_ms", "push_peer_rows_skipped", "full_step_candidates_ms", "push_rejected"):
-            if k in live:
-                base_info[k] = live[k]                    # the selection happens once: its record goes with every candidate
-        if len(counts) > 1:
-            good = True
-            try:
-                cand["step"]()
-                job.sync_all()
-                good = bool(cand["check"]())
-            except Exception as e:  # noqa: BLE001
-                good = False
-                sys.stderr.write(f"[bench] rows with {nc} column chunks failed on rank {job.rank}: {e!r}\n")
-            if not job.agree(good):
-                continue
-            timing[nc] = job.timed_s(cand["step"], reps=2, warm=0)
-        if best is None or (len(counts) > 1 and timing[nc] < timing[best[0]]):
-            best = (nc, cand, dict(job.info), getattr(job, "rows_inbound_bytes", None))
-        del cand
+
+    def attempt(exchange):
+        """build (and, when there is a choice or the exchange is the need-aware one, validate and time) every chunk count"""
+        best, timing = None, {}
+        for nc in counts:
+            set_info(base_info)
+            if getattr(job, "rows_inbound_bytes", None) is not None:
+                job.rows_inbound_bytes = None
+            cand = _build_rows_for(job, ref, nc, exchange)
+            exchange = job.info["exchange"]
+            for k in ("exchange_candidates_ms", "push_peer_rows_skipped", "full_step_candidates_ms", "push_rejected",
+                      "halo_a2a_rejected"):
+                if k in live:
+                    base_info[k] = live[k]                # the selection happens once: its record goes with every candidate
+            if len(counts) > 1 or str(exchange).startswith("halo"):
+                good = True
+                try:
+                    cand["step"]()
+                    job.sync_all()
+                    good = bool(cand["check"]())
+                except Exception as e:  # noqa: BLE001
+                    good = False
+                    sys.stderr.write(f"[bench] rows with {nc} column chunks ({exchange}) failed on rank {job.rank}: {e!r}\n")
+                if not job.agree(good):
+                    continue
+                timing[nc] = job.timed_s(cand["step"], reps=2, warm=0)
+            if best is None or (nc in timing and timing[nc] < timing.get(best[0], float("inf"))):
+                best = (nc, cand, dict(job.info), getattr(job, "rows_inbound_bytes", None))
+            del cand
+        return best, timing, exchange
+
+    best, timing, exchange = attempt(None)
+    if best is None and str(exchange).startswith("halo"):
+        # the need-aware exchange did not reproduce itself on this system: the run goes on with the full-replica exchange
+        base_info["halo_rejected"] = f"{exchange}: validation failed, fell back to the full-replica exchange"
+        best, timing, exchange = attempt("p2p")
     if best is None:
         raise RuntimeError("no column chunking of the row-sharded layout passed validation")
     nc, cand, info, inbound = best
@@ -875,9 +886,9 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
             for c in range(len(tables)):
                 t_prev = tables[c] if K == 1 else hbufs[c][(K - 2) % job.nbuf]
                 if K >= 2:                                    # the ghosts of hop K-1 are the owners' rows, bit for bit
-                    ok = ok and halo_checksums(plan, t_prev, hops[K - 1][c])
+                    ok = halo_checksums(plan, t_prev, hops[K - 1][c]) and ok     # collective: never behind a short circuit
                 if check_fn is not None:
-                    ok = ok and check_fn(cblk, t_prev, hops[K][c])
+                    ok = check_fn(cblk, t_prev, hops[K][c]) and ok
             if ref is not None:
                 ok = ok and all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(hops[K], chunks))
             return ok
@@ -909,9 +920,10 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
             # what the last hop read: the replica of hop K-1 (the input itself when K == 1)
             x_prev = xc if K == 1 else (prop._push_local[c][(K - 2) % 2] if exchange == "push" else cbufs[c][(K - 2) % job.nbuf])
             if K >= 2 and exchange != "push":     # every rank's rows of hop K-1 arrived intact in my replica (the push
-                ok = ok and exchange_checksums(x_prev, hops[K - 1][c], bounds)   # transport skips rows this rank never gathers)
+                ok = exchange_checksums(x_prev, hops[K - 1][c], bounds) and ok   # transport skips rows this rank never gathers);
+                                                                                 # collective: never behind a short circuit
             if check_fn is not None:
-                ok = ok and check_fn(blk, x_prev, hops[K][c])
+                ok = check_fn(blk, x_prev, hops[K][c]) and ok
         if ref is not None:  # a replica-based reference chain exists anyway (alternative layouts were asked for)
             ok = ok and all(ref.close(t, prop.lo, prop.hi, a, b) for t, (a, b) in zip(hops[K], chunks))
         return ok
@@ -1171,8 +1183,8 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
     bnds = [int(v) for v in pb[:, 0]] + [int(pb[-1, -1])]
     for c in range(len(x_chunks)):
         x_prev = cbufs[c][(K - 2) % 2]
-        ok = ok and exchange_checksums(x_prev, x_prev[prop.lo:prop.hi], bnds)
-        ok = ok and engine.sampled_rows_check(blk, x_prev, hops[K][c])
+        ok = exchange_checksums(x_prev, x_prev[prop.lo:prop.hi], bnds) and ok      # collective: never behind a short circuit
+        ok = engine.sampled_rows_check(blk, x_prev, hops[K][c]) and ok
     dev_ = x_chunks[0].device
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev_)
     if world > 1:
@@ -1238,8 +1250,8 @@ def _papers_halo(args, engine, rank, world, wl, bounds, nnz, blk, t0, collective
     for c in range(len(tables)):
         t_prev = bufs[c][(K - 2) % 2] if K >= 2 else tables[c]
         if K >= 2:
-            ok = ok and halo_checksums(plan, t_prev, t_prev[:plan.n_own])
-        ok = ok and engine.sampled_rows_check(cblk, t_prev, hops[K][c])
+            ok = halo_checksums(plan, t_prev, t_prev[:plan.n_own]) and ok           # collective: never behind a short circuit
+        ok = engine.sampled_rows_check(cblk, t_prev, hops[K][c]) and ok
     dev_ = tables[0].device
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev_)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

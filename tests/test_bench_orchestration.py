@@ -162,7 +162,7 @@ def _emulate_all_to_all_single(rank, world):
     dist.all_to_all_single = a2a_single
 
 
-def _worker(rank, world, port, out_dir, extra=(), a2a=False):
+def _worker(rank, world, port, out_dir, extra=(), a2a=False, break_halo=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -175,6 +175,28 @@ def _worker(rank, world, port, out_dir, extra=(), a2a=False):
     lines = []
     engine_cls = _make_engine()
     engine_cls.halo_collective = bool(a2a)
+    if break_halo:
+        # a need-aware exchange that delivers wrong rows on one rank (a transport that misbehaves on some system): the exact
+        # checksums must catch it and the run must go on with the full-replica exchange
+        good_halo = engine_cls.block_halo
+
+        def bad_halo(self, args_, blk, bounds):
+            plan, prop, cblk = good_halo(self, args_, blk, bounds)
+            if rank == 1:
+                real = prop.begin_exchange
+
+                def corrupt(y_own, table_next, key=0):
+                    w = real(y_own, table_next, key)
+
+                    class W:
+                        def wait(self_inner):
+                            w.wait()
+                            if plan.n_ghost:
+                                table_next[plan.n_own, 0] += 1.0
+                    return W()
+                prop.begin_exchange = corrupt
+            return plan, prop, cblk
+        engine_cls.block_halo = bad_halo
     out = bench.run(args, engine_cls=engine_cls, workloads=TINY, emit=lines.append)
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump({"lines": lines, "returned": out is not None, "initialized_after": dist.is_initialized()}, f)
@@ -355,3 +377,15 @@ def test_bench_need_aware_exchange_as_one_all_to_all(tmp_path):
     plan = j["config"]["plan"]
     assert plan["exchange"] == "halo_a2a" and set(plan["col_chunks_candidates_ms"]) == {"2", "4"} and j["value"] > 0
     assert "halo as one all_to_all_single" in j["config"]["parallelism"] and plan["rows"]["exchange"] == "halo_a2a"
+
+
+def test_bench_falls_back_when_the_need_aware_exchange_misdelivers(tmp_path):
+    """a need-aware exchange that corrupts one ghost value on one rank is caught by the exact checksums (on every chunking) and
+    the job continues, validated, on the full-replica exchange -- and says so"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--exchange", "halo", "--col-chunks", "auto"), False, True),
+             nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert plan["exchange"] == "p2p" and plan["halo_rejected"].startswith("halo: validation failed") and j["value"] > 0
+    assert "halo" not in plan and plan["rows"]["exchange"] == "p2p" and plan["rows"]["exchange_skipped_fraction"] == 0.0
