@@ -76,10 +76,10 @@ class HopCache:
             from . import device as dev
             hops = []
             for k in range(n_hops):
-                a = np.load(os.path.join(d, f"hop_{k}.npy"), mmap_mode="r")
+                a = np.load(os.path.join(d, f"hop_{k}.npy"))
                 if list(a.shape) != meta["shape"] or a.dtype != np.float32:
                     raise ValueError("unexpected array")
-                hops.append(dev.upload_rows(np.ascontiguousarray(a), device))
+                hops.append(dev.upload_rows(a, device))
         except (OSError, ValueError, KeyError, json.JSONDecodeError):
             self.misses += 1
             return None
