@@ -328,10 +328,18 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
     }
 }
 
+// Register budget of the register-resident row kernels: few hop vectors per lane -> insist on 8 workgroups per CU (<= 64 VGPRs);
+// left at 4 the scheduler spends the 128 registers it is allowed on speculation (HMAX = 6: 128 VGPRs, 4 waves per SIMD) instead of
+// the ~46 the kernel needs: NAFS at d = 128, H = 6 0.715 -> 0.739 of peak.  Two restructurings that aimed at more waves for MANY
+// hops were measured and rejected (round 3): an online softmax without a score array (0.58 vs 0.67: the per-hop chain serialises
+// what the fused form interleaves) and one row per wavefront with the hops split over the half-waves (v_permlane32_swap
+// exchanges; 8 waves, but 0.57 / 0.48 vs 0.67 / 0.62) -- profiles/r03_aggregators_{online_gate,hop_split}_experiment.log.
+#define ROWREG_MIN_BLOCKS(HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((HMAX) * (CH) <= 16) ? 4 : 2))
+
 // Fused NAFS: one pass over the H hop rows held in registers -> cosine scores -> softmax -> weighted sum.
 // LPR lanes per row, CH float4 chunks per lane (d <= LPR*4*CH), H <= HMAX.  Same arithmetic as the two-pass path.
 template <int LPR, int CH, int HMAX>
-__global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void nafs_fused_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+__global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
                                                          const int64_t ldo, float *__restrict__ wout, const int64_t ldw,
                                                          const int64_t n, const int d) {
     constexpr int RPB = 256 / LPR;
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void nafs_fused_ker
 // two-pass path up to the rounding of expf.  wout [n, H] = the softmax weights, gout [n, H] = the sigmoid outputs (what the
 // backward needs besides the hops).
 template <int LPR, int CH, int HMAX>
-__global__ __launch_bounds__(256, (HMAX * CH <= 16) ? 4 : 2) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
+__global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
                                                          const float bias, float *__restrict__ out, const int64_t ldo,
                                                          float *__restrict__ wout, const int64_t ldw, float *__restrict__ gout,
                                                          const int64_t ldg, const int64_t n, const int d) {

@@ -28,7 +28,6 @@ static std::map<std::string, int64_t> &tune_map() {
         {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
         {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)
         {"spmm_xcd_remap", 1},   // contiguous row ranges per XCD
-        {"spmm_tail_nt", 0},     // split layout: main-row gathers as separate non-temporal loads
         {"agg_blocks", 0},       // 0 = one 16-byte element per thread (grid capped at 2^22 blocks); > 0 caps the grid of the streaming aggregators (grid-stride)
         {"nafs_fused", 1},       // 0 = force the two-pass NAFS path
         {"row_lpr32x2", 1},      // row-wise kernels, 128 < d <= 256: 32 lanes x 2 chunks per row (2 rows per wavefront)

@@ -35,7 +35,7 @@ def main():
     if os.environ.get("AGG_BLOCKS"):
         _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)
-    for d, H in ((100, 4), (128, 11), (147, 6), (16, 4)):
+    for d, H in ((100, 4), (128, 11), (147, 6), (128, 6), (16, 4)):
         feats = [dev.alloc_rows(n, d, device) for _ in range(H)]
         for f in feats:
             f.normal_()
