@@ -1,0 +1,204 @@
+"""Layout candidates of an N-rank job: the contract layout (rows.py) first, then -- only when asked for -- the alternatives that
+replicate A_hat (feature-sharded columns, 2 x N/2 grid), each validated against the single-GPU chain on a gathered replica."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .common import _phase
+from .rows import _build_rows
+
+
+class _Reference:
+    """The single-GPU k-hop chain computed on this rank's own replica: what every multi-GPU layout must reproduce."""
+
+    def __init__(self, job):
+        self.full_spmm = job.piece_spmms(np.array([0, job.n], dtype=np.int64))[0][0]
+        bufs = [torch.empty_like(job.x0) for _ in range(job.K)]
+
+        def chain():
+            last = job.x0
+            for h in range(job.K):
+                self.full_spmm(last, bufs[h])
+                last = bufs[h]
+            return last
+        chain()
+        job.engine.sync()
+        t0 = time.perf_counter()
+        self.last = chain()
+        job.engine.sync()
+        self.ms = (time.perf_counter() - t0) * 1e3          # one rank's single-GPU step: the yardstick of the fallback rule
+        del bufs[:job.K - 1]
+        self.scale = max(float(self.last.abs().max()), 1e-30)
+
+    def close(self, block, r0, r1, c0, c1):
+        want = self.last[r0:r1, c0:c1]
+        return want.numel() == 0 or float((block - want).abs().max()) <= 1e-5 * self.scale
+
+
+# ---- the layout candidates of an N-rank job (sgl_amd/dist/).  Each builder returns {"step", "check", "describe"} ------
+
+def _build_cols(job, ref):
+    """feature-sharded: every rank runs the whole chain on d/N columns, no communication"""
+    from sgl_amd.dist import column_slices
+    a, b = column_slices(job.d, job.world)[job.rank]
+    w, K = b - a, job.K
+    xs = job.engine_pack(job.x0, a, b)
+    outs = [torch.empty_like(xs) for _ in range(K)]
+
+    def step():
+        cur = xs
+        for h in range(K if w else 0):
+            ref.full_spmm(cur, outs[h])
+            cur = outs[h]
+    return {"step": step, "check": lambda: K == 0 or ref.close(outs[K - 1][:, :w], 0, job.n, a, b),
+            "describe": f"feature-sharded x{job.world} (each GPU: all rows x {w} of {job.d} columns, no communication)"}
+
+
+def _build_grid(job, ref, row_groups):
+    """row_groups row blocks x N/row_groups column slices, the exchange inside a column group relayed over all ranks.
+    How many row pieces a hop is cut into trades exposed transfer time (the last piece's) against per-piece launch and
+    issue cost, and the optimum depends on what the links deliver -- so every count in --grid-pieces is built,
+    validated and timed (untimed setup), and the fastest one is this layout's candidate."""
+    from sgl_amd.dist import GridLayout, ShardedPropagator, all_piece_bounds, column_slices, tapered_weights
+    K = job.K
+    layout = GridLayout(job.world, row_groups)
+    rg, cg = layout.coords(job.rank)
+    slices = column_slices(job.d, layout.col_groups)
+    job.full_adj()
+    if job.rp_host is None:
+        job.rp_host = job.rowptr.cpu().numpy()
+    a, b = slices[cg]
+    w = b - a
+    xs = job.engine_pack(job.x0, a, b)
+    widths = [job.engine_pack(job.x0[:1], sa, sb).shape[1] for sa, sb in slices]
+    bufs = [torch.empty_like(xs) for _ in range(job.nbuf)]
+
+    def variant(pieces):
+        # the last piece's transfer is the one nothing can hide: make it half as large as the others
+        pb = all_piece_bounds(job.rp_host, row_groups, pieces, tapered_weights(pieces))
+        fns, _handles = job.piece_spmms(pb[rg])
+        prop = ShardedPropagator(fns, pb, rg, row_groups, job.n, transport=getattr(job.engine, "relay_transport", "relay"),
+                                 layout=layout, me=job.rank, widths=widths)
+        ybufs = [torch.empty((prop.hi - prop.lo, xs.shape[1]), dtype=xs.dtype, device=xs.device) for _ in range(K)]
+
+        def step():
+            return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs)   # every buffer preallocated: no allocator traffic
+        return prop, step
+
+    counts = [int(t) for t in str(job.args.grid_pieces).split(",") if t.strip()]
+    best, timing = None, {}
+    for pieces in counts:
+        good, made = True, None
+        try:
+            made = variant(pieces)
+            good = bool(ref.close(made[1]()[K][:, :w], made[0].lo, made[0].hi, a, b))
+        except Exception as e:  # noqa: BLE001  (same code on every rank, so an error is too; agree() settles it)
+            good = False
+            sys.stderr.write(f"[bench] grid with {pieces} pieces failed on rank {job.rank}: {e!r}\n")
+        if not job.agree(good):
+            continue
+        timing[pieces] = job.timed_s(made[1], reps=2, warm=0)
+        if best is None or timing[pieces] < timing[best[0]]:
+            best = (pieces,) + made
+    if best is None:
+        raise RuntimeError("no grid variant reproduced the single-GPU result")
+    pieces, prop, step = best
+    job.info["grid_pieces"] = pieces
+    job.info["grid_pieces_candidates_ms"] = {str(k): round(v * 1e3, 3) for k, v in timing.items()}
+    return {"step": step, "check": lambda: ref.close(step()[K][:, :w], prop.lo, prop.hi, a, b), "halves": (prop, [xs], [bufs]),
+            "describe": f"grid {row_groups} row blocks x {layout.col_groups} column slices, pair exchange relayed over all "
+                        f"{job.world} ranks, {pieces} row pieces"}
+
+
+def _alternatives(job):
+    """which replica-based layouts --layout asks for besides the contract one"""
+    world, layout = job.world, job.args.layout
+    grid_ok = world >= 4 and world % 2 == 0
+    if layout == "grid" and not grid_ok:
+        raise SystemExit("--layout grid needs an even number of at least 4 ranks")
+    if layout == "rows" or world == 1:
+        return []
+    if layout == "auto":
+        return ["grid"] if (world >= 8 and grid_ok) else ["cols"]
+    if layout == "all":
+        return ["cols"] + (["grid"] if grid_ok else [])
+    return [layout]
+
+
+def _select_layout(job):
+    """Build the contract layout (rows) first, then the alternatives --layout asks for while the setup budget lasts;
+    validate each, time a full step (MAX over ranks), run the fastest.  The row-sharded figures are always reported.
+    Returns (step, {layout: (propagator, x_chunks, buffers)} for the layouts that exchange rows)."""
+    args, info, world = job.args, job.info, job.world
+    alts = _alternatives(job)
+    wanted = (["rows"] if args.layout in ("auto", "all", "rows") else []) + alts
+    ref = None
+    cands, timing, rejected, skipped = {}, {}, [], []
+    for name in wanted:
+        if name != "rows" and cands and not job.agree(job.budget_left() > 0):
+            skipped.append(name)                          # out of setup budget: the contract layout is already in hand
+            continue
+        # a candidate that raises is dropped on EVERY rank (the code path is the same on all of them, so an error is
+        # too; agree() keeps the control flow identical even if it is not)
+        c, good = None, True
+        _phase(f"select_layout: candidate {name!r}")
+        try:
+            if name != "rows" and ref is None:
+                ref = _Reference(job)
+            c = _build_rows(job) if name == "rows" else (_build_cols(job, ref) if name == "cols" else _build_grid(job, ref, 2))
+            c["step"]()                                   # warm: plans, communicators, staging buffers
+            job.sync_all()
+            good = bool(c["check"]())
+        except Exception as e:  # noqa: BLE001
+            good = False
+            sys.stderr.write(f"[bench] layout {name!r} failed on rank {job.rank}: {e!r}\n")
+        if not job.agree(good):
+            rejected.append(name)
+            continue
+        timing[name] = job.timed_s(c["step"], reps=3 if name == "rows" else 2, warm=0)
+        cands[name] = c
+    # Fallback rule (auto, >= 8 ranks): the communication-free feature-sharded layout is a known quantity -- every rank runs the
+    # whole chain on d/N columns, measured at 0.26 of the single-GPU step for 8 ranks (profiles/r01_layout_shares.log).  It is
+    # only built when neither exchanging layout beats that estimate (links slower than assumed), and the budget allows.
+    if (args.layout == "auto" and "cols" not in wanted and ref is not None and timing and world >= 8
+            and job.agree(min(timing.values()) * 1e3 > 0.26 * ref.ms and job.budget_left() > 0)):
+        _phase("select_layout: fallback candidate 'cols'")
+        c, good = None, True
+        try:
+            c = _build_cols(job, ref)
+            c["step"]()
+            job.sync_all()
+            good = bool(c["check"]())
+        except Exception as e:  # noqa: BLE001
+            good = False
+            sys.stderr.write(f"[bench] layout 'cols' failed on rank {job.rank}: {e!r}\n")
+        if job.agree(good):
+            timing["cols"] = job.timed_s(c["step"], reps=2, warm=0)
+            cands["cols"] = c
+            info["cols_fallback"] = "built because no exchanging layout beat the feature-sharded estimate"
+        else:
+            rejected.append("cols")
+    if not cands:
+        raise SystemExit(f"no multi-GPU layout passed validation (tried {wanted}, rejected {rejected})")
+    chosen = min(timing, key=timing.get)
+    info["layout"] = chosen
+    info["contract_layout"] = "rows"
+    info["layout_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in timing.items()}
+    if rejected:
+        info["layout_rejected"] = rejected
+    if skipped:
+        info["layout_skipped_setup_budget"] = skipped
+    if "rows" in timing:
+        info["rows"] = {"ms_per_step": round(timing["rows"] * 1e3, 3),
+                        "value": job.nnz * job.d * job.K / timing["rows"], "unit": "edge\u00b7featdim/s",
+                        "parallelism": cands["rows"]["describe"], "exchange": info.get("exchange"),
+                        "exchange_skipped_fraction": (info.get("halo") or {}).get("exchange_skipped_fraction_mean", 0.0)}
+    info["alternatives"] = {k: round(v * 1e3, 3) for k, v in timing.items() if k != "rows"}
+    info["parallelism"] = cands[chosen]["describe"] + ("" if chosen == "rows" else " [contract layout rows: see plan.rows]")
+    halves = {name: c["halves"] for name, c in cands.items() if "halves" in c}
+    if chosen == "rows":
+        job.drop_full()                                   # nothing replica-based runs in the timed region
+        ref = None
+    return cands[chosen]["step"], halves

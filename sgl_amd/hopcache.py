@@ -27,12 +27,11 @@ def _tensor_digest(t):
 def _bits_digest(bits):
     """order-sensitive 64-bit digest of an int32 tensor (wrapping int64 arithmetic on the device, chunked)"""
     bits = bits.contiguous().view(-1)
-    t = bits
-    total = torch.zeros((), dtype=torch.int64, device=t.device)
+    total = torch.zeros((), dtype=torch.int64, device=bits.device)
     step = 1 << 26
     for s in range(0, bits.numel(), step):
         part = bits[s:s + step].to(torch.int64)
-        pos = torch.arange(s, s + part.numel(), dtype=torch.int64, device=t.device)
+        pos = torch.arange(s, s + part.numel(), dtype=torch.int64, device=bits.device)
         total += ((part ^ (pos * -7046029254386353131)) * 1099511628211).sum()
     return int(total.item()) & 0xFFFFFFFFFFFFFFFF
 
