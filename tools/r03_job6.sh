@@ -9,3 +9,4 @@ cut -c1-300 gpurun_out/r03_bench_S1.json; tail -1 gpurun_out/r03_bench_S1.err
 timeout 900 tools/gpu_profile.sh S1_products > gpurun_out/r03_gpu_profile.log 2>&1; tail -3 gpurun_out/r03_gpu_profile.log
 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 600 python bench.py --force-sharded --no-cpu-baseline --steps 5 > gpurun_out/r03_bench_sharded1.json 2> gpurun_out/r03_bench_sharded1.err
 cut -c1-200 gpurun_out/r03_bench_sharded1.json; tail -2 gpurun_out/r03_bench_sharded1.err
+timeout 600 python tools/bench_aggregators.py > gpurun_out/r03_aggregators.log 2>&1; grep -c AGG gpurun_out/r03_aggregators.log
