@@ -117,11 +117,6 @@ int sgl_spmm_multi_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, int n_out,
                        int64_t d, const uint8_t *d_row_mask, void *stream);
 /* d_row_mask (optional, [n_rows] bytes on device): bit q set = destination q+1 receives this row; a peer whose shard
  * never references column i does not need row i of the next feature block, so its store is skipped (NULL = all). */
-/* Y = A . X with the pack step of the need-aware exchange in the epilogue: output row i is also stored at row d_pos[q][i] of
- * destination q (n_dest <= 7 matrices with Y's leading dimension: the peers' shares of the send buffer) when bit q of
- * d_row_mask[i] is set.  h_dest / h_pos: HOST arrays of device pointers.  Replaces the row-gather pass over Y; same bits. */
-int sgl_spmm_pack_f32(sgl_csr_t *csr, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, int n_dest,
-                      float *const *h_dest, const int32_t *const *h_pos, const uint8_t *d_row_mask, void *stream);
 
 /* The hop loop of GraphOp.propagate (sgl/operators/base_op.py:29-35) in one call: Y_1 = A.X_0, Y_k = A.Y_{k-1}.
  * h_y / h_ldy: HOST arrays of n_hops device pointers / leading dimensions.  A must be square. */

@@ -40,7 +40,6 @@ PROTOTYPES = {
     "sgl_csr_info": (c_int, [c_void_p, POINTER(c_int64)]),
     "sgl_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sgl_spmm_multi_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
-    "sgl_spmm_pack_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_spmm_chain_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_chain_graph_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64]),
     "sgl_chain_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -129,17 +129,13 @@ struct SpmmArgs {
     float *y_more[7];
     int32_t n_more;
     const uint8_t *row_mask;   // optional [n_rows]: bit q set = replica q needs this row (NULL = every replica gets it)
-    // optional per replica [n_rows]: the row of replica q that output row i goes to (sgl_spmm_pack_f32: the replicas are the
-    // packed send buffers of the need-aware exchange); NULL = the same row as in Y
-    const int32_t *pos_more[7];
     const int32_t *rowmap;     // optional [n_rows]: storage row -> output row (sgl_csr_set_rowmap); NULL = identity
 };
 
 struct MultiOut {
-    float *p[7];   // already offset to the item's first row (un-offset where pos[q] redirects the rows)
+    float *p[7];   // already offset to the item's first row
     int n;
     const uint8_t *mask;   // already offset to the item's first row (or nullptr)
-    const int32_t *pos[7];   // already offset to the item's first row: destination row in replica q (nullptr = same row as Y)
 };
 
 struct Epilogue {
@@ -325,10 +321,8 @@ __device__ __forceinline__ void run_rows(const int32_t *__restrict__ colb, const
                         const int need = mo.mask ? (int)mo.mask[ri] : 0x7f;   // wave-uniform: one byte per row
 #pragma unroll
                         for (int q = 0; q < 7; ++q)  // replicas (peer memory): posted stores, nothing waits on them
-                            if (q < mo.n && ((need >> q) & 1)) {
-                                const int64_t rq = mo.pos[q] ? (int64_t)mo.pos[q][ri] : ro;   // wave-uniform
-                                *reinterpret_cast<V *>(mo.p[q] + rq * ldo + colofs[ch]) = v;
-                            }
+                            if (q < mo.n && ((need >> q) & 1))
+                                *reinterpret_cast<V *>(mo.p[q] + ro * ldo + colofs[ch]) = v;
                     }
                 }
         }
@@ -357,7 +351,6 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         MultiOut solo;
         solo.n = 0;
         solo.mask = nullptr;
-        for (int q = 0; q < 7; ++q) solo.pos[q] = nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, false>(a.col + pc.begin, a.val + pc.begin, my_rel, 1, pc.len, a.x, a.ldx,
                                          a.partial + (int64_t)p * a.ldp, a.ldp, a.d, false, lane, none, 0, solo);
     } else {
@@ -392,11 +385,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmArgs a) {
         mo.n = MULTI ? a.n_more : 0;
         mo.mask = (MULTI && a.row_mask) ? a.row_mask + row_begin : nullptr;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const bool live_q = MULTI && q < a.n_more;
-            mo.pos[q] = (live_q && a.pos_more[q]) ? a.pos_more[q] + row_begin : nullptr;
-            mo.p[q] = live_q ? a.y_more[q] + (mo.pos[q] ? (int64_t)0 : (int64_t)row_begin * a.ldy) : nullptr;
-        }
+        for (int q = 0; q < 7; ++q) mo.p[q] = (MULTI && q < a.n_more) ? a.y_more[q] + (int64_t)row_begin * a.ldy : nullptr;
         run_rows<VEC, GROUP, NCH, U, NT, MULTI>(a.col + base, a.val + base, my_rel, nrows, tot, a.x, a.ldx,
                                          a.y + first * a.ldy, a.ldy, a.d, a.accumulate != 0, lane, epi,
                                          a.ldres, mo, rm);
@@ -428,7 +417,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int32_t *__restri
     const int need = mo.mask ? (int)mo.mask[row] : 0x7f;
 #pragma unroll
     for (int q = 0; q < 7; ++q)
-        if (q < mo.n && ((need >> q) & 1)) mo.p[q][(mo.pos[q] ? (int64_t)mo.pos[q][row] : (int64_t)row) * ldy + k] = acc;
+        if (q < mo.n && ((need >> q) & 1)) mo.p[q][(int64_t)row * ldy + k] = acc;
 }
 
 template <int VEC, int GROUP, int NCH, int U, bool NT>
@@ -675,7 +664,6 @@ struct EpiHost {
     int n_more = 0;             // replicas of Y (sgl_spmm_multi_f32)
     float *y_more[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const uint8_t *row_mask = nullptr;
-    const int32_t *pos_more[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // running aggregate (sgl_spmm_acc_f32)
     float *acc = nullptr;
     int64_t ldacc = 0;
@@ -751,10 +739,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
     a.acc_mode = eh.acc_mode;
     a.n_more = eh.n_more;
     a.row_mask = eh.row_mask;
-    for (int q = 0; q < 7; ++q) {
-        a.y_more[q] = eh.y_more[q];
-        a.pos_more[q] = eh.pos_more[q];
-    }
+    for (int q = 0; q < 7; ++q) a.y_more[q] = eh.y_more[q];
     a.rowmap = h->d_rowmap;
     a.piece_blocks = (int32_t)((h->n_pieces + waves - 1) / waves);
     const int64_t item_blocks = (h->n_items + waves - 1) / waves;
@@ -802,10 +787,7 @@ static int spmm_slice(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, i
         MultiOut fmo;
         fmo.n = eh.n_more;
         fmo.mask = eh.row_mask;
-        for (int q = 0; q < 7; ++q) {
-            fmo.p[q] = eh.y_more[q];
-            fmo.pos[q] = eh.pos_more[q];
-        }
+        for (int q = 0; q < 7; ++q) fmo.p[q] = eh.y_more[q];
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)fg), dim3(256), 0, st, h->d_rowmap ? h->d_long_out : h->d_long_row,
                            h->d_long_first, h->d_partial, a.ldp,
                            d_y, ldy, d, accumulate, eh.res, eh.ldres, fe, fmo);
@@ -875,25 +857,6 @@ SGL_EXPORT int sgl_spmm_multi_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, i
     eh.n_more = n_out - 1;
     for (int q = 1; q < n_out; ++q) eh.y_more[q - 1] = h_y[q];
     return spmm_impl(h, d_x, ldx, h_y[0], ldy, d, 0, stream, eh, "sgl_spmm_multi_f32");
-}
-
-// Y = A X and, in the same pass, the PACK step of the need-aware exchange (sgl_amd/dist/halo.py): output row i is also stored at
-// row d_pos[q][i] of destination q -- the share of the send buffer that peer q receives -- when bit q of d_row_mask[i] is set.
-// The rows a peer gathers leave the producing wavefront directly; the separate row-gather pass over Y (sgl_gather_rows_f32) and
-// its launch disappear.  Destinations share Y's leading dimension.  A row-mapped handle is refused (use the gather pass).
-SGL_EXPORT int sgl_spmm_pack_f32(sgl_csr_t *h, const float *d_x, int64_t ldx, float *d_y, int64_t ldy, int64_t d, int n_dest,
-                                 float *const *h_dest, const int32_t *const *h_pos, const uint8_t *d_row_mask, void *stream) {
-    SGL_REQUIRE(n_dest >= 0 && n_dest <= 7, "sgl_spmm_pack_f32: n_dest must be in [0, 7]");
-    SGL_REQUIRE(n_dest == 0 || (h_dest && h_pos && d_row_mask), "sgl_spmm_pack_f32: destinations need pointers, positions and the row mask");
-    EpiHost eh;
-    eh.row_mask = d_row_mask;
-    eh.n_more = n_dest;
-    for (int q = 0; q < n_dest; ++q) {
-        SGL_REQUIRE(h_pos[q] != nullptr, "sgl_spmm_pack_f32: NULL position array");
-        eh.y_more[q] = h_dest[q];
-        eh.pos_more[q] = h_pos[q];
-    }
-    return spmm_impl(h, d_x, ldx, d_y, ldy, d, 0, stream, eh, "sgl_spmm_pack_f32");
 }
 
 // X_1 = A X_0, X_2 = A X_1, ... : the whole hop loop of GraphOp.propagate (base_op.py:29-35) issued from one call, so a

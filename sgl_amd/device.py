@@ -283,35 +283,6 @@ class DeviceCSR:
                                            ptr(row_mask) if row_mask is not None else None, current_stream_ptr()),
                   "sgl_spmm_multi_f32")
 
-    def spmm_pack(self, x, out, dests, positions, row_mask):
-        """out = A @ x and, in the same kernel, the pack step of the need-aware exchange (sgl_spmm_pack_f32): row i of the product
-        is also stored at row positions[q][i] of dests[q] when bit q of row_mask[i] is set.  dests: <= 7 [*, d] matrices with out's
-        row pitch (the peers' shares of a send buffer); positions: int32 [n_rows] device tensors; row_mask: uint8 [n_rows]."""
-        _check_mat(x, "x")
-        _check_mat(out, "out")
-        d = x.shape[1]
-        if x.shape[0] != self.shape[1] or out.shape != (self.shape[0], d):
-            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
-        n_dest = len(dests)
-        if n_dest > 7 or len(positions) != n_dest:
-            raise ValueError("at most 7 destinations, one position array each")
-        for t in dests:
-            if t.numel():
-                _check_mat(t, "dest")
-                if t.shape[1] != d or _ld(t) != _ld(out):
-                    raise ValueError("every destination needs the width and row pitch of `out`")
-        for p_ in positions:
-            if not (p_.is_cuda and p_.dtype == torch.int32 and p_.is_contiguous() and p_.numel() == self.shape[0]):
-                raise ValueError("positions must be contiguous int32 CUDA tensors with one entry per row")
-        if n_dest and not (row_mask.is_cuda and row_mask.dtype == torch.uint8 and row_mask.is_contiguous() and row_mask.numel() == self.shape[0]):
-            raise ValueError("row_mask must be a contiguous uint8 CUDA tensor with one entry per row")
-        dp = (c_void_p * max(n_dest, 1))(*[(t.data_ptr() if t.numel() else out.data_ptr()) for t in dests])
-        pp = (c_void_p * max(n_dest, 1))(*[p_.data_ptr() for p_ in positions])
-        with torch.cuda.device(self.device):
-            check(lib().sgl_spmm_pack_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), d, n_dest, dp, pp,
-                                          ptr(row_mask) if n_dest else None, current_stream_ptr()), "sgl_spmm_pack_f32")
-        return out
-
     def spmm_chain(self, x, n_hops, outs=None):
         """[A x, A^2 x, ..., A^k x] with ONE library call (the hop loop runs in C).  x: [n, d] row-major CUDA; the
         results are row-padded buffers of the same width as x (or the caller's `outs`)."""

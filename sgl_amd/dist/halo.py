@@ -143,27 +143,6 @@ class HaloPlan:
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_own):
             raise RuntimeError("halo plan: a peer asked for a row outside this rank's block")
 
-    def pack_maps(self):
-        """(peers, positions, row_mask) for the pack step fused into the SpMM epilogue (sgl_spmm_pack_f32): peers = the other
-        ranks in rank order (at most 7), positions[k][i] = the row of peer k's share that own row i is packed to, bit k of
-        row_mask[i] = peer k gathers own row i.  None when there are more than 7 peers."""
-        if self.world - 1 > 7:
-            return None
-        if getattr(self, "_pack_maps", None) is None:
-            dev = self.send_idx.device
-            peers = [q for q in range(self.world) if q != self.rank]
-            mask = torch.zeros(max(self.n_own, 1), dtype=torch.uint8, device=dev)[:self.n_own]
-            positions = []
-            for k, q in enumerate(peers):
-                rows = self.send_rows[q].to(torch.int64)
-                pos = torch.zeros(max(self.n_own, 1), dtype=torch.int32, device=dev)[:self.n_own]
-                if rows.numel():
-                    pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=dev)
-                    mask[rows] |= (1 << k)
-                positions.append(pos.contiguous())
-            self._pack_maps = (peers, positions, mask.contiguous())
-        return self._pack_maps
-
     def relabel(self, col):
         """the block's GLOBAL column ids as positions in the compact table (int32, same order)"""
         dev = col.device
@@ -202,11 +181,8 @@ class HaloPropagator:
     spmm(x_compact [n_compact, w], out [n_own, w]) : the local SpMM on relabelled columns
     Tables are [n_compact, w]; rows [0, n_own) are the rank's own, the rest ghosts."""
 
-    def __init__(self, plan, spmm, staged=None, spmm_pack=None):
-        """spmm_pack(x_compact, out, dests): optional -- the SpMM with the pack step in its epilogue (dests = the peers' shares of
-        the send buffer in plan.pack_maps() order); used by the hop loop instead of spmm + the row-gather pack pass."""
+    def __init__(self, plan, spmm, staged=None):
         self.plan, self.spmm = plan, spmm
-        self.spmm_pack = spmm_pack
         self.staged = staged
         self.lo, self.hi, self.n = plan.lo, plan.hi, plan.n
         self.rank, self.world, self.group = plan.rank, plan.world, plan.group
@@ -239,33 +215,13 @@ class HaloPropagator:
             torch.index_select(y_own, 0, pl.send_idx, out=buf)
         return buf
 
-    def _send_buffer(self, w, like, key):
-        rows = int(self.plan.send_off[-1])
-        buf = self._send.get(key)
-        if buf is None or buf.shape != (rows, w) or buf.device != like.device:
-            buf = self._send[key] = torch.empty((rows, w), dtype=like.dtype, device=like.device)
-        return buf
-
-    def _spmm_packed(self, x, y_own, key):
-        """SpMM into y_own with the peers' shares of the send buffer filled by the same kernel; False if that form is not available"""
-        if self.spmm_pack is None or self.world == 1 or not y_own.is_cuda or self.plan.n_own == 0:
-            return False
-        maps = self.plan.pack_maps()
-        if maps is None:
-            return False
-        pl = self.plan
-        buf = self._send_buffer(y_own.shape[1], y_own, key)
-        dests = [buf[pl.send_off[q]:pl.send_off[q + 1]] for q in maps[0]]
-        self.spmm_pack(x, y_own, dests)
-        return True
-
-    def begin_exchange(self, y_own, table_next, key=0, packed=False):
-        """pack my rows for the peers (unless the SpMM already did: packed=True) and start the grouped send / recv that fills the
-        ghost ranges of table_next.  Returns an object with wait() (stream-level on RCCL)."""
+    def begin_exchange(self, y_own, table_next, key=0):
+        """pack my rows for the peers and start the grouped send / recv that fills the ghost ranges of table_next.
+        Returns an object with wait() (stream-level on RCCL)."""
         pl = self.plan
         if self.world == 1:
             return _post(self.group, [], [])
-        buf = self._send_buffer(y_own.shape[1], y_own, key) if packed else self._pack(y_own, key)
+        buf = self._pack(y_own, key)
         staged = _is_staged(self.group, table_next) if self.staged is None else self.staged
         if self.collective and not staged:
             from .transports import _Works
@@ -337,15 +293,12 @@ class HaloPropagator:
                     y_own = y_buffers[c][h - 1]
                 else:
                     y_own = torch.empty((n_own, w_c), dtype=tables[c].dtype, device=tables[c].device)
-                packed = False
                 if n_own:
-                    packed = (not last) and self._spmm_packed(cur[c], y_own, c)
-                    if not packed:
-                        self.spmm(cur[c], y_own)
+                    self.spmm(cur[c], y_own)
                 if not last:
                     if not direct:
                         t_next[:n_own].copy_(y_own)
-                    pending[c] = self.begin_exchange(y_own, t_next, key=c, packed=packed)
+                    pending[c] = self.begin_exchange(y_own, t_next, key=c)
                     cur[c] = t_next
                 outs.append(y_own)
             hops.append(outs)
@@ -398,15 +351,9 @@ def block_halo(block, bounds, group=None, strict=False, reorder=None):
         if rowmap is not None:
             rowptr, ccol, val = permute_rows(rowptr, ccol, val, rowmap)
     handle = DeviceCSR(rowptr, ccol, val, (block.n_local, plan.n_compact), strict=strict)
-    spmm_pack = None
     if rowmap is not None:
         handle.set_rowmap(rowmap)
-    elif ccol.is_cuda and plan.world > 1 and plan.pack_maps() is not None:
-        _, positions, mask = plan.pack_maps()              # the pack step rides on the SpMM's epilogue (no row map, <= 7 peers)
-
-        def spmm_pack(x, out, dests):
-            handle.spmm_pack(x, out, dests, positions, mask)
-    return plan, HaloPropagator(plan, lambda x, out: handle.spmm(x, out=out), spmm_pack=spmm_pack), handle
+    return plan, HaloPropagator(plan, lambda x, out: handle.spmm(x, out=out)), handle
 
 
 def halo_checksums(plan, table, y_own):

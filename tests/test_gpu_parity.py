@@ -1062,48 +1062,6 @@ def test_reorder_auto_and_row_sharded_blocks(cuda):
                     assert op.halo_plan.reorder_info["applied"] is True and op._props["halo"][2].rowmap is not None
 
 
-@pytest.mark.parametrize("d", [100, 36, 4, 1100])
-def test_pack_step_in_the_spmm_epilogue_equals_the_gather_pass(cuda, d):
-    """sgl_spmm_pack_f32: the rows a peer gathers leave the producing wavefront straight into that peer's share of the send buffer
-    (positions + row mask from HaloPlan.pack_maps) -- the same send buffer, bit for bit, as SpMM followed by the row-gather pack
-    pass, for rows walked by items AND long rows folded by the fix-up kernel, narrow / wide / column-sliced widths; the product
-    itself is untouched.  Plan of rank 1 of a 4-rank job, built offline."""
-    from sgl_amd import device as dev
-    from sgl_amd.dist import HaloPlan, HaloPropagator, balanced_bounds
-    big = long_row_graph(n=1600, seed=21)
-    big = (big + big.T).tocsr()
-    big.sort_indices()
-    n = big.shape[0]
-    ptr, col, val = big.indptr.astype(np.int64), big.indices.astype(np.int32), big.data.astype(np.float32)
-    bounds = balanced_bounds(ptr, 4)
-    rank = 1
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    cols = lambda q: torch.from_numpy(col[ptr[bounds[q]]:ptr[bounds[q + 1]]]).to(cuda)      # noqa: E731
-    plan = HaloPlan.offline(rank, bounds, n, cols)
-    ccol = plan.relabel(cols(rank))
-    rp = torch.from_numpy(ptr[lo:hi + 1] - ptr[lo]).to(cuda)
-    vv = torch.from_numpy(val[ptr[lo]:ptr[hi]]).to(cuda)
-    csr = dev.DeviceCSR(rp, ccol, vv, (hi - lo, plan.n_compact), long_row_nnz=128)
-    assert csr.info()["n_long_rows"] > 0
-    peers, positions, mask = plan.pack_maps()
-    assert peers == [0, 2, 3] and int(mask.max()) <= 7 and int(plan.send_off[-1]) > 0
-    table = torch.from_numpy(hash_matrix(plan.n_compact, d, seed=d)).to(cuda)
-    y_ref = csr.spmm(table)
-    prop = HaloPropagator(plan, lambda x, out: csr.spmm(x, out=out), spmm_pack=lambda x, out, dests: csr.spmm_pack(x, out, dests, positions, mask))
-    want = prop._pack(y_ref.contiguous(), "ref").clone()
-    y = torch.full((hi - lo, d), float("nan"), device=cuda)
-    buf = prop._send_buffer(d, y, "fused")
-    buf.fill_(float("nan"))
-    dests = [buf[plan.send_off[q]:plan.send_off[q + 1]] for q in peers]
-    csr.spmm_pack(table, y, dests, positions, mask)
-    assert torch.equal(y, y_ref) and torch.equal(buf, want)
-    # through the propagator's hook (what the hop loop calls)
-    y2 = torch.empty_like(y)
-    prop._send.pop("fused")
-    prop.world = 4                                         # the plan's world (the propagator was built without a process group)
-    assert prop._spmm_packed(table, y2, "fused") and torch.equal(prop._send["fused"], want) and torch.equal(y2, y_ref)
-
-
 def test_aggregators_fuzz_random_shapes(cuda):
     """40 random (rows, width, hops, padded / dense) shapes through every aggregator kernel family: the bit-exact ones
     (sum / max / concat) against numpy bit for bit, the weighted ones and their gradients within tolerance -- widths 1..600

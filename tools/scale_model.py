@@ -67,21 +67,6 @@ def simulate(spmm, pack, xfer, k=K):
     return t_comp
 
 
-def simulate_fused(spmm, fused, xfer, k=K):
-    """the same schedule with the pack step in the SpMM's epilogue: every exchanging hop runs the fused kernel, the last the plain one"""
-    C = len(spmm)
-    t_comp = t_link = 0.0
-    landed = [0.0] * C
-    for h in range(1, k + 1):
-        for c in range(C):
-            start = max(t_comp, landed[c])
-            t_comp = start + (fused[c] if h < k else spmm[c])
-            if h < k:
-                t_link = max(t_link, t_comp) + xfer[c]
-                landed[c] = t_link
-    return t_comp
-
-
 def rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, device):
     lo, hi = int(bounds[r]), int(bounds[r + 1])
     nb, ne = int(rp_host[lo]), int(rp_host[hi])
@@ -98,24 +83,17 @@ def rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, de
     y_full = torch.empty((hi - lo, d), device=device)
     out["spmm_whole"] = timed(lambda: csr.spmm(t0, out=y_full))
 
-    maps = plan.pack_maps()
-
     def per_chunk(chs):
-        sp, pk, fused = [], [], []
+        sp, pk = [], []
         for a, b in chs:
             t = t0[:, a:b].contiguous()
             y = torch.empty((hi - lo, b - a), device=device)
             sp.append(timed(lambda: csr.spmm(t, out=y)))
             buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
             pk.append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf)) if buf.shape[0] else 0.0)
-            if maps is not None and buf.shape[0]:
-                dests = [buf[plan.send_off[q]:plan.send_off[q + 1]] for q in maps[0]]
-                fused.append(timed(lambda: csr.spmm_pack(t, y, dests, maps[1], maps[2])))
-            else:
-                fused.append(sp[-1] + pk[-1])
             del t, y, buf
-        return sp, pk, fused
-    out["spmm"], out["pack"], out["fused"] = per_chunk(chunks)
+        return sp, pk
+    out["spmm"], out["pack"] = per_chunk(chunks)
     out["alt"] = {nc: per_chunk(column_chunks(d, nc)) for nc in ALT_CHUNKS}
     # the same block against the FULL replica (global column ids): what the plain all-gather layout multiplies
     csr_g = dev.DeviceCSR(rp_local, col[nb:ne], val[nb:ne], (hi - lo, n))
@@ -154,33 +132,29 @@ def main():
     print(f"`python tools/scale_model.py`: workload S1 (N = {n}, nnz(A_hat) = {nnz}, d = {d}, k = {K}); single-GPU step measured here: "
           f"**{t1:.2f} ms** (3 hops).  Column chunks {chunks}.  Every rank's block, compact table, SpMM and pack kernel are built and timed on this GPU; "
           "the exchange enters as a link rate B per direction per link (xGMI: 76.8 GB/s peak).\n")
-    print("| G | rank | own rows | ghost rows | skipped | spmm whole (compact / full replica) ms | spmm per chunk ms | pack per chunk ms | spmm with the pack in its epilogue, per chunk ms | in-bound MB (need-aware / full) | busiest link in / out MB |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| G | rank | own rows | ghost rows | skipped | spmm whole (compact / full replica) ms | spmm per chunk ms | pack per chunk ms | in-bound MB (need-aware / full) | busiest link in / out MB |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     model = {}
     for G in (2, 4, 8):
         bounds = balanced_bounds(rp_host, G)
         per_rank = [rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, device) for r in range(G)]
         for m in per_rank:
             print(f"| {G} | {m['rank']} | {m['own']} | {m['ghost']} | {m['skipped']:.3f} | {m['spmm_whole']:.3f} / {m['spmm_whole_full_replica']:.3f} | "
-                  f"{' + '.join(f'{t:.3f}' for t in m['spmm'])} | {' + '.join(f'{t:.3f}' for t in m['pack'])} | {' + '.join(f'{t:.3f}' for t in m['fused'])} | "
+                  f"{' + '.join(f'{t:.3f}' for t in m['spmm'])} | {' + '.join(f'{t:.3f}' for t in m['pack'])} | "
                   f"{m['in_total'] / 1e6:.0f} / {m['full_in_total'] / 1e6:.0f} | {m['in_peer_max'] / 1e6:.1f} / {m['out_peer_max'] / 1e6:.1f} |")
         model[G] = per_rank
     print()
     print("## Predicted ms per step (k = 3) and speed-up over the single-GPU step\n")
     print("Schedule simulated: compute stream = spmm(chunk A), pack(A), spmm(B), pack(B), ...; one grouped exchange per chunk and hop whose duration is "
           "the busiest link's bytes / B; hop h+1 of a chunk waits only for that chunk's exchange; the slowest rank decides.  "
-          "`halo` = need-aware packed exchange with a separate pack kernel, `halo_fused` = the pack step in the SpMM epilogue (sgl_spmm_pack_f32: what the hop loop runs), `full` = every row to every rank.\n")
+          "`halo` = need-aware packed exchange, `full` = every row to every rank (no pack kernel).\n")
     print("| G | exchange | " + " | ".join(f"B = {b} GB/s" for b in rates) + " | no exchange at all |")
     print("|---|---|" + "---|" * (len(rates) + 1))
 
     def step_ms(G, B, kind):
         worst = 0.0
         for m in model[G]:
-            if kind == "halo_fused":
-                link = max(m["in_peer_max"], m["out_peer_max"])
-                xfer = [link * (b - a) / d / (B * 1e9) * 1e3 for a, b in chunks]
-                t = simulate_fused(m["spmm"], m["fused"], xfer)
-            elif kind == "halo":
+            if kind == "halo":
                 link = max(m["in_peer_max"], m["out_peer_max"])
                 xfer = [link * (b - a) / d / (B * 1e9) * 1e3 for a, b in chunks]
                 t = simulate(m["spmm"], m["pack"], xfer)
@@ -192,7 +166,7 @@ def main():
         return worst
 
     for G in (2, 4, 8):
-        for kind in ("halo_fused", "halo", "full"):
+        for kind in ("halo", "full"):
             cells = []
             for B in rates:
                 t = step_ms(G, B, kind)
@@ -200,7 +174,7 @@ def main():
             t_inf = step_ms(G, 1e9, kind)
             print(f"| {G} | {kind} | " + " | ".join(cells) + f" | {t_inf:.2f} ms ({t1 / t_inf:.2f}x) |")
     print()
-    print("### Pipelining granularity: the need-aware exchange (pack fused into the SpMM) with 1 / 3 / 4 column chunks instead of 2\n")
+    print("### Pipelining granularity: the need-aware exchange with 1 / 3 / 4 column chunks instead of 2\n")
     print("More chunks shorten the un-overlapped head (first chunk's SpMM + pack) and tail (last chunk's last SpMM) of the step; every chunk still "
           "gathers whole 128-byte lines (d = 100 -> 32 + 32 + 32 + 4), so the SpMM total barely moves.\n")
     print("| G | chunks | spmm per chunk ms (slowest rank) | " + " | ".join(f"B = {b} GB/s" for b in rates) + " |")
@@ -214,13 +188,13 @@ def main():
                 for m in model[G]:
                     link = max(m["in_peer_max"], m["out_peer_max"])
                     xfer = [link * (b - a) / d / (B * 1e9) * 1e3 for a, b in chs]
-                    t = simulate_fused(m["alt"][nc][0], m["alt"][nc][2], xfer)
+                    t = simulate(m["alt"][nc][0], m["alt"][nc][1], xfer)
                     if t > worst:
                         worst, slow = t, m
                 cells.append(f"{worst:.2f} ms ({t1 / worst:.2f}x)")
             print(f"| {G} | {len(chs)} {chs} | {' + '.join(f'{v:.3f}' for v in slow['alt'][nc][0])} | " + " | ".join(cells) + " |")
     print()
-    for kind in ("halo_fused", "halo", "full"):
+    for kind in ("halo", "full"):
         lo_b, hi_b = 1.0, 2000.0
         if t1 / step_ms(8, hi_b, kind) < 5.0:
             print(f"* `{kind}`: 5x at 8 GPUs is out of reach at any link rate with this schedule ({t1 / step_ms(8, hi_b, kind):.2f}x with free links).")
@@ -272,34 +246,31 @@ def papers(device):
           f"({plan.send_off[-1] * d * 4 / 1e9:.1f} GB packed per hop); in-bound {plan.n_ghost * d * 4 / 1e9:.1f} GB per hop instead of "
           f"{plan.rows_in_full * d * 4 / 1e9:.1f} GB; busiest link in {max(int(t.numel()) for t in plan.need) * d * 4 / 1e9:.2f} GB, out "
           f"{max(int(t.numel()) for t in plan.send_rows) * d * 4 / 1e9:.2f} GB.\n")
-    spmm, pack, fused = [], [], []
-    maps = plan.pack_maps()
+    spmm, pack = [], []
     for a, b in chunks:
         t = torch.empty((plan.n_compact, b - a), device=device).uniform_(-1, 1)
         y = torch.empty((plan.n_own, b - a), device=device)
         spmm.append(timed(lambda: csr.spmm(t, out=y), reps=3, warm=1))
         buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
         pack.append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf), reps=3, warm=1))
-        dests = [buf[plan.send_off[q]:plan.send_off[q + 1]] for q in maps[0]]
-        fused.append(timed(lambda: csr.spmm_pack(t, y, dests, maps[1], maps[2]), reps=3, warm=1))
-        del t, y, buf, dests
+        del t, y, buf
     t = torch.empty((plan.n_compact, d), device=device).uniform_(-1, 1)
     y = torch.empty((plan.n_own, d), device=device)
     whole = timed(lambda: csr.spmm(t, out=y), reps=3, warm=1)
     del t, y
     print(f"measured: SpMM whole width {whole:.2f} ms (the same block against the full 57 GB replica: 37-43 ms, profiles/r02_*), per chunk "
-          f"{' + '.join(f'{v:.2f}' for v in spmm)} ms, pack per chunk {' + '.join(f'{v:.2f}' for v in pack)} ms, SpMM with the pack in its epilogue {' + '.join(f'{v:.2f}' for v in fused)} ms.\n")
+          f"{' + '.join(f'{v:.2f}' for v in spmm)} ms, pack per chunk {' + '.join(f'{v:.2f}' for v in pack)} ms.\n")
     link = max(max(int(t_.numel()) for t_ in plan.need), max(int(t_.numel()) for t_ in plan.send_rows)) * d * 4
     full_link = max(int(bounds[q + 1] - bounds[q]) for q in range(1, G)) * d * 4
     t1 = 3 * 320.0
     print("| exchange | " + " | ".join(f"B = {b} GB/s" for b in (25, 35, 45, 55, 65, 76.8)) + " |")
     print("|---|" + "---|" * 6)
-    for kind in ("halo_fused", "halo", "full"):
+    for kind in ("halo", "full"):
         cells = []
         for B in (25, 35, 45, 55, 65, 76.8):
-            lk = full_link if kind == "full" else link
+            lk = link if kind == "halo" else full_link
             xfer = [lk * (b - a) / d / (B * 1e9) * 1e3 for a, b in chunks]
-            ts = simulate_fused(spmm, fused, xfer) if kind == "halo_fused" else simulate(spmm, pack if kind == "halo" else [0.0, 0.0], xfer)
+            ts = simulate(spmm, pack if kind == "halo" else [0.0, 0.0], xfer)
             cells.append(f"{ts:.0f} ms ({t1 / ts:.2f}x)")
         print(f"| {kind} | " + " | ".join(cells) + " |")
     print(f"\n(speed-up against 3 x 320 ms = the whole graph on one GPU, `profiles/r02_bench_S1.json`; rank 0 only, SpMM times of the compact "
