@@ -2263,3 +2263,16 @@ def test_rccl_backend_accepts_the_calls_the_layouts_make(cuda, tmp_path):
     s.close()
     mp.spawn(_rccl_world1_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / "ok.txt").read() == "ok"
+
+
+def test_python_examples_run_end_to_end(cuda):
+    """the Python examples as a user would start them (small sizes): quick-start SGC, GAMLP label reuse, row-sharded NAFS flow"""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for script, extra, expect in (("sgc_synthetic.py", ["--nodes", "4000", "--feat", "64", "--epochs", "5"], "test acc"),
+                                  ("nafs_row_sharded.py", ["--nodes", "200000", "--hops", "3", "--feat", "64"], "NAFS row-sharded x1")):
+        r = subprocess.run([_sys.executable, os.path.join(root, "examples", script), *extra], capture_output=True, text=True, timeout=600,
+                           env=env)
+        assert r.returncode == 0 and expect in r.stdout, (script, r.stdout[-800:], r.stderr[-1500:])
