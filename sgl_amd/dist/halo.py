@@ -25,6 +25,9 @@ from .sharded_adj import _world
 from .transports import _post
 
 
+_CHUNK = 1 << 26     # elements per pass of the marking / relabelling loops (bounds the int64 temporaries; tests shrink it)
+
+
 def _global_rank(group, q):
     return dist.get_global_rank(group, q) if (group is not None and dist.is_initialized()) else q
 
@@ -84,7 +87,7 @@ class HaloPlan:
     @staticmethod
     def _marks(n, col):
         mark = torch.zeros(n, dtype=torch.bool, device=col.device)
-        for part in col.split(1 << 26):
+        for part in col.split(_CHUNK):
             mark[part.long()] = True
         return mark
 
@@ -153,7 +156,7 @@ class HaloPlan:
             if m:
                 lut[self.need[q]] = torch.arange(self.ghost_off[q], self.ghost_off[q] + m, dtype=torch.int32, device=dev)
         out = torch.empty_like(col)
-        step = 1 << 26
+        step = _CHUNK
         for s in range(0, col.numel(), step):
             out[s:s + step] = lut[col[s:s + step].long()]
         if out.numel() and int(out.min()) < 0:

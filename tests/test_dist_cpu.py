@@ -202,7 +202,8 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import oracle
     from inputs import hash_matrix
-    from sgl_amd.dist import HaloPlan, HaloPropagator, balanced_bounds, halo_checksums
+    from sgl_amd.dist import HaloPlan, HaloPropagator, balanced_bounds, halo, halo_checksums
+    halo._CHUNK = 777            # the marking / relabelling loops run in many passes (at papers100M size they do: 1.7 G non-zeros per rank)
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
