@@ -25,6 +25,10 @@ reorder       None -> the rows of A_hat are processed in the caller's node order
               Pays on graphs that HAVE communities their ids do not show (-32 % per hop on the shuffled community graph of
               tools/bench_reorder.py), neutral on the random benchmark graph; "auto" -> run the ordering and keep it only
               when it makes the graph measurably more local than its own ids do (sgl_amd.reorder.plan_rowmap)
+trace         True (SGL_AMD_TRACE=1) -> every GraphOp.propagate() records the wall time of its phases (adjacency: fingerprint /
+              upload / normalise / plan; features: upload; hops: the k SpMMs; output: download or cache), synchronising at the phase
+              ends, in `op.last_trace` and prints them on stderr -- the reference times its whole preprocess() with time.time() and a
+              print (tasks/node_classification.py:34-38)
 hop_cache_dir None -> every propagate() computes; a directory -> the hop matrices of propagate() are kept on disk under a key of
               the CONTENT of adjacency + features + operator parameters and loaded on a hit (sgl_amd/hopcache.py; the reference
               recomputes them in every run of every task)
@@ -49,3 +53,4 @@ fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)
 reorder = os.environ.get("SGL_AMD_REORDER") or None
 hop_cache_dir = os.environ.get("SGL_AMD_HOP_CACHE") or None
+trace = _env_bool("SGL_AMD_TRACE", False)

@@ -194,6 +194,35 @@ class GraphOp:
         return acc[:, :d] if acc.shape[1] != d else acc
 
     def propagate(self, adj, feature):
+        if not config.trace:
+            return self._propagate_or_cache(adj, feature)
+        # SGL_AMD_TRACE: wall time per phase (the phases mark themselves through self._mark; synchronised at their ends)
+        import sys
+        import time
+        marks = [("start", time.perf_counter())]
+
+        def mark(name):
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+        self._mark = mark
+        try:
+            out = self._propagate_or_cache(adj, feature)
+            mark("output")
+        finally:
+            self._mark = None
+        self.last_trace = {b[0] + "_s": round(b[1] - a[1], 6) for a, b in zip(marks, marks[1:])}
+        self.last_trace["total_s"] = round(marks[-1][1] - marks[0][1], 6)
+        sys.stderr.write(f"[sgl_amd trace] {type(self).__name__}.propagate: " +
+                         " ".join(f"{k}={v * 1e3:.2f}ms" for k, v in self.last_trace.items()) + "\n")
+        return out
+
+    _mark = None
+
+    def _phase_done(self, name):
+        if self._mark is not None:
+            self._mark(name)
+
+    def _propagate_or_cache(self, adj, feature):
         cache_dir = self._opt("hop_cache_dir")
         if not cache_dir or self._opt("host_output") or self._opt("slab_hops"):
             return self._propagate(adj, feature)
@@ -213,8 +242,10 @@ class GraphOp:
     def _propagate(self, adj, feature, checked=False):
         if not checked:
             self._checked(adj, feature)
+        self._phase_done("adjacency")
         device = self._adj.device
         cur = self._device_features(feature)
+        self._phase_done("features")
         # the k hops run inside one library call, over the padded width so every d gets 16-byte lanes (pad columns
         # are zeros and stay zeros under propagation)
         d = cur.shape[1]
@@ -233,6 +264,7 @@ class GraphOp:
             if pooled is not None:
                 return pooled
         prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
+        self._phase_done("hops")
 
         if self._opt("host_output"):
             # reference contract: CPU FloatTensors (ordinary pageable memory, like the reference's).  The download runs through

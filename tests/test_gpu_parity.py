@@ -730,6 +730,30 @@ def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
     hostpool.trim()
 
 
+def test_trace_records_the_phases_of_a_propagation(goldens, cuda, capsys):
+    """SGL_AMD_TRACE (tracing): propagate() records the wall time of its phases and prints one line; results are
+    untouched; off by default"""
+    from sgl_amd import config
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g = goldens.graph("pl2000")
+    x = hash_matrix(2000, 40, seed=1)
+    plain = LaplacianGraphOp(3).propagate(g, x)
+    op = LaplacianGraphOp(3)
+    config.trace = True
+    try:
+        traced = op.propagate(g, x)
+        again = op.propagate(g, x)
+    finally:
+        config.trace = False
+    assert all(torch.equal(a, b) for a, b in zip(plain, traced)) and all(torch.equal(a, b) for a, b in zip(plain, again))
+    t = op.last_trace
+    assert set(t) == {"adjacency_s", "features_s", "hops_s", "output_s", "total_s"} and all(v >= 0 for v in t.values())
+    assert abs(t["total_s"] - (t["adjacency_s"] + t["features_s"] + t["hops_s"] + t["output_s"])) < 1e-4
+    err = capsys.readouterr().err
+    assert err.count("[sgl_amd trace] LaplacianGraphOp.propagate:") == 2 and "hops_s=" in err
+    assert not hasattr(LaplacianGraphOp(3), "last_trace")
+
+
 def test_on_disk_hop_cache_is_keyed_on_content(goldens, cuda, tmp_path):
     """GraphOp(hop_cache_dir=...): a second operator (another process, another run) finds the hop matrices of the same adjacency
     CONTENT + features + parameters on disk and loads them bit for bit; any change of a value, a feature entry, r, alpha or
