@@ -31,13 +31,21 @@ class ShardedGraphOp:
     (row-sharded layout only: grid layouts address ranks of the default group)."""
 
     def __init__(self, prop_steps, r=0.5, alpha=None, pieces=2, col_chunks=2, strict_order=False, group=None,
-                 device=None, row_groups=None, transport=None, symmetric=True, reorder=None):
+                 device=None, row_groups=None, transport=None, symmetric=True, reorder=None, partition=None):
         self.prop_steps, self.r, self.alpha = prop_steps, r, alpha
         self.pieces, self.col_chunks, self.strict_order, self.group = pieces, col_chunks, strict_order, group
         self.device = device
         self.row_groups, self.transport = row_groups, transport
         self.symmetric = symmetric
         self.reorder = reorder                # None / "community" / "auto": RowBlock inputs only (rows ordered inside the rank's block)
+        # None / "community" / "auto": full-adjacency inputs, row-sharded layout: the node ids are RELABELLED in a community order
+        # before the matrix is cut into row blocks, so that a block references mostly its own rows and the need-aware exchange
+        # moves a fraction of the foreign rows (50 % instead of 98 % at 8 ranks on a graph with 80 % intra-community edges,
+        # profiles/r03_partition_locality.log).  The hop shards then belong to the nodes `self.node_ids` (original ids of rows
+        # [lo, hi) of the relabelled problem); gather_full(..., original_order=True) undoes the relabelling.  P A P^T sorts a row's
+        # terms by NEW column id, so hops agree with the unpartitioned run to rounding (1e-5), not bit for bit: refused with strict_order.
+        self.partition = partition
+        self.node_ids = None
         self.lo = self.hi = self.c0 = self.c1 = None
         self._cache = None
         self._props = {}
@@ -134,6 +142,12 @@ class ShardedGraphOp:
         caller_adj = adj                     # the cache is keyed on the CALLER's object, never on a temporary of ours
         n = adj.shape[0]
         row_groups = world if self.row_groups is None else int(self.row_groups)
+        if self.partition:
+            if row_groups != world:
+                raise ValueError("partition= applies to the row-sharded layout only")
+            if self.strict_order:
+                raise ValueError("partition= relabels the problem (a row's terms are added in another order): not with strict_order")
+            return self._propagate_partitioned(adj, feature, rank, world, device)
         layout = GridLayout(world, row_groups)
         rg, cg = layout.coords(rank)
         key = (world, rank, row_groups)
@@ -185,12 +199,64 @@ class ShardedGraphOp:
         hops = prop.propagate(xs, self.prop_steps)
         return [h[:, :w] for h in hops]
 
-    def gather_full(self, local):
-        """assemble the full [N, d] matrix on every rank from the ranks' blocks (e.g. the final aggregated features).
+    def _propagate_partitioned(self, adj, feature, rank, world, device):
+        """full adjacency in, community-aware row blocks: normalise, relabel in the plan-time community order (when it helps),
+        cut the RELABELLED matrix into nnz-balanced row blocks, keep this rank's block and run the need-aware exchange on it"""
+        from .. import device as dev
+        from ..io import DeviceAdjacency
+        from ..operators.base_op import AdjIdentity
+        from ..reorder import permute_csr, plan_order
+        from .halo import block_halo
+        from .layout import balanced_bounds
+        n = adj.shape[0]
+        key = ("partitioned", world, rank, self.partition)
+        if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(adj):
+            ident = AdjIdentity(adj)
+            dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=device)
+            rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, self.r, self.alpha)
+            order, info = plan_order(rowptr, col, n, self.partition)       # identical on every rank: same kernels, same input
+            if order is not None:
+                rowptr, col, val = permute_csr(rowptr, col, val, order)
+                perm = torch.argsort(order)                                 # perm[k] = original id of the node relabelled k
+            else:
+                perm = torch.arange(n, dtype=torch.int64, device=rowptr.device)
+            bounds = balanced_bounds(rowptr.cpu().numpy(), world)
+            lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+            a0, a1 = int(rowptr[lo]), int(rowptr[hi])
+            blk = RowBlock(lo, hi, n, (rowptr[lo:hi + 1] - rowptr[lo]).contiguous(), col[a0:a1].contiguous(), val[a0:a1].contiguous())
+            del rowptr, col, val
+            plan, prop, handle = block_halo(blk, [int(b) for b in bounds], group=self.group, strict=False, reorder=self.reorder)
+            self._cache = (key, plan, prop, handle, perm, info)
+            self._cache_ident = ident
+            self.a_hat_block = blk
+        _, plan, prop, _, perm, info = self._cache
+        self._prop, self.halo_plan, self.partition_info = prop, plan, info
+        self.lo, self.hi = plan.lo, plan.hi
+        self.node_ids = perm[plan.lo:plan.hi]
+        self._perm = perm
+        x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
+        x = x.to(device=device, dtype=torch.float32)
+        if x.shape[0] != n:
+            raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
+        self.c0, self.c1 = 0, x.shape[1]
+        table = dev.gather_rows(x.contiguous(), perm[plan.global_ids])      # the compact table of the RELABELLED problem, cut out of X
+        chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
+        if len(chunks) == 1:
+            return prop.propagate(table, self.prop_steps)
+        hops = prop.propagate_chunked([table[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+        return [torch.cat(h, dim=1) for h in hops]
+
+    def gather_full(self, local, original_order=False):
+        """assemble the full [N, d] matrix on every rank from the ranks' blocks (e.g. the final aggregated features);
+        original_order=True undoes the relabelling of partition= (row i = node i again).
         `local` is this rank's block: rows [lo, hi), any width (the same inside a column group); the column groups'
         blocks are laid side by side in column-group order."""
         rank, world = self._ranks()
         if world == 1:
+            if original_order and getattr(self, "_perm", None) is not None and self.partition:
+                out = torch.empty_like(local)
+                out[self._perm.to(local.device)] = local
+                return out
             return local
         prop = self._prop
         layout = prop.layout or GridLayout(world, world)
@@ -220,7 +286,12 @@ class ShardedGraphOp:
             w.wait()
         for r0, r1, c, buf in landings:
             full[r0:r1, c:c + buf.shape[1]].copy_(buf)
-        return full.to(local.device) if staged else full
+        full = full.to(local.device) if staged else full
+        if original_order and getattr(self, "_perm", None) is not None and self.partition:
+            out = torch.empty_like(full)
+            out[self._perm.to(full.device)] = full          # row k of the relabelled problem is node perm[k]
+            return out
+        return full
 
     def gather_rows(self, local):
         """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (row-sharded layout)"""

@@ -23,7 +23,7 @@ import torch
 from . import _lib, io
 from ._lib import check, current_stream_ptr, lib, ptr
 
-__all__ = ["community_order", "community_order_reference", "permute_csr", "edge_locality", "plan_rowmap", "local_rowmap"]
+__all__ = ["community_order", "community_order_reference", "permute_csr", "edge_locality", "plan_rowmap", "plan_order", "local_rowmap"]
 
 
 @torch.no_grad()
@@ -149,6 +149,25 @@ def plan_rowmap(rowptr, col, n, mode):
     else:
         info["applied"] = True
     return torch.argsort(order).to(torch.int32), info
+
+
+@torch.no_grad()
+def plan_order(rowptr, col, n, mode):
+    """order[i] = new id of node i for a RELABELLING of the problem (P A P^T: what a community-aware partition cuts), or None.
+    Same decision rule as plan_rowmap ("auto": only when the graph becomes measurably more local).  Returns (order, info)."""
+    if mode is None:
+        return None, {"partition": None}
+    if mode not in ("community", "auto"):
+        raise ValueError("partition must be None, 'community' or 'auto'")
+    order, text = community_order(rowptr, col, n)
+    info = {"partition": mode, "communities": text, "applied": True}
+    if mode == "auto":
+        before, after = edge_locality(rowptr, col), edge_locality(rowptr, col, order)
+        use = after >= AUTO_MIN_LOCALITY and after >= before + AUTO_MIN_GAIN
+        info.update({"edge_locality_before": round(before, 4), "edge_locality_after": round(after, 4), "applied": bool(use)})
+        if not use:
+            return None, info
+    return order, info
 
 
 @torch.no_grad()
