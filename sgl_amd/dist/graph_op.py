@@ -134,10 +134,14 @@ class ShardedGraphOp:
     def propagate(self, adj, feature):
         from .. import device as dev
         from ..io import DeviceAdjacency
-        if isinstance(adj, RowBlock):
+        if isinstance(adj, RowBlock) and not self.partition:
             return self._propagate_block(adj, feature)
         rank, world = self._ranks()
         device = torch.device(self.device) if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if isinstance(adj, RowBlock):
+            if self.strict_order:
+                raise ValueError("partition= relabels the problem (a row's terms are added in another order): not with strict_order")
+            return self._propagate_partitioned(adj, feature, rank, world, adj.device)
         from ..operators.base_op import AdjIdentity
         caller_adj = adj                     # the cache is keyed on the CALLER's object, never on a temporary of ours
         n = adj.shape[0]
@@ -208,12 +212,21 @@ class ShardedGraphOp:
         from ..reorder import permute_csr, plan_order
         from .halo import block_halo
         from .layout import balanced_bounds
-        n = adj.shape[0]
+        n = adj.n if isinstance(adj, RowBlock) else adj.shape[0]
         key = ("partitioned", world, rank, self.partition)
         if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(adj):
             ident = AdjIdentity(adj)
-            dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=device)
-            rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, self.r, self.alpha)
+            if isinstance(adj, RowBlock):
+                # storage already row-sharded: normalise the block where it lies, then assemble the normalised matrix on every rank
+                # (27 GB of CSR at papers100M size: affordable once, for the plan) to find and apply the relabelling
+                from .sharded_adj import allgather_blocks
+                rp_b, c_b, v_b = dev.normalize_block(adj.rowptr, adj.col, adj.val, adj.lo, n, self.r, self.alpha,
+                                                     symmetric=self.symmetric, group=self.group)
+                rowptr, col, val = allgather_blocks(RowBlock(adj.lo, adj.hi, n, rp_b, c_b, v_b), self.group)
+                self._block_bounds = None
+            else:
+                dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=device)
+                rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, self.r, self.alpha)
             order, info = plan_order(rowptr, col, n, self.partition)       # identical on every rank: same kernels, same input
             if order is not None:
                 rowptr, col, val = permute_csr(rowptr, col, val, order)
@@ -236,6 +249,14 @@ class ShardedGraphOp:
         self._perm = perm
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
         x = x.to(device=device, dtype=torch.float32)
+        if isinstance(adj, RowBlock) and x.shape[0] == adj.n_local and x.shape[0] != n:
+            # this rank's feature rows only (old ids): the rows a relabelled block needs are scattered over all ranks
+            sizes = [None] * world
+            if world > 1:
+                dist.all_gather_object(sizes, (adj.lo, adj.hi), group=self.group)
+            else:
+                sizes = [(adj.lo, adj.hi)]
+            x = allgather_rows(x.contiguous(), [s_[0] for s_ in sizes] + [sizes[-1][1]], n, group=self.group)
         if x.shape[0] != n:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
         self.c0, self.c1 = 0, x.shape[1]

@@ -1128,6 +1128,19 @@ def _partition_worker(rank, world, port, out_dir):
         flags = [bool(ok)]
         ok = ok and op.halo_plan.n_ghost < 0.85 * base.n_ghost      # (2 ranks, 10 % far edges: ~75 %; 50 % at 8 ranks, r03_partition_locality.log)
         flags.append(bool(ok))
+        # storage ALREADY row-sharded (RowBlock input, own feature rows only): the normalised matrix is assembled once for the plan,
+        # the relabelled blocks and what they return are the same
+        from sgl_amd.dist import scatter_row_blocks
+        from sgl_amd.operators.utils import canonical_csr
+        raw = canonical_csr(adj)
+        bnd = balanced_bounds(raw.indptr.astype(np.int64) + np.arange(n + 1), world)
+        whole = tuple(torch.from_numpy(np.ascontiguousarray(a_, dtype=t_)).to(dv) for a_, t_ in
+                      ((raw.indptr, np.int64), (raw.indices, np.int32), (raw.data, np.float32))) if rank == 0 else None
+        blk = scatter_row_blocks(whole, bnd, n, dv)
+        opb = ShardedGraphOp(3, r=0.5, partition="community", col_chunks=2)
+        hb = opb.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+        ok = ok and torch.equal(opb.node_ids, ids) and all(torch.equal(a_, b_) for a_, b_ in zip(hb, hops))
+        flags.append(bool(ok))
         # "auto" keeps the ids when there is nothing to gain (the same graph in its natural order)
         adj0c = adj0.tocsr()
         adj0c.sort_indices()
