@@ -62,6 +62,7 @@ struct Plan {
 constexpr int kMaxItemRows = 63;        // row-pointer window of one wavefront: 64 lanes hold rows+1 offsets
 constexpr int kDefaultItemNnz = 512;
 constexpr int kDefaultLongRowNnz = 2048;
+constexpr int64_t kSmallLaunchNnz = 100000000;   // below this a launch gets 256-nnz work items (sgl_csr_create)
 
 int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz);
 

@@ -1,5 +1,6 @@
 // Host-only part of libsgl_hip.so: error text, tuning knobs, and the SpMM execution-plan builder.
 // No device code here, so these entry points work (and are unit-tested) on a machine without a GPU.
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -28,6 +29,7 @@ static std::map<std::string, int64_t> &tune_map() {
         {"spmm_group", 0},       // 0 = auto; force lanes-per-feature-row (8/16/32/64)
         {"spmm_waves", 0},       // 0 = default (4 waves per workgroup)
         {"spmm_xcd_remap", 1},   // contiguous row ranges per XCD
+        {"spmm_heavy_first", 1}, // plan time: work items that end in a heavy row are issued first inside every XCD range
         {"agg_blocks", 0},       // 0 = one 16-byte element per thread (grid capped at 2^22 blocks); > 0 caps the grid of the streaming aggregators (grid-stride)
         {"nafs_fused", 1},       // 0 = force the two-pass NAFS path
         {"row_lpr32x2", 1},      // row-wise kernels, 128 < d <= 256: 32 lanes x 2 chunks per row (2 rows per wavefront)
@@ -42,6 +44,38 @@ int64_t tuning(const char *key, int64_t dflt) {
     auto it = m.find(key);
     if (it == m.end()) return dflt;
     return it->second;
+}
+
+// Issue order of the work items.  An item closes when it reaches item_nnz non-zeros, so one that ends in a heavy row holds up
+// to item_nnz + long_row_nnz of them: several times the usual wavefront lifetime.  Where such an item is issued late, the launch
+// ends with a few wavefronts on an otherwise empty chip -- one per cent of the single-GPU launch, but a rank's launch of the
+// 8-rank job is only ~3.5 rounds of resident wavefronts (profiles/r03_probe_small_launch.log: -3.5 %).  Inside every XCD's range
+// of the item list (the ranges spmm_kernel walks with 4 wavefronts per block) the items holding >= 2 x item_nnz non-zeros
+// therefore go first, longest first; the others keep their row order.  Items are whole rows: results do not change.
+static void heavy_items_first(Plan &plan, const int64_t *rowptr, int32_t item_nnz) {
+    const int64_t n = (int64_t)plan.items.size() / 2;
+    if (n < 64) return;
+    const int64_t range = (((n + 3) / 4 + 7) / 8) * 4;
+    const int64_t heavy = 2 * (int64_t)std::max(item_nnz, 1);
+    struct It {
+        int32_t b, e;
+        int64_t nnz;
+    };
+    std::vector<It> seg;
+    for (int64_t lo = 0; lo < n; lo += range) {
+        const int64_t hi = std::min(n, lo + range);
+        seg.clear();
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t b = plan.items[2 * i], e = plan.items[2 * i + 1];
+            seg.push_back(It{b, e, rowptr[e] - rowptr[b]});
+        }
+        auto mid = std::stable_partition(seg.begin(), seg.end(), [&](const It &t) { return t.nnz >= heavy; });
+        std::stable_sort(seg.begin(), mid, [](const It &x, const It &y) { return x.nnz > y.nnz; });
+        for (int64_t i = lo; i < hi; ++i) {
+            plan.items[2 * i] = seg[(size_t)(i - lo)].b;
+            plan.items[2 * i + 1] = seg[(size_t)(i - lo)].e;
+        }
+    }
 }
 
 // Greedy partition of the rows into work items (see include/sgl_hip.h, "execution plan").
@@ -92,6 +126,7 @@ int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_n
         if (cur_nnz >= item_nnz || (r + 1 - cur_begin) >= kMaxItemRows) close_item(r + 1);
     }
     close_item(n_rows);
+    if (tuning("spmm_heavy_first", 1) != 0) heavy_items_first(plan, rowptr, item_nnz);
     return SGL_OK;
 }
 

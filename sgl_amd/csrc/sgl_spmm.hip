@@ -517,10 +517,14 @@ SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, i
     SGL_REQUIRE(h_rowptr[0] == 0 && h_rowptr[n_rows] == nnz, "sgl_csr_create: rowptr[0]=%lld rowptr[n]=%lld but nnz=%lld",
                 (long long)h_rowptr[0], (long long)h_rowptr[n_rows], (long long)nnz);
     if (item_nnz <= 0) {
-        // one wavefront per item: small matrices get smaller items so that the chip (256 CUs x 4 SIMDs x 8 waves)
-        // still sees enough wavefronts to hide memory latency; large ones use the 512-nnz default
+        // one wavefront per item: small matrices get smaller items so that the chip (256 CUs x 4 SIMDs x 8 waves) still
+        // sees enough wavefronts to hide memory latency; large ones use the 512-nnz default.  In between -- a launch of fewer
+        // than ~200 000 such items, e.g. a rank's block of a sharded job: a few "rounds" of the 8 192 resident wavefronts --
+        // 256-nnz items end the launch more evenly (profiles/r03_probe_small_launch.log: -3 % at an eighth of the
+        // products-sized graph, neutral on the whole of it).  Results do not depend on the item size.
         const int64_t want_items = 256 * 4 * 8;
-        item_nnz = (int32_t)std::min<int64_t>(sgl::kDefaultItemNnz, std::max<int64_t>(32, nnz / want_items));
+        const int64_t cap = nnz >= sgl::kSmallLaunchNnz ? sgl::kDefaultItemNnz : sgl::kDefaultItemNnz / 2;
+        item_nnz = (int32_t)std::min<int64_t>(cap, std::max<int64_t>(32, nnz / want_items));
     }
     if (long_row_nnz == 0) long_row_nnz = sgl::kDefaultLongRowNnz;
     if (flags & SGL_CSR_STRICT_ORDER) long_row_nnz = -1;

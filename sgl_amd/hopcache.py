@@ -9,6 +9,7 @@ arrays, a position-weighted wrapping sum of the raw bits for device tensors) and
 anything unexpected (partial directory, shape mismatch) is a miss.  Files: <dir>/<key>/hop_<k>.npy + meta.json (written last)."""
 import json
 import os
+import uuid
 
 import numpy as np
 import torch
@@ -89,12 +90,13 @@ class HopCache:
         d = os.path.join(self.dir, key)
         os.makedirs(d, exist_ok=True)
         from . import device as dev
+        tag = f"{os.getpid()}.{uuid.uuid4().hex[:8]}"
         for k, h in enumerate(hops):
             a = (dev.download_rows(h) if h.is_cuda else h.detach()).contiguous().numpy()
-            tmp = os.path.join(d, f".hop_{k}.tmp.npy")
+            tmp = os.path.join(d, f".hop_{k}.{tag}.tmp.npy")     # per-writer names: ranks of one job may save the same key at once
             np.save(tmp, a)
             os.replace(tmp, os.path.join(d, f"hop_{k}.npy"))
-        tmp = os.path.join(d, ".meta.tmp")
+        tmp = os.path.join(d, f".meta.{tag}.tmp")
         with open(tmp, "w") as f:
             json.dump({"n_hops": len(hops), "shape": list(hops[0].shape)}, f)
         os.replace(tmp, os.path.join(d, "meta.json"))        # written last: a directory without it is a miss

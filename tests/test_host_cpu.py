@@ -97,6 +97,38 @@ def test_plan_partitions_every_row_exactly_once(seed, item_nnz, long_nnz):
     assert counts[0] == len(items) and counts[5] == n
 
 
+def test_plan_issues_heavy_items_first_inside_every_xcd_range():
+    """an item that ends in a heavy row holds several times item_nnz non-zeros; issued late it is the tail of the launch
+    (profiles/r03_probe_small_launch.log).  Inside every XCD's range of the item list the items with >= 2 x item_nnz non-zeros
+    come first, longest first, the rest keep their row order -- and the tuning key turns it off"""
+    rng = np.random.default_rng(5)
+    n, item_nnz, long_nnz = 40000, 64, 600
+    deg = np.minimum(rng.lognormal(1.2, 1.5, n).astype(np.int64), 3000)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    items, *_ = build_plan(rowptr, item_nnz, long_nnz)
+    _lib.set_tuning("spmm_heavy_first", 0)
+    try:
+        plain, *_ = build_plan(rowptr, item_nnz, long_nnz)
+    finally:
+        _lib.set_tuning("spmm_heavy_first", 1)
+    assert (np.diff(plain[:, 0]) > 0).all()                                   # the greedy partition itself: row order
+    assert sorted(map(tuple, items)) == sorted(map(tuple, plain))             # the same items, another issue order
+    ni = len(items)
+    rng_len = (((ni + 3) // 4 + 7) // 8) * 4                                  # what spmm_kernel's XCD remap walks (4 waves / block)
+    nnz = rowptr[items[:, 1]] - rowptr[items[:, 0]]
+    n_heavy = 0
+    for lo in range(0, ni, rng_len):
+        seg, seg_nnz = items[lo:lo + rng_len], nnz[lo:lo + rng_len]
+        assert sorted(map(tuple, seg)) == sorted(map(tuple, plain[lo:lo + rng_len]))   # nobody leaves its XCD range
+        heavy = seg_nnz >= 2 * item_nnz
+        k = int(heavy.sum())
+        n_heavy += k
+        assert heavy[:k].all() and not heavy[k:].any()
+        assert (np.diff(seg_nnz[:k]) <= 0).all()
+        assert (np.diff(seg[k:, 0]) > 0).all()
+    assert n_heavy > 50
+
+
 def test_plan_rejects_bad_rowptr():
     lib = _lib.lib()
     rp = np.array([0, 5, 3], dtype=np.int64)
