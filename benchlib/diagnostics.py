@@ -59,6 +59,9 @@ def _diagnostics(job, halves):
         if hasattr(prop, "pack_only"):                        # need-aware exchange: the pack kernel alone (inside exchange_only too)
             ys = prop.spmm_only(halves["rows"][1])
             diag["pack_only_ms_per_hop_max_rank"] = job.timed_s(lambda: prop.pack_only(ys), reps=3) * 1e3
+            timing = getattr(prop, "pack_timing_ms", None)
+            if timing:                                        # rank 0's choice per (rows, columns) of a chunk: peer order or own-row order
+                diag["pack_order_ms_rank0"] = {f"{r}x{w}": t for (r, w), t in timing.items()}
     if "grid" in halves and job.nbuf > 0:
         prop, x_chunks, cbufs = halves["grid"]
         inbound = (prop.world - 1) / prop.world * job.n * x_chunks[0].shape[1] * 4

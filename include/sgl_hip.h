@@ -319,6 +319,11 @@ int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ld
 /* out[i, :] = X[idx[i], :]   (idx: int64 on device; negative indices are NOT wrapped) */
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);
+/* out[dst[i], :] = X[src[i], :] for i < n_idx   (src, dst: int64 on device, dst entries distinct and < n_out_rows; a bad index
+ * traps the kernel).  The pack step of the need-aware exchange (sgl_exchange_rows): the (own row, send-buffer row) pairs sorted
+ * by own row, so that a row several peers gather is read from HBM once. */
+int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
+                         int64_t n_idx, float *d_out, int64_t ldo, int64_t n_out_rows, int64_t d, void *stream);
 
 /* order-sensitive 64-bit hash of a HOST buffer, multi-threaded (what the reference-signature shims key their cached adjacency
  * on; the operator layer fingerprints scipy index / value arrays with it).  Host-only: works without a GPU. */

@@ -93,6 +93,8 @@ PROTOTYPES = {
                              c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
+    "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                     c_int64, c_void_p]),
     "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_fill": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_features": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),

@@ -559,22 +559,48 @@ __global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, con
     }
 }
 
-// out[i,:] = X[idx[i],:]
-template <int LPR, int VEC>
+// out[i,:] = X[idx[i],:].  A thread copies one 16-byte vector of U rows (U index loads, U row loads, U stores: independent).
+// The destination is written once and read later by someone else (the transport, the MLP), while the source rows are re-read --
+// by every peer that gathers them at the pack step of the need-aware exchange -- so the stores are non-temporal: they do not
+// displace the source in L2 / Infinity Cache (pack of the S1 job on 8 ranks: 0.157 -> 0.145 ms at 64 columns, 0.268 -> 0.223 at
+// 100; with repeats adjacent 0.141 -> 0.091 ms = 5.1 TB/s written; profiles/r03_pack_order.log).
+// With `dst` the copy is out[dst[i],:] = X[idx[i],:] (n_out destination rows): the pack step of the need-aware exchange walks its
+// (source row, send-buffer row) pairs in SOURCE order, so a row that several peers gather is read from HBM once and hit in L1 / L2
+// for the others.
+template <int LPR, int VEC, int U>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int64_t ldx,
                                                           const int64_t n_rows, const int64_t *__restrict__ idx,
+                                                          const int64_t *__restrict__ dst, const int64_t n_out,
                                                           const int64_t n_idx, float *__restrict__ out,
                                                           const int64_t ldo, const int d) {
     using V = typename Vt<VEC>::type;
     constexpr int RPB = 256 / LPR;
     const int l = threadIdx.x % LPR;
-    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-    if (i >= n_idx) return;
-    int64_t src = idx[i];
-    if (src < 0) src += n_rows;                       // python-style negative index
-    if (src < 0 || src >= n_rows) __builtin_trap();   // out of range: abort the kernel loudly (like torch's assert)
-    for (int c = l * VEC; c < d; c += LPR * VEC)
-        *reinterpret_cast<V *>(out + i * ldo + c) = *reinterpret_cast<const V *>(x + src * ldx + c);
+    const int64_t i0 = (int64_t)blockIdx.x * (RPB * U) + threadIdx.x / LPR;
+    int64_t src[U], to[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * RPB;
+        int64_t s = i < n_idx ? idx[i] : 0;
+        if (s < 0) s += n_rows;                       // python-style negative index
+        if (s < 0 || s >= n_rows) __builtin_trap();   // out of range: abort the kernel loudly (like torch's assert)
+        src[u] = s;
+        to[u] = i;
+        if (dst && i < n_idx) {
+            to[u] = dst[i];
+            if (to[u] < 0 || to[u] >= n_out) __builtin_trap();
+        }
+    }
+    for (int c = l * VEC; c < d; c += LPR * VEC) {
+        V v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const V *>(x + src[u] * ldx + c);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * RPB;
+            if (i < n_idx) __builtin_nontemporal_store(v[u], reinterpret_cast<V *>(out + to[u] * ldo + c));
+        }
+    }
 }
 
 // out[:, h*d + k] = X_h[:, k]
@@ -1195,19 +1221,29 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     return wsum2d_impl(false, n_hops, h_x, h_ldx, d_w_out, ldw, d_out, ldo, n, d, stream);
 }
 
-SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
-                                   float *d_out, int64_t ldo, int64_t d, void *stream) {
-    SGL_REQUIRE(n_idx >= 0 && d >= 0 && d < INT32_MAX && n_rows >= 0, "sgl_gather_rows_f32: bad sizes");
+static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, const int64_t *d_dst,
+                     int64_t n_out, int64_t n_idx, float *d_out, int64_t ldo, int64_t d, void *stream) {
+    SGL_REQUIRE(n_idx >= 0 && d >= 0 && d < INT32_MAX && n_rows >= 0 && n_out >= 0, "%s: bad sizes", who);
     if (n_idx == 0 || d == 0) return SGL_OK;
-    SGL_REQUIRE(d_x && d_idx && d_out && ldx >= d && ldo >= d, "sgl_gather_rows_f32: bad arguments");
+    SGL_REQUIRE(d_x && d_idx && d_out && ldx >= d && ldo >= d, "%s: bad arguments", who);
     const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_x, 16) && aligned_to(d_out, 16);
     hipStream_t st = sgl::as_stream(stream);
     const int lpr = pick_lpr(d, vec4 ? 4 : 1);
-    const int64_t blocks = (n_idx + (256 / lpr) - 1) / (256 / lpr);
-    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_gather_rows_f32: too many indices for one launch");
-    SGL_REQUIRE(blocks < INT32_MAX, "sgl_gather_rows_f32: too many rows");
-#define SGL_GR(L, V) \
-    hipLaunchKernelGGL((gather_rows_kernel<L, V>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, n_idx, d_out, ldo, (int)d)
+    // U rows per thread once there are enough rows to fill the chip several times over; small batches keep one row per thread
+    const int rpb = 256 / lpr;
+    const int u = n_idx >= (int64_t)rpb * 4 * 256 * 8 ? 4 : 1;
+    const int64_t blocks = (n_idx + (int64_t)rpb * u - 1) / ((int64_t)rpb * u);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: too many indices for one launch", who);
+    SGL_REQUIRE(blocks < INT32_MAX, "%s: too many rows", who);
+#define SGL_GR(L, V)                                                                                                             \
+    do {                                                                                                                         \
+        if (u == 4)                                                                                                              \
+            hipLaunchKernelGGL((gather_rows_kernel<L, V, 4>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
+                               d_dst, n_out, n_idx, d_out, ldo, (int)d);                                                         \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((gather_rows_kernel<L, V, 1>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
+                               d_dst, n_out, n_idx, d_out, ldo, (int)d);                                                         \
+    } while (0)
     if (vec4) {
         switch (lpr) {
             case 8: SGL_GR(8, 4); break;
@@ -1224,8 +1260,22 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
         }
     }
 #undef SGL_GR
-    SGL_LAUNCH_CHECK("sgl_gather_rows_f32");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sgl::fail((int)e, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
     return SGL_OK;
+}
+
+SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
+                                   float *d_out, int64_t ldo, int64_t d, void *stream) {
+    return copy_rows("sgl_gather_rows_f32", d_x, ldx, n_rows, d_idx, nullptr, n_idx, n_idx, d_out, ldo, d, stream);
+}
+
+// out[dst[i], :] = X[src[i], :], i < n_idx (dst entries distinct; every index is range-checked in the kernel, which traps on a
+// bad one).  The pack step of the need-aware exchange: the (own row, send-buffer row) pairs sorted by own row.
+SGL_EXPORT int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
+                                    int64_t n_idx, float *d_out, int64_t ldo, int64_t n_out_rows, int64_t d, void *stream) {
+    SGL_REQUIRE(n_idx == 0 || d_dst != nullptr, "sgl_scatter_rows_f32: NULL destination index");
+    return copy_rows("sgl_scatter_rows_f32", d_x, ldx, n_rows, d_src, d_dst, n_out_rows, n_idx, d_out, ldo, d, stream);
 }
 
 // ---- learnable gates -------------------------------------------------------------------------------------------------------

@@ -875,6 +875,26 @@ def nafs_aggregate(feats, return_weights=False):
     return (out, w) if return_weights else out
 
 
+def scatter_rows(x, src, dst, out):
+    """out[dst[i]] = x[src[i]] on device (sgl_scatter_rows_f32; src, dst: int64 CUDA tensors of one length, dst entries distinct).
+    The pack step of the need-aware exchange: pairs sorted by source row, so a row several peers gather is read once."""
+    _check_mat(x, "x")
+    _check_mat(out, "out")
+    if x.shape[1] != out.shape[1]:
+        raise ValueError("scatter_rows: x and out must have the same row length")
+    for t, nm in ((src, "src"), (dst, "dst")):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.is_contiguous()):
+            raise TypeError(f"scatter_rows: {nm} must be a contiguous 1-D int64 CUDA tensor")
+    if src.numel() != dst.numel():
+        raise ValueError("scatter_rows: src and dst must have the same length")
+    if src.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(lib().sgl_scatter_rows_f32(ptr(x), _ld(x), x.shape[0], ptr(src), ptr(dst), src.numel(), ptr(out), _ld(out),
+                                         out.shape[0], x.shape[1], current_stream_ptr()), "sgl_scatter_rows_f32")
+    return out
+
+
 def gather_rows(x, idx, out=None):
     """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60).  `out`: optional
     preallocated [len(idx), d] destination (the pack step of the need-aware exchange re-uses one send buffer per hop)."""

@@ -10,8 +10,9 @@ a property of the graph, so it is found ONCE:
     compact table     the rank's gather source is no longer an [N, d] replica but [own rows | ghosts of peer 0 | peer 1 | ...]
                       ([n_own + n_ghost, d]); the block's column ids are relabelled once to positions in that table.  The order
                       of a row's terms is untouched, so every hop is bit-identical to the full-replica run.
-    per hop           SpMM (compact columns) -> own rows of the next table; ONE row-gather kernel packs the rows the peers need
-                      into a send buffer, peer after peer (sgl_gather_rows_f32); a grouped send / recv delivers every peer's
+    per hop           SpMM (compact columns) -> own rows of the next table; ONE row-copy kernel packs the rows the peers need
+                      into a send buffer, peer after peer (sgl_gather_rows_f32 in peer order or sgl_scatter_rows_f32 in own-row
+                      order -- every row read once --, whichever is faster for the shape); a grouped send / recv delivers every peer's
                       share straight into its ghost range of the next table.  Nothing is unpacked: ghosts are stored packed.
 
 A rank therefore never holds the whole feature matrix (57 GB at papers100M size): it starts from its OWN feature rows and
@@ -145,6 +146,9 @@ class HaloPlan:
             torch.empty(0, dtype=torch.int64, device=dev)
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_own):
             raise RuntimeError("halo plan: a peer asked for a row outside this rank's block")
+        # the same pairs (own row -> send-buffer row) in OWN-ROW order: a row that several peers gather is then read once by the
+        # pack kernel and served from cache for the others (each peer's list is sorted, so this is a merge of world - 1 runs)
+        self.pack_src, self.pack_dst = torch.sort(self.send_idx, stable=True)
 
     def relabel(self, col):
         """the block's GLOBAL column ids as positions in the compact table (int32, same order)"""
@@ -192,6 +196,8 @@ class HaloPropagator:
         self.layout = None                                   # what ShardedGraphOp.gather_full / over_smooth_aggregate look at
         self.pb = np.stack([plan.bounds[:-1], plan.bounds[1:]], axis=1)
         self._send = {}
+        self.pack_mode = "auto"                              # "gather" | "scatter" | "auto" (CUDA: measured once per shape)
+        self._pack_choice, self.pack_timing_ms = {}, {}
         # The send buffer holds the peers' shares in rank order and so do the ghost ranges of a table: the whole exchange is ONE
         # all_to_all_single with split sizes (an all-to-all-v) -- one call instead of 2 (G - 1) point-to-point operations, which is
         # what bounds how finely a hop can be cut on the host side.  Off by default (gloo has no all_to_all; bench.py times it
@@ -211,12 +217,44 @@ class HaloPropagator:
         if rows == 0:
             return buf
         if y_own.is_cuda:
-            from .. import device as dev
             src = y_own if y_own.stride(1) == 1 else y_own.contiguous()
-            dev.gather_rows(src, pl.send_idx, out=buf)
+            self._pack_device(src, buf, (key, rows, w))
+        elif self.pack_mode == "scatter":
+            buf.index_copy_(0, pl.pack_dst, y_own.index_select(0, pl.pack_src))
         else:
             torch.index_select(y_own, 0, pl.send_idx, out=buf)
         return buf
+
+    def _pack_device(self, src, buf, key):
+        """Two orders of the same copy: peer after peer (gather: sequential writes, every own row re-read once per peer that
+        gathers it) or own row after own row (scatter: every row read once, rows written to world - 1 places).  Which is faster
+        depends on the row width -- scattered rows must be whole 128-byte lines -- and on whether the send buffer still fits the
+        caches (profiles/r03_pack_order.log: 0.098 vs 0.145 ms at 64 columns, 0.108 vs 0.095 ms at 36, S1 on 8 ranks; equal at
+        the papers100M size), so with pack_mode "auto" the first pack of a shape times both (identical bytes either way)."""
+        from .. import device as dev
+        pl = self.plan
+
+        def gather():
+            dev.gather_rows(src, pl.send_idx, out=buf)
+
+        def scatter():
+            dev.scatter_rows(src, pl.pack_src, pl.pack_dst, buf)
+
+        mode = self.pack_mode if self.pack_mode != "auto" else self._pack_choice.get(key)
+        if mode is None:
+            best = {}
+            for name, fn in (("gather", gather), ("scatter", scatter)):
+                fn()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                fn()
+                fn()
+                ev[1].record()
+                ev[1].synchronize()
+                best[name] = ev[0].elapsed_time(ev[1])
+            mode = self._pack_choice[key] = min(best, key=best.get)
+            self.pack_timing_ms[key[1:]] = {k: round(v / 2, 4) for k, v in best.items()}
+        (scatter if mode == "scatter" else gather)()
 
     def begin_exchange(self, y_own, table_next, key=0):
         """pack my rows for the peers and start the grouped send / recv that fills the ghost ranges of table_next.

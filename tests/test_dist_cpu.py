@@ -246,6 +246,12 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
             ok = ok and len(hops) == K + 1 and np.array_equal(hops[K].numpy(), ref[K][lo:hi])
             if not in_place:
                 ok = ok and all(np.array_equal(hops[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        # the pack step in own-row order (every row read once, written to each peer's share) fills the same send buffer
+        ok = ok and torch.equal(plan.send_idx[plan.pack_dst], plan.pack_src) and bool((plan.pack_src[1:] >= plan.pack_src[:-1]).all())
+        prop.pack_mode = "scatter"
+        hops_s = prop.propagate(t_own.clone(), K)
+        prop.pack_mode = "auto"
+        ok = ok and np.array_equal(hops_s[K].numpy(), ref[K][lo:hi])
         # the same exchange as ONE all_to_all_single with split sizes (the RCCL form; gloo has none, so its contract is emulated
         # with point-to-point operations: rows [sum(in[:q]), +in[q]) of the input go to rank q, rows from rank q land at
         # [sum(out[:q]), +out[q]) of the output)

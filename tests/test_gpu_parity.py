@@ -1477,6 +1477,25 @@ def test_gather_rows(cuda):
         gather_rows(x, [1000])
 
 
+def test_gather_and_scatter_rows_many_rows_per_thread(cuda):
+    """large index lists take the 4-rows-per-thread variant (ragged last block included); scatter_rows = the pack step of the
+    need-aware exchange: (own row, send-buffer row) pairs in own-row order give the buffer the peer-ordered gather gives"""
+    from sgl_amd.device import gather_rows, scatter_rows
+    g = torch.Generator(device=cuda).manual_seed(3)
+    for d, n_src, n_idx in ((64, 5000, 300_001), (36, 7777, 270_003), (100, 3001, 140_007), (7, 900, 600_005)):
+        x = torch.randn((n_src, d), device=cuda, generator=g)
+        idx = torch.randint(0, n_src, (n_idx,), device=cuda, generator=g)
+        want = x.index_select(0, idx)
+        assert torch.equal(gather_rows(x, idx), want)
+        src, dst = torch.sort(idx, stable=True)
+        out = torch.full((n_idx + 5, d), -1.0, device=cuda)
+        scatter_rows(x, src, dst, out)
+        assert torch.equal(out[:n_idx], want) and bool((out[n_idx:] == -1.0).all())
+    with pytest.raises(ValueError):
+        scatter_rows(x, src, dst[:-1].contiguous(), out)
+    assert scatter_rows(x, src[:0], dst[:0], out) is out
+
+
 def test_models_match_reference_goldens(goldens, cuda):
     from sgl_amd.models import homo
     g4 = goldens.npz("g4_models")

@@ -6,7 +6,7 @@ hold -- its nnz-balanced row block of A_hat with the columns relabelled to its c
 (HaloPlan.offline: the same plan the collective constructor produces) -- and measures on this GPU:
 
     spmm_c   the rank's SpMM per column chunk (what runs between exchanges)
-    pack_c   the pack kernel per chunk (rows the peers gather -> send buffer)
+    pack_c   the pack kernel per chunk (rows the peers gather -> send buffer; the faster of peer order / own-row order)
     in / out bytes per peer link per hop (need-aware) next to the full all-gather volume
 
 The exchange itself cannot be measured here; it enters as a link rate B (GB/s per direction per link).  A small event simulation
@@ -90,7 +90,8 @@ def rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, de
             y = torch.empty((hi - lo, b - a), device=device)
             sp.append(timed(lambda: csr.spmm(t, out=y)))
             buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
-            pk.append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf)) if buf.shape[0] else 0.0)
+            pk.append(min(timed(lambda: dev.scatter_rows(y, plan.pack_src, plan.pack_dst, buf)),
+                          timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf))) if buf.shape[0] else 0.0)   # the faster order, like HaloPropagator
             del t, y, buf
         return sp, pk
     out["spmm"], out["pack"] = per_chunk(chunks)
@@ -252,7 +253,8 @@ def papers(device):
         y = torch.empty((plan.n_own, b - a), device=device)
         spmm.append(timed(lambda: csr.spmm(t, out=y), reps=3, warm=1))
         buf = torch.empty((int(plan.send_off[-1]), b - a), device=device)
-        pack.append(timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf), reps=3, warm=1))
+        pack.append(min(timed(lambda: dev.scatter_rows(y, plan.pack_src, plan.pack_dst, buf), reps=3, warm=1),
+                        timed(lambda: dev.gather_rows(y, plan.send_idx, out=buf), reps=3, warm=1)))
         del t, y, buf
     t = torch.empty((plan.n_compact, d), device=device).uniform_(-1, 1)
     y = torch.empty((plan.n_own, d), device=device)
