@@ -197,16 +197,20 @@ def _select_exchange(job, full, halo):
             # bit-checksums of every ghost range on random data) on every rank
             from sgl_amd.dist import halo_checksums
             good = True
+            probe = [torch.rand_like(y) for y in ys0]
             try:
                 hp.collective = True
-                probe = [torch.rand_like(y) for y in ys0]
                 hp.exchange_only(probe, first)
                 engine.sync()
-                good = all([halo_checksums(halo["plan"], t, y) for t, y in zip(first, probe)])   # a list: every collective runs
             except Exception as e:  # noqa: BLE001
                 good = False
                 sys.stderr.write(f"[bench] all_to_all form of the need-aware exchange unavailable on rank {job.rank}: {e!r}\n")
-            if job.agree(good):
+            if job.agree(good):                               # every rank got through the call: now the (collective) check
+                good = all([halo_checksums(halo["plan"], t, y) for t, y in zip(first, probe)])   # a list: every collective runs
+                good = job.agree(good)
+            else:
+                good = False
+            if good:
                 cand["halo_a2a"] = job.timed_s(lambda: hp.exchange_only(ys0, first))
             else:
                 info["halo_a2a_rejected"] = True
@@ -295,14 +299,23 @@ def _build_rows(job, ref=None):
                 if k in live:
                     base_info[k] = live[k]                # the selection happens once: its record goes with every candidate
             if len(counts) > 1 or str(exchange).startswith("halo"):
+                # two phases, each closed by an agreement every rank reaches: a rank whose step raised never leaves the others
+                # alone inside the collectives of the check
                 good = True
                 try:
                     cand["step"]()
+                    job.engine.sync()
+                except Exception as e:  # noqa: BLE001
+                    good = False
+                    sys.stderr.write(f"[bench] rows with {nc} column chunks ({exchange}) failed on rank {job.rank}: {e!r}\n")
+                if not job.agree(good):
+                    continue
+                try:
                     job.sync_all()
                     good = bool(cand["check"]())
                 except Exception as e:  # noqa: BLE001
                     good = False
-                    sys.stderr.write(f"[bench] rows with {nc} column chunks ({exchange}) failed on rank {job.rank}: {e!r}\n")
+                    sys.stderr.write(f"[bench] rows with {nc} column chunks ({exchange}): check failed on rank {job.rank}: {e!r}\n")
                 if not job.agree(good):
                     continue
                 timing[nc] = job.timed_s(cand["step"], reps=2, warm=0)
