@@ -306,12 +306,18 @@ class HaloPropagator:
         """tables: list of C compact tables [n_compact, w_c] (the column chunks of hop 0).  Software-pipelined like
         ShardedPropagator.propagate_chunked: while chunk c's rows travel, chunk c+1 is multiplied, and hop h+1 of chunk c
         waits only for chunk c's own exchange.  Returns hops[h][c] = LOCAL shard [n_own, w_c]; with in_place only the last
-        hop is retained (earlier entries are views the hop after next overwrites)."""
+        hop is retained (earlier entries are views the hop after next overwrites).  `buffers[c]`: the caller's tables for the
+        exchanged hops; with prop_steps - 1 (or more) of them per chunk, hops 1..K-1 are views of their own rows (valid until
+        the caller reuses the tables) and nothing is copied."""
         C = len(tables)
         n_own = self.plan.n_own
         hops = [[t[:n_own] for t in tables]]
         if prop_steps == 0:
             return hops
+        # the CALLER's tables, one per exchanged hop: nothing is overwritten inside a step, so the hop matrices can simply BE the
+        # own rows of those tables (no copy into the table, no separate output); with fewer (ping-pong) tables or our own
+        # temporaries the hops are separate matrices, as before
+        keep_in_tables = buffers is not None and all(len(b) >= prop_steps - 1 for b in buffers)
         if buffers is None:
             buffers = [[torch.empty_like(t) for _ in range(min(2, max(prop_steps - 1, 0)))] for t in tables]
         cur = list(tables)
@@ -327,7 +333,7 @@ class HaloPropagator:
                 t_next = None if last else buffers[c][(h - 1) % len(buffers[c])]
                 if t_next is not None and t_next.numel() and t_next.data_ptr() == cur[c].data_ptr():
                     raise RuntimeError("need two distinct tables per chunk to ping-pong between hops")
-                direct = in_place and not last
+                direct = (in_place or keep_in_tables) and not last
                 if direct:
                     y_own = t_next[:n_own]
                 elif y_buffers is not None and y_buffers[c][h - 1] is not None:

@@ -91,6 +91,7 @@ class ShardedPropagator:
         hops = [x_full[self.lo:self.hi]]
         if prop_steps == 0:
             return hops
+        keep_in_replicas = x_buffers is not None and len(x_buffers) >= prop_steps - 1     # see propagate_chunked
         if x_buffers is None:
             x_buffers = [torch.empty_like(x_full) for _ in range(min(2, max(prop_steps - 1, 0)))]
         cur = x_full
@@ -107,7 +108,7 @@ class ShardedPropagator:
             x_next = None if last else x_buffers[(h - 1) % len(x_buffers)]
             if x_next is not None and x_next.numel() and x_next.data_ptr() == cur.data_ptr():
                 raise RuntimeError("need two distinct full-size buffers to ping-pong between hops")
-            direct = in_place and not last
+            direct = (in_place or keep_in_replicas) and not last
             if direct:
                 y_local = x_next[self.lo:self.hi]
             else:
@@ -310,13 +311,16 @@ class ShardedPropagator:
         x_chunks: list of C replicas [N, w_c]; returns hops[h][c] = LOCAL shard [hi-lo, w_c].
         y_buffers[c][h-1]: optional preallocated outputs (see propagate).
         in_place: as in propagate() -- hops 1..K-1 are produced directly in this rank's rows of the next replica (views that
-        the hop after next overwrites); only the last hop is retained."""
+        the hop after next overwrites); only the last hop is retained.  With prop_steps - 1 (or more) caller-owned `buffers` per
+        chunk nothing is overwritten inside a step: the hops are those views and nothing is copied."""
         C = len(x_chunks)
         n = x_chunks[0].shape[0]
         assert n == self.n and self.pieces >= 1
         hops = [[x[self.lo:self.hi] for x in x_chunks]]
         if prop_steps == 0:
             return hops
+        # (the caller's replicas, one per exchanged hop: the hop shards can simply be this rank's rows of them -- no copy)
+        keep_in_replicas = buffers is not None and all(len(b) >= prop_steps - 1 for b in buffers)
         if buffers is None:
             buffers = [[torch.empty_like(x) for _ in range(min(2, max(prop_steps - 1, 0)))] for x in x_chunks]
         cur = list(x_chunks)
@@ -332,7 +336,7 @@ class ShardedPropagator:
                 x_next = None if last else buffers[c][(h - 1) % len(buffers[c])]
                 if x_next is not None and x_next.numel() and x_next.data_ptr() == cur[c].data_ptr():
                     raise RuntimeError("need two distinct buffers per chunk to ping-pong between hops")
-                direct = in_place and not last
+                direct = (in_place or keep_in_replicas) and not last
                 if direct:
                     y_local = x_next[self.lo:self.hi]
                 elif y_buffers is not None and y_buffers[c][h - 1] is not None:
