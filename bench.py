@@ -14,7 +14,7 @@ block, each rank normalises its own block (sgl_norm_block_*, one all-reduce of t
 plus a per-hop all-gather of the feature block over RCCL, column chunks software-pipelined across hops.  Two things are
 measured during setup, not assumed: the exchange (need-aware packed exchange -- a rank receives only the rows its block
 gathers, sgl_amd/dist/halo.py -- as grouped send/recv or as one all_to_all_single, grouped p2p of full replicas, RCCL
-all-gather) and the pipelining granularity (2 or 4 column chunks).  Validated without any replica of A_hat (exact
+all-gather) and the pipelining granularity (2, 3 or 4 column chunks).  Validated without any replica of A_hat (exact
 bit-checksums of the exchanged rows + sampled rows recomputed in fp64).  --layout auto / cols / grid / all additionally
 build alternatives that REPLICATE A_hat (reported under config.plan.alternatives).  Total work is fixed -> "scaling": "strong".
 The helper modules live in benchlib/ (engine, rows = the contract layout, layouts = the alternatives, diagnostics, papers).
@@ -59,8 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=os.environ.get("SGL_BENCH_WORKLOAD", "S1_products"))
     ap.add_argument("--pieces", type=int, default=2, help="row pieces per rank (N>1): transfers start per piece")
     ap.add_argument("--col-chunks", default="auto",
-                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain; auto = 2 and 4 "
-                         "are both built, validated and timed during setup and the faster runs")
+                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain; auto = 2, 3 and 4 "
+                         "are all built, validated and timed during setup and the fastest runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
     ap.add_argument("--exchange", choices=("auto", "halo", "halo_a2a", "p2p", "allgather", "push"),

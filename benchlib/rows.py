@@ -272,12 +272,22 @@ def _rows_halo(job, chunks):
 
 def _build_rows(job, ref=None):
     """The contract layout.  --col-chunks auto (default): how finely the feature block is cut for the pipelined exchange trades
-    the un-overlapped head and tail of a step against per-chunk launch / issue cost (profiles/r03_scale_model.md: 4 chunks win
-    in the model when the links are the bound, 2 when compute is), and that depends on what the links deliver -- so both are
-    built, validated and timed (untimed setup; the exchange is selected once, with the first) and the faster is kept."""
+    the un-overlapped head and tail of a step against per-chunk launch cost and against the gather efficiency of narrow chunks
+    (profiles/r03_scale_model.md: 3 or 4 chunks win in the model when the links are the bound, 2 when compute is), and that
+    depends on what the links deliver -- so 2, 3 and 4 chunks (d = 100: 64 + 36, 32 + 32 + 36, 32 + 32 + 32 + 4; always 4 lines per
+    gathered row) are built, validated and timed (untimed setup; the exchange is selected once, with the first) and the fastest
+    is kept."""
     args = job.args
     auto = str(args.col_chunks) == "auto"
-    counts = [2, 4] if (auto and job.world > 1 and job.nbuf > 0) else [2 if auto else int(args.col_chunks)]
+    measure = auto and job.world > 1 and job.nbuf > 0
+    counts = [2, 3, 4] if measure else [2 if auto else int(args.col_chunks)]
+    from sgl_amd.dist import column_chunks
+    seen = []
+    for nc in list(counts):                               # narrow feature blocks: several counts give the same cut
+        cut = column_chunks(job.d, nc)
+        if cut in seen:
+            counts.remove(nc)
+        seen.append(cut)
     base_info = dict(job.info)
     live = job.info                                       # callers hold a reference to this dict: it is edited in place
 
@@ -298,7 +308,7 @@ def _build_rows(job, ref=None):
                       "halo_a2a_rejected"):
                 if k in live:
                     base_info[k] = live[k]                # the selection happens once: its record goes with every candidate
-            if len(counts) > 1 or str(exchange).startswith("halo"):
+            if measure or str(exchange).startswith("halo"):
                 # two phases, each closed by an agreement every rank reaches: a rank whose step raised never leaves the others
                 # alone inside the collectives of the check
                 good = True

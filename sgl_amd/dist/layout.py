@@ -60,16 +60,28 @@ def device_piece_spmms(rowptr, col, val, n_cols, my_bounds, rowptr_host=None, st
 
 
 def column_chunks(d, n_chunks=2):
-    """Split the feature dimension into `n_chunks` column ranges whose widths are multiples of 32 floats (one
-    128-byte line) except the last: stored as separate contiguous matrices, a chunk row then covers whole cache
-    lines and the chunks together touch no more lines than the unsplit row (d = 100 -> 64 + 36: 2 + 2 lines)."""
+    """Split the feature dimension into (up to) `n_chunks` column ranges for the software-pipelined exchange.  Stored as
+    separate contiguous matrices, a chunk row should cover whole 128-byte lines (32 floats) so that the chunks together touch
+    no more lines than the unsplit row: the d // 32 full lines are dealt out as evenly as possible (earlier chunks get the
+    extra ones) and the d % 32 leftover columns ride with the last chunk (d = 100: 64 + 36 for two chunks, 32 + 32 + 36 for
+    three -- 4 lines per gathered row either way).  More chunks than full lines: the leftover columns become a chunk of their
+    own (d = 100, four chunks: 32 + 32 + 32 + 4)."""
+    d, n_chunks = int(d), int(n_chunks)
     if n_chunks <= 1 or d <= 32:
         return [(0, d)]
-    width = max(32, ((d + n_chunks - 1) // n_chunks + 31) // 32 * 32)
+    full, tail = divmod(d, 32)
+    k = min(n_chunks, full)
+    base, extra = divmod(full, k)
+    widths = [(base + (1 if q < extra else 0)) * 32 for q in range(k)]
+    if tail:
+        if k < n_chunks:
+            widths.append(tail)
+        else:
+            widths[-1] += tail
     out, c = [], 0
-    while c < d:
-        out.append((c, min(d, c + width)))
-        c += width
+    for w in widths:
+        out.append((c, c + w))
+        c += w
     return out
 
 

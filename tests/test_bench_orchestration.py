@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TINY = {"T_tiny": dict(n=3000, m=20_000, d_max=300, d=40, k=3)}
+TINY = {"T_tiny": dict(n=3000, m=20_000, d_max=300, d=40, k=3),
+        "T_wide": dict(n=2000, m=12_000, d_max=200, d=100, k=3)}      # d = 100: 2 / 3 / 4 column chunks are three different cuts
 
 
 def _free_port():
@@ -297,8 +298,9 @@ def test_bench_eight_ranks_gloo_default_is_the_contract_layout(tmp_path):
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])
     plan = j["config"]["plan"]
-    # the pipelining granularity is measured, not assumed: 2 and 4 column chunks both validated and timed, the faster kept
-    assert set(plan["col_chunks_candidates_ms"]) == {"2", "4"}
+    # the pipelining granularity is measured, not assumed: the distinct cuts of 2 / 3 / 4 column chunks are validated and timed,
+    # the fastest kept (d = 40 here: every count cuts 32 + 8, so one candidate remains)
+    assert set(plan["col_chunks_candidates_ms"]) == {"2"}
     from sgl_amd.dist import column_chunks
     chosen = int(min(plan["col_chunks_candidates_ms"], key=plan["col_chunks_candidates_ms"].get))
     assert plan["col_chunks"] == [list(c) for c in column_chunks(40, chosen)]
@@ -371,11 +373,14 @@ def test_bench_need_aware_exchange_as_one_all_to_all(tmp_path):
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo", "halo_a2a"} and "halo_a2a_rejected" not in plan
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto", "--exchange", "halo_a2a"), True),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path),
+                            ("--col-chunks", "auto", "--exchange", "halo_a2a", "--workload", "T_wide"), True), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
-    assert plan["exchange"] == "halo_a2a" and set(plan["col_chunks_candidates_ms"]) == {"2", "4"} and j["value"] > 0
+    assert plan["exchange"] == "halo_a2a" and set(plan["col_chunks_candidates_ms"]) == {"2", "3", "4"} and j["value"] > 0
+    from sgl_amd.dist import column_chunks
+    chosen = int(min(plan["col_chunks_candidates_ms"], key=plan["col_chunks_candidates_ms"].get))
+    assert plan["col_chunks"] == [list(c) for c in column_chunks(100, chosen)]
     assert "halo as one all_to_all_single" in j["config"]["parallelism"] and plan["rows"]["exchange"] == "halo_a2a"
 
 

@@ -31,7 +31,7 @@ from sgl_amd import synthetic  # noqa: E402
 from sgl_amd.dist import HaloPlan, balanced_bounds, column_chunks  # noqa: E402
 
 K = 3
-ALT_CHUNKS = (1, 3, 4)     # other column-chunk counts of the pipelined schedule, modelled next to the default 2
+ALT_CHUNKS = (1, 2, 3, 4)     # column-chunk counts of the pipelined schedule modelled next to each other (bench.py times 2, 3 and 4)
 
 
 def timed(fn, reps=5, warm=2):
@@ -175,9 +175,10 @@ def main():
             t_inf = step_ms(G, 1e9, kind)
             print(f"| {G} | {kind} | " + " | ".join(cells) + f" | {t_inf:.2f} ms ({t1 / t_inf:.2f}x) |")
     print()
-    print("### Pipelining granularity: the need-aware exchange with 1 / 3 / 4 column chunks instead of 2\n")
-    print("More chunks shorten the un-overlapped head (first chunk's SpMM + pack) and tail (last chunk's last SpMM) of the step; every chunk still "
-          "gathers whole 128-byte lines (d = 100 -> 32 + 32 + 32 + 4), so the SpMM total barely moves.\n")
+    print("### Pipelining granularity: the need-aware exchange with 1 / 2 / 3 / 4 column chunks\n")
+    print("More chunks shorten the un-overlapped head (first chunk's SpMM + pack) and tail (last chunk's last SpMM) of the step; every cut keeps "
+          "whole 128-byte lines per chunk row (d = 100 -> 64 + 36, 32 + 32 + 36, 32 + 32 + 32 + 4: four lines per gathered row either way), so the "
+          "SpMM total moves little.\n")
     print("| G | chunks | spmm per chunk ms (slowest rank) | " + " | ".join(f"B = {b} GB/s" for b in rates) + " |")
     print("|---|---|---|" + "---|" * len(rates))
     for G in (2, 4, 8):
