@@ -72,7 +72,10 @@ int sgl_get_tuning(const char *key, int64_t *value);
  *   - rows longer than `long_row_nnz` are cut into "pieces" of <= long_row_nnz non-zeros whose partial sums are
  *     combined in storage order by a fix-up pass (never with atomics: results are deterministic).
  * long_row_nnz <= 0 disables splitting (every row is summed by one sequential fmaf chain, bit-compatible with
- * the reference's matmul.c:23-40 order). */
+ * the reference's matmul.c:23-40 order).
+ * The item LIST is in issue order, not row order: inside every eighth of it (the range one XCD walks) the items holding
+ * >= 2 x item_nnz non-zeros come first, longest first, the rest in row order (tuning key "spmm_heavy_first" = 0 keeps plain
+ * row order).  Items are whole rows, so the order never changes a result. */
 typedef struct sgl_plan sgl_plan_t;
 int sgl_plan_build(sgl_plan_t **out, const int64_t *h_rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz);
 /* counts[0]=n_items, [1]=n_pieces, [2]=n_long_rows, [3]=max rows in an item, [4]=max nnz in an item, [5]=n_rows */
@@ -94,7 +97,8 @@ typedef struct sgl_csr sgl_csr_t;
  * concurrent launches on the same matrix; they can share the caller's CSR arrays).
  * Wraps caller-owned device arrays (NOT copied; they must outlive the handle) and builds the execution plan
  * (copies the row pointers to the host once: this call synchronises `stream`).
- * item_nnz / long_row_nnz: 0 = library default. */
+ * item_nnz / long_row_nnz: 0 = library default (items of 512 non-zeros from 1e8 non-zeros per launch, 256 below, fewer for
+ * matrices too small to fill the chip; rows above 2048 non-zeros are cut). */
 int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
                    const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
                    int32_t long_row_nnz, void *stream);
