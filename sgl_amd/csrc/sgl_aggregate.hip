@@ -330,11 +330,45 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
 
 // Register budget of the register-resident row kernels: few hop vectors per lane -> insist on 8 workgroups per CU (<= 64 VGPRs);
 // left at 4 the scheduler spends the 128 registers it is allowed on speculation (HMAX = 6: 128 VGPRs, 4 waves per SIMD) instead of
-// the ~46 the kernel needs: NAFS at d = 128, H = 6 0.715 -> 0.739 of peak.  Two restructurings that aimed at more waves for MANY
-// hops were measured and rejected (round 3): an online softmax without a score array (0.58 vs 0.67: the per-hop chain serialises
-// what the fused form interleaves) and one row per wavefront with the hops split over the half-waves (v_permlane32_swap
-// exchanges; 8 waves, but 0.57 / 0.48 vs 0.67 / 0.62) -- profiles/r03_aggregators_{online_gate,hop_split}_experiment.log.
+// the ~46 the kernel needs: NAFS at d = 128, H = 6 0.715 -> 0.739 of peak.  At MANY hops these kernels were VALU-issue-bound (see
+// "one hop per lane" below), which is why two restructurings that bought wavefronts with extra instructions lost (round 3): an
+// online softmax without a score array (0.58 vs 0.67) and one row per wavefront with the hops split over the half-waves
+// (v_permlane32_swap exchanges; 8 waves, but 0.57 / 0.48 vs 0.67 / 0.62) -- profiles/r03_aggregators_{online_gate,hop_split}_experiment.log.
 #define ROWREG_MIN_BLOCKS(HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((HMAX) * (CH) <= 16) ? 4 : 2))
+
+// ---- per-row scalars, one hop per lane -------------------------------------------------------------------------------------
+// After the row reductions every lane of a row's group holds all H per-hop scalars.  Evaluating sigmoid / softmax / the IEEE
+// divisions hop after hop costs H instruction sequences per WAVEFRONT (every lane repeats them): ~1 050 VALU instructions at
+// H = 11, i.e. 85 % of the VALU issue slots at the streaming rate (profiles/r03_agg_pmc.md) -- the row kernels were issue-bound.
+// With H <= LPR lane l of the group takes hop l (it keeps hop l's reduced scalars as they are produced): ONE sequence per
+// wavefront, then the weights are broadcast back -- and no per-hop score array stays in registers (NAFS at 12 hop vectors:
+// 82 -> 62 VGPRs, 5 -> 8 wavefronts per SIMD).  The
+// arithmetic (operations, their order, IEEE division, the hop-ordered sum) is unchanged: results are bit-identical.
+template <int LPR>
+__device__ __forceinline__ float from_lane(const float v, const int h) {   // value of lane h of this lane's group
+    if constexpr (LPR == 64) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), h));
+    } else {
+        const int lane = (int)(threadIdx.x & 63);
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & ~(LPR - 1)) + h) << 2, __float_as_int(v)));
+    }
+}
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_xchg<0xB1>(v));
+    v = fmaxf(v, dpp_xchg<0x4E>(v));
+    v = fmaxf(v, dpp_xchg<0x141>(v));
+    if constexpr (LPR >= 16) v = fmaxf(v, dpp_xchg<0x140>(v));
+    if constexpr (LPR >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    if constexpr (LPR >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
 
 // Fused NAFS: one pass over the H hop rows held in registers -> cosine scores -> softmax -> weighted sum.
 // LPR lanes per row, CH float4 chunks per lane (d <= LPR*4*CH), H <= HMAX.  Same arithmetic as the two-pass path.
@@ -359,48 +393,90 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_k
             if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
         }
     }
-    float score[HMAX];
-    float n0 = 0.f, run_max = -INFINITY;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) {
-        score[h] = -INFINITY;
-        if (h < n_hops) {
-            float dot = 0.f, sq = 0.f;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dot = __builtin_fmaf(x[0][c][e], x[h][c][e], dot);
-                    sq = __builtin_fmaf(x[h][c][e], x[h][c][e], sq);
-                }
-            dot = group_sum<LPR>(dot);
-            sq = group_sum<LPR>(sq);
-            const float nh = __fadd_rn(__fsqrt_rn(sq), 1e-10f);
-            if (h == 0) n0 = nh;
-            score[h] = __fdiv_rn(__fdiv_rn(dot, nh), n0);
-            run_max = fmaxf(run_max, score[h]);
-        }
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h)
-        if (h < n_hops) {
-            score[h] = expf(score[h] - run_max);
-            sum += score[h];
-        }
     f4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMAX <= LPR) {
+        // lane l of the row's group collects <x_0, x_l> and |x_l|^2 and owns hop l from here on (see "one hop per lane")
+        float dl = 0.f, ql = 0.f;
 #pragma unroll
-    for (int h = 0; h < HMAX; ++h)
-        if (h < n_hops) {
-            const float w = __fdiv_rn(score[h], sum);
-            if (wout && live && l == 0) wout[r * ldw + h] = w;
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                float dot = 0.f, sq = 0.f;
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[c][e] = __fadd_rn(acc[c][e], __fmul_rn(w, x[h][c][e]));
+                    for (int e = 0; e < 4; ++e) {
+                        dot = __builtin_fmaf(x[0][c][e], x[h][c][e], dot);
+                        sq = __builtin_fmaf(x[h][c][e], x[h][c][e], sq);
+                    }
+                dot = group_sum<LPR>(dot);
+                sq = group_sum<LPR>(sq);
+                dl = (l == h) ? dot : dl;
+                ql = (l == h) ? sq : ql;
+            }
+        const bool mine = l < n_hops;
+        const float nh = __fadd_rn(__fsqrt_rn(ql), 1e-10f);
+        const float n0 = from_lane<LPR>(nh, 0);
+        const float sc = mine ? __fdiv_rn(__fdiv_rn(dl, nh), n0) : -INFINITY;
+        const float run_max = group_max<LPR>(sc);
+        const float ex = mine ? expf(sc - run_max) : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) sum += from_lane<LPR>(ex, h);     // in hop order, like the sequential formulation
+        const float wl = __fdiv_rn(ex, sum);
+        if (wout && live && mine) wout[r * ldw + l] = wl;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                const float w = from_lane<LPR>(wl, h);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __fadd_rn(acc[c][e], __fmul_rn(w, x[h][c][e]));
+            }
+    } else {
+        float score[HMAX];
+        float n0 = 0.f, run_max = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            score[h] = -INFINITY;
+            if (h < n_hops) {
+                float dot = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dot = __builtin_fmaf(x[0][c][e], x[h][c][e], dot);
+                        sq = __builtin_fmaf(x[h][c][e], x[h][c][e], sq);
+                    }
+                dot = group_sum<LPR>(dot);
+                sq = group_sum<LPR>(sq);
+                const float nh = __fadd_rn(__fsqrt_rn(sq), 1e-10f);
+                if (h == 0) n0 = nh;
+                score[h] = __fdiv_rn(__fdiv_rn(dot, nh), n0);
+                run_max = fmaxf(run_max, score[h]);
+            }
         }
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                score[h] = expf(score[h] - run_max);
+                sum += score[h];
+            }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                const float w = __fdiv_rn(score[h], sum);
+                if (wout && live && l == 0) wout[r * ldw + h] = w;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __fadd_rn(acc[c][e], __fmul_rn(w, x[h][c][e]));
+            }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         if (on[c]) {
@@ -447,46 +523,83 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_k
             if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
         }
     }
-    float score[HMAX];
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) {
-        score[h] = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) score[h] = __builtin_fmaf(vv[c][e], x[h][c][e], score[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) score[h] = group_sum<LPR>(score[h]);   // independent chains: interleaved by the scheduler
-    float run_max = -INFINITY;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h)
-        if (h < n_hops) {
-            score[h] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-__fadd_rn(score[h], bias))));     // sigmoid(Linear(x))
-            run_max = fmaxf(run_max, score[h]);
-            if (gout && live && l == 0) gout[r * ldg + h] = score[h];
-        }
-    float sum = 0.f;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) {
-        if (h < n_hops) {
-            score[h] = expf(score[h] - run_max);
-            sum += score[h];
-        }
-    }
     f4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMAX <= LPR) {
+        // lane l of the row's group collects the score of hop l and owns that hop from here on (see "one hop per lane")
+        float sl = 0.f;
 #pragma unroll
-    for (int h = 0; h < HMAX; ++h)
-        if (h < n_hops) {
-            const float w = __fdiv_rn(score[h], sum);
-            if (wout && live && l == 0) wout[r * ldw + h] = w;
+        for (int h = 0; h < HMAX; ++h) {
+            float sc = 0.f;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
+                for (int e = 0; e < 4; ++e) sc = __builtin_fmaf(vv[c][e], x[h][c][e], sc);
+            sc = group_sum<LPR>(sc);
+            sl = (l == h) ? sc : sl;
         }
+        const bool mine = l < n_hops;
+        const float g = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-__fadd_rn(sl, bias))));     // sigmoid(Linear(x))
+        const float run_max = group_max<LPR>(mine ? g : -INFINITY);
+        const float ex = mine ? expf(g - run_max) : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) sum += from_lane<LPR>(ex, h);     // in hop order, like the sequential formulation
+        const float wl = __fdiv_rn(ex, sum);
+        if (live && mine) {
+            if (gout) gout[r * ldg + l] = g;
+            if (wout) wout[r * ldw + l] = wl;
+        }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                const float w = from_lane<LPR>(wl, h);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
+            }
+    } else {
+        float score[HMAX];
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            score[h] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) score[h] = __builtin_fmaf(vv[c][e], x[h][c][e], score[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) score[h] = group_sum<LPR>(score[h]);   // independent chains: interleaved by the scheduler
+        float run_max = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                score[h] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-__fadd_rn(score[h], bias))));     // sigmoid(Linear(x))
+                run_max = fmaxf(run_max, score[h]);
+                if (gout && live && l == 0) gout[r * ldg + h] = score[h];
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            if (h < n_hops) {
+                score[h] = expf(score[h] - run_max);
+                sum += score[h];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                const float w = __fdiv_rn(score[h], sum);
+                if (wout && live && l == 0) wout[r * ldw + h] = w;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
+            }
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         if (on[c]) {

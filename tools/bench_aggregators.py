@@ -35,7 +35,10 @@ def main():
     if os.environ.get("AGG_BLOCKS"):
         _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)
-    for d, H in ((100, 4), (128, 11), (147, 6), (128, 6), (16, 4)):
+    shapes = ((100, 4), (128, 11), (147, 6), (128, 6), (16, 4))
+    if os.environ.get("AGG_SHAPES"):                      # e.g. AGG_SHAPES=250x11,200x6
+        shapes = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["AGG_SHAPES"].split(","))
+    for d, H in shapes:
         feats = [dev.alloc_rows(n, d, device) for _ in range(H)]
         for f in feats:
             f.normal_()
