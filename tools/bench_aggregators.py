@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the MessageOp kernels at the products shape (N = 2 449 029, d = 100, H = 4 hops) on the GPU box.
-Prints achieved GB/s against the algorithmic bytes of each op."""
+Prints achieved GB/s against the algorithmic bytes of each op.
+Environment: AGG_N = rows (default 2 449 029), AGG_SHAPES = "dxH,dxH,..." replaces the default shapes (e.g. 250x11,200x6: the
+two-chunks-per-lane instantiations of the row kernels)."""
 import os
 import sys
 
