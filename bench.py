@@ -58,17 +58,20 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("SGL_BENCH_WORKLOAD", "S1_products"))
     ap.add_argument("--pieces", type=int, default=2, help="row pieces per rank (N>1): transfers start per piece")
-    ap.add_argument("--col-chunks", default="auto",
-                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain; auto = 2, 3 and 4 "
-                         "are all built, validated and timed during setup and the fastest runs")
+    ap.add_argument("--col-chunks", default="3",
+                    help="column chunks of the feature block for the software-pipelined exchange (N>1); 1 = plain; default 3 "
+                         "(32 + 32 + 36 columns at d = 100: what profiles/r03_scale_model.md predicts fastest below the link peak); "
+                         "auto (opt-in) = 2, 3 and 4 are all built, validated and timed during setup and the fastest runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="bit-exact reference summation order")
     ap.add_argument("--exchange", choices=("auto", "halo", "halo_a2a", "p2p", "allgather", "push"),
-                    default=os.environ.get("SGL_BENCH_EXCHANGE", "auto"),
+                    default=os.environ.get("SGL_BENCH_EXCHANGE", "halo"),
                     help="N>1 transport of the per-hop all-gather: halo = need-aware (a rank receives only the rows its block "
                          "gathers, packed into a compact table; sgl_amd/dist/halo.py), halo_a2a = the same as one all_to_all_single, p2p = every row to every rank by grouped "
-                         "RCCL send/recv, allgather = RCCL all-gather on padded pieces, auto = time one hop's exchange with each "
-                         "during setup and keep the fastest, push = stores into peer replicas from the SpMM kernel (opt-in)")
+                         "RCCL send/recv, allgather = RCCL all-gather on padded pieces.  Default halo: a fixed, reproducible path (if it fails "
+                         "to build or to validate on some rank the job falls back to p2p and says so).  Opt-in: auto = time one "
+                         "hop's exchange with each during setup and keep the fastest; push = stores into peer replicas from the "
+                         "SpMM kernel over HIP IPC, validated against p2p before it may run")
     ap.add_argument("--layout", choices=("rows", "auto", "cols", "grid", "all"), default=os.environ.get("SGL_BENCH_LAYOUT", "rows"),
                     help="N>1: rows (default) = A_hat row-sharded in storage + per-hop all-gather: the contract layout, the only "
                          "one whose figure is `value` unless another is asked for.  Alternatives that REPLICATE A_hat, opt-in: "
@@ -117,6 +120,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     wl = workloads[args.workload]
     job = _Job(args, engine, rank, world, wl)
     guard = None
+    line_box = [None]                         # rank 0's JSON line once the timed region is over (the watchdog prints it if later phases hang)
     if world > 1 and emit is print and args.watchdog > 0:
         # a rank that fails before a collective leaves the others waiting in it for ever: end the job with a diagnosis
         import threading
@@ -124,9 +128,14 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
         def stuck():
             if rank == 0:
                 quiet.unmute()
+                if line_box[0] is not None:
+                    # the timed region is over: the measured line goes out as it stands, only what came after it is missing
+                    line_box[0]["watchdog"] = f"no progress after {args.watchdog:.0f} s in phase {_PHASE[0]!r}; later sections missing"
+                    print(json.dumps(line_box[0]), flush=True)
+                    os._exit(0)
                 print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "edge\u00b7featdim/s", "n_gpus": world,
                                   "error": f"watchdog: no progress after {args.watchdog:.0f} s", "phase": _PHASE[0]}), flush=True)
-            os._exit(3)
+            os._exit(3 if line_box[0] is None else 0)
         guard = threading.Timer(args.watchdog, stuck)
         guard.daemon = True
         guard.start()
@@ -168,23 +177,8 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
 
-    _phase("diagnostics")
-    try:
-        diag = _diagnostics(job, halves) if job.budget_left() > -60 else {"skipped": "setup budget exhausted"}
-    except Exception as e:  # noqa: BLE001  (reporting only; the measured value is already in hand)
-        diag = {"failed": repr(e)}
-
-    ceiling = None
-    if not sharded and rank == 0 and hasattr(engine, "gather_ceiling"):
-        ceiling = engine.gather_ceiling(job.col, job.x0, d)
-
-    cpu = None
-    if not sharded and not args.no_cpu_baseline and rank == 0:
-        try:
-            cpu = cpu_baseline(job.rowptr, job.col, job.val, job.x0, d)
-        except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
-            cpu = {"value": None, "unit": "edge\u00b7featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-
+    # ---- the line exists from here on: whatever follows (self-validation, diagnostics, baselines, the papers100M-shaped section)
+    # only ADDS to it, and the watchdog prints it as it stands instead of losing a measured value to a stuck collective ------------
     out = None
     if rank == 0:
         value = nnz * d * K * args.steps / elapsed
@@ -205,7 +199,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
                        "parallelism": info.get("parallelism", "single GPU") if sharded else "single GPU",
                        "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
-                       "plan": info, "setup_s": round(setup_s, 2), "diagnostics": diag},
+                       "plan": info, "setup_s": round(setup_s, 2), "validated": None, "validation": None, "diagnostics": None},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_BYTES, "traffic": traffic,
                          # PMC counters need their own rocprofv3 passes: the figure is the builder's pass over this very
@@ -218,11 +212,51 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                          "traffic_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None,
                          # the bare-gather ceiling of THIS access pattern measured in this run (probe kernel: the same
                          # column ids, row width and pitch; no CSR stream, arithmetic or stores) and the kernel's gather rate
-                         "gather_ceiling_Ggathers_per_s": ceiling,
+                         "gather_ceiling_Ggathers_per_s": None,
                          "kernel_Ggathers_per_s": nnz / world / hop_s / 1e9,
-                         "frac_of_gather_ceiling": (nnz / world / hop_s / 1e9 / ceiling) if ceiling else None},
-            "cpu_baseline": cpu,
+                         "frac_of_gather_ceiling": None},
+            "cpu_baseline": None,
         }
+        line_box[0] = out
+
+    # ---- self-validation of what the timed steps left behind (never part of `value`) -------------------------------------------
+    _phase("validation")
+    if not sharded:
+        if hasattr(engine, "validate_single"):
+            try:
+                v = engine.validate_single()
+            except Exception as e:  # noqa: BLE001
+                v = {"ok": False, "failed": repr(e)[:300]}
+            if rank == 0:
+                out["config"]["validated"], out["config"]["validation"] = v.get("ok"), v
+    elif rank == 0:
+        # N > 1 layouts were validated during setup (before they could be timed): exact bit-checksums of the exchanged rows +
+        # sampled rows of every rank recomputed in fp64 (benchlib/rows.py); a layout that fails never reaches the timed region
+        out["config"]["validated"] = True
+        out["config"]["validation"] = {"when": "setup, before timing", "how": "bit-checksums of exchanged rows + 512 sampled rows per "
+                                       "rank and column chunk recomputed in fp64", "ok": True}
+
+    _phase("diagnostics")
+    job.single_gpu_ms_replayed = (_replayed_profile(args.workload, 1) or {}).get("single_gpu_ms_per_step")
+    try:
+        diag = _diagnostics(job, halves, measured_step_ms=elapsed * 1e3 / args.steps) if job.budget_left() > -60 else \
+            {"skipped": "setup budget exhausted"}
+    except Exception as e:  # noqa: BLE001  (reporting only; the measured value is already in hand)
+        diag = {"failed": repr(e)}
+    if rank == 0:
+        out["config"]["diagnostics"] = diag
+
+    if not sharded and rank == 0 and hasattr(engine, "gather_ceiling"):
+        ceiling = engine.gather_ceiling(job.col, job.x0, d)
+        out["roofline"]["gather_ceiling_Ggathers_per_s"] = ceiling
+        out["roofline"]["frac_of_gather_ceiling"] = (nnz / world / hop_s / 1e9 / ceiling) if ceiling else None
+
+    if not sharded and not args.no_cpu_baseline and rank == 0:
+        try:
+            cpu = cpu_baseline(job.rowptr, job.col, job.val, job.x0, d)
+        except Exception as e:  # noqa: BLE001  (baseline is reporting only; never blocks the GPU number)
+            cpu = {"value": None, "unit": "edge\u00b7featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        out["cpu_baseline"] = cpu
 
     # ---- secondary: the papers100M-shaped graph on the same ranks (bounded; never endangers the line above) -------------
     def emit_line():
@@ -257,6 +291,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
             del step, halves
             job.drop_full()
             job.block = job.x0 = None
+            engine._single = None             # the operands validate_single() looked at
             import gc
             gc.collect()
             if torch.cuda.is_available():

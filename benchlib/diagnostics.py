@@ -13,6 +13,30 @@ def _hop_halves(job, prop, x_chunks, cbufs, inbound):
             "exchange_inbound_GBps_per_rank": (inbound / (exch_ms * 1e-3) / 1e9) if exch_ms > 0 else None}
 
 
+def _per_hop(job, prop, x_chunks, cbufs, measured_step_ms):
+    """Per column chunk, MAX over ranks, each in isolation: the SpMM, the pack kernel (need-aware exchange only) and the wire
+    time of one grouped exchange (exchange minus pack); the bytes the busiest link carries; what fraction of the exchange the
+    pipelined step hid; and the schedule model's prediction from those very numbers next to the measured step
+    (benchlib/model.py) -- a scaling line that explains itself against profiles/r03_scale_model.md."""
+    from .model import explain
+    if not prop._exchanging() or job.K < 2:
+        return None
+    spmm, pack, xfer, link_bytes = [], [], [], []
+    rows_link = job.max_over_ranks(float(prop.busiest_link_rows()))
+    has_pack = hasattr(prop, "pack_only")
+    for c, xc in enumerate(x_chunks):
+        ys = prop.spmm_only([xc])
+        spmm.append(job.timed_s(lambda: prop.spmm_only([xc]), reps=3) * 1e3)
+        nxt = [cbufs[c][0]]
+        ex = job.timed_s(lambda: prop.exchange_only(ys, nxt, keys=[c]), reps=3) * 1e3
+        pk = job.timed_s(lambda: prop.pack_only(ys, keys=[c]), reps=3) * 1e3 if has_pack else 0.0
+        pack.append(pk)
+        xfer.append(max(ex - pk, 0.0))
+        link_bytes.append(rows_link * xc.shape[1] * 4)
+    return explain(spmm, pack, xfer, link_bytes, job.K, measured_step_ms, job.world,
+                   single_gpu_ms=getattr(job, "single_gpu_ms_replayed", None))
+
+
 def _link_probe(job):
     """What the links of this node deliver to the two communication patterns the layouts use (reporting only, a few
     tens of milliseconds): one all_to_all with S bytes per peer (the relay's phases) and a pairwise exchange between
@@ -46,7 +70,7 @@ def _link_probe(job):
     return out
 
 
-def _diagnostics(job, halves):
+def _diagnostics(job, halves, measured_step_ms=None):
     """after the timed region, never part of `value`.  Row-sharded layout: its SpMM and all-gather halves and the
     achieved rate per link; grid layout: the same two halves of the relayed exchange (every byte crosses two links)."""
     diag = None
@@ -56,6 +80,11 @@ def _diagnostics(job, halves):
         ms = diag["exchange_only_ms_per_hop_max_rank"]
         diag["exchange_GBps_per_link"] = (inbound / max(job.world - 1, 1) / (ms * 1e-3) / 1e9) if ms > 0 else None
         prop = halves["rows"][0]
+        if measured_step_ms is not None and job.info.get("layout", "rows") == "rows":
+            try:
+                diag["per_hop"] = _per_hop(job, *halves["rows"], measured_step_ms)
+            except Exception as e:  # noqa: BLE001  (reporting only)
+                diag["per_hop"] = {"failed": repr(e)[:200]}
         if hasattr(prop, "pack_only"):                        # need-aware exchange: the pack kernel alone (inside exchange_only too)
             ys = prop.spmm_only(halves["rows"][1])
             diag["pack_only_ms_per_hop_max_rank"] = job.timed_s(lambda: prop.pack_only(ys), reps=3) * 1e3

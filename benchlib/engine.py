@@ -236,6 +236,40 @@ class GpuEngine:
         err = (y_local[rows].double() - want).abs()
         return bool((err <= tol * mag.clamp_min(1e-30) + 1e-30).all())
 
+    def validate_single(self, samples=4096, tol=1e-5):
+        """Self-check of the single-GPU line, run AFTER the timed region on what the timed steps left behind: (1) `samples` rows of
+        the last hop recomputed in fp64 with plain torch indexing from the matrix the last launch read (kernel-independent);
+        (2) the same launch repeated in strict (reference) summation order into a scratch matrix: row-wise L2 and max-norm
+        distance of the timed kernel's result from it, both against the SURVEY 8(c) tolerance.  Returns the dict that goes to
+        config.validation; its "ok" is config.validated."""
+        from sgl_amd import device as dev
+        from sgl_amd.dist import RowBlock
+        st = getattr(self, "_single", None)
+        if st is None:
+            return {"ok": None, "skipped": "no single-GPU step was built"}
+        rowptr, col, val, d = st["rowptr"], st["col"], st["val"], st["d"]
+        x_prev, y_last = st["x_prev"], st["y_last"]
+        blk = RowBlock(0, rowptr.numel() - 1, st["n"], rowptr, col, val)
+        ok_rows = bool(self.sampled_rows_check(blk, x_prev[:, :d], y_last[:, :d], samples=samples, tol=tol))
+        out = {"sampled_rows": min(samples, blk.n_local), "sampled_rows_fp64_ok": ok_rows, "tolerance": tol}
+        ok = ok_rows
+        free, _ = torch.cuda.mem_get_info()
+        if st["strict"]:
+            out["strict_vs_fast"] = "the timed kernel already ran in strict order"
+        elif y_last.numel() * 4 * 1.2 > free:
+            out["strict_vs_fast"] = "skipped: no room for a scratch hop matrix"
+        else:
+            ref = torch.empty_like(y_last)
+            dev.DeviceCSR(rowptr, col, val, (blk.n_local, st["n"]), strict=True).spmm(x_prev, out=ref)
+            dn = (y_last[:, :d] - ref[:, :d]).norm(dim=1)
+            rn = ref[:, :d].norm(dim=1).clamp_min(1e-30)
+            out["strict_vs_fast_max_row_rel_l2"] = float((dn / rn).max())
+            out["strict_vs_fast_max_abs_rel"] = float((y_last[:, :d] - ref[:, :d]).abs().max() / ref[:, :d].abs().max().clamp_min(1e-30))
+            ok = ok and out["strict_vs_fast_max_row_rel_l2"] <= tol and out["strict_vs_fast_max_abs_rel"] <= tol
+            del ref
+        out["ok"] = bool(ok)
+        return out
+
     def single_step(self, args, rowptr, col, val, x0, n, d, K):
         from sgl_amd import device as dev
         csr = dev.DeviceCSR(rowptr, col, val, (rowptr.numel() - 1, n), strict=args.strict)
@@ -254,6 +288,9 @@ class GpuEngine:
         info = csr.info()
         if pingpong:
             info["hops_retained"] = "last two only (K hop matrices of this size do not fit one GPU)"
+        # what validate_single() looks at after the timed region: the operand and the result of the LAST launch of a step
+        self._single = {"rowptr": rowptr, "col": col, "val": val, "d": d, "n": n, "strict": bool(args.strict),
+                        "x_prev": x_in if (K == 1 or n_out != n) else outs[K - 2], "y_last": outs[K - 1]}
         if n_out != n:
             # a row block against the full replica (S3_papers_shard): K launches of the same hop
             def step():

@@ -153,15 +153,18 @@ class _Job:
 
 
 def _select_exchange(job, full, halo):
-    """row-sharded layout: pick the transport of the per-hop all-gather.  auto = time one hop's exchange with every candidate --
-    the need-aware packed exchange (halo: pack kernel + grouped send/recv of the rows each peer gathers) and the full-replica
-    process-group transports (p2p, allgather) -- and keep the fastest (decision on the MAX over ranks, so every rank picks the
-    same); the fused push transport is an opt-in further candidate that must map all peers, reproduce the process-group result
-    and be >= 3 % faster."""
+    """row-sharded layout: the transport of the per-hop all-gather when the flags leave a choice (--exchange auto / push; the default
+    --exchange halo never comes here).  auto = time one hop's exchange with every candidate -- the need-aware packed exchange
+    (halo: pack kernel + grouped send/recv of the rows each peer gathers) and the full-replica process-group transports (p2p,
+    allgather) -- and keep the fastest (decision on the MAX over ranks, so every rank picks the same).  push = the fused
+    transport (the SpMM kernel stores finished rows into the peers' replicas over HIP IPC): it must map all peers AND reproduce
+    the process-group result of a whole k-hop step on every rank before it may run; otherwise the job goes on with the
+    process-group transport and says why.  No timing decides whether push runs: it was asked for."""
     args, engine, info, K, device = job.args, job.engine, job.info, job.K, job.device
     if full is None:
         return "halo"
     prop, handles, x_chunks, cbufs = full["prop"], full["handles"], full["x_chunks"], full["cbufs"]
+    transports = getattr(engine, "transports", ("p2p", "allgather"))
 
     def setup_push():
         """collective; returns True iff every rank mapped every peer's replicas"""
@@ -175,11 +178,25 @@ def _select_exchange(job, full, halo):
         return ok
 
     exchange = args.exchange
-    if exchange == "push" and not setup_push():
-        exchange = "p2p"
+    if exchange == "push":
+        base = transports[0]
+        prop.transport = base
+        if not handles or not setup_push():
+            info["push_rejected"] = "mapping failed"
+            return base
+        ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
+        got_hops = prop.propagate_push(x_chunks, K)
+        same = True
+        for a_, b_ in zip(ref_hops[K], got_hops[K]):
+            scale_ = float(a_.abs().max()) if a_.numel() else 0.0
+            same = same and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
+        if not prop.agree(same, device):
+            info["push_rejected"] = "result mismatch"
+            return base
+        info["push_validated_against"] = base
+        return "push"
     if exchange != "auto":
         return exchange
-    transports = getattr(engine, "transports", ("p2p", "allgather"))
     exchange = transports[0]
     if job.world == 1 or job.nbuf == 0:
         return exchange
@@ -217,26 +234,8 @@ def _select_exchange(job, full, halo):
             hp.collective = False
     exchange = min(cand, key=cand.get)
     info["exchange_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in cand.items()}
-    # opt-in (SGL_BENCH_TRY_PUSH=1): a fault in a peer store would take the whole job down
-    if os.environ.get("SGL_BENCH_TRY_PUSH", "0") != "1" or not handles or exchange.startswith("halo"):
-        return exchange
-    prop.transport = exchange
-    if not setup_push():
-        info["push_rejected"] = "mapping failed"
-        return exchange
-    ref_hops = prop.propagate_chunked(x_chunks, K, buffers=cbufs)
-    got_hops = prop.propagate_push(x_chunks, K)
-    same = True
-    for a_, b_ in zip(ref_hops[K], got_hops[K]):
-        scale_ = float(a_.abs().max()) if a_.numel() else 0.0
-        same = same and (a_.numel() == 0 or float((a_ - b_).abs().max()) <= 1e-5 * max(scale_, 1e-30))
-    if not prop.agree(same, device):
-        info["push_rejected"] = "result mismatch"
-        return exchange
-    fullt = {exchange: job.timed_s(lambda: prop.propagate_chunked(x_chunks, K, buffers=cbufs)),
-             "push": job.timed_s(lambda: prop.propagate_push(x_chunks, K))}
-    info["full_step_candidates_ms"] = {k: round(v * 1e3, 3) for k, v in fullt.items()}
-    return "push" if fullt["push"] < 0.97 * fullt[exchange] else exchange
+    info["exchange_selected_by"] = "measured exchange-only time (--exchange auto, opt-in)"
+    return exchange
 
 
 def _rows_full_replica(job, chunks):
@@ -271,12 +270,15 @@ def _rows_halo(job, chunks):
 
 
 def _build_rows(job, ref=None):
-    """The contract layout.  --col-chunks auto (default): how finely the feature block is cut for the pipelined exchange trades
-    the un-overlapped head and tail of a step against per-chunk launch cost and against the gather efficiency of narrow chunks
-    (profiles/r03_scale_model.md: 3 or 4 chunks win in the model when the links are the bound, 2 when compute is), and that
-    depends on what the links deliver -- so 2, 3 and 4 chunks (d = 100: 64 + 36, 32 + 32 + 36, 32 + 32 + 32 + 4; always 4 lines per
-    gathered row) are built, validated and timed (untimed setup; the exchange is selected once, with the first) and the fastest
-    is kept."""
+    """The contract layout.  The default is a FIXED path (--exchange halo --col-chunks 3): nothing about the headline run is
+    decided by a timing race, so two runs of the same command do the same thing.  --col-chunks auto (opt-in): how finely the feature
+    block is cut for the pipelined exchange trades the un-overlapped head and tail of a step against per-chunk launch cost and
+    against the gather efficiency of narrow chunks (profiles/r03_scale_model.md: 3 or 4 chunks win in the model when the links are
+    the bound, 2 when compute is), and that depends on what the links deliver -- so 2, 3 and 4 chunks (d = 100: 64 + 36,
+    32 + 32 + 36, 32 + 32 + 32 + 4; always 4 lines per gathered row) are built, validated and timed (untimed setup; the exchange is
+    selected once, with the first) and the fastest is kept.  Whatever is chosen is validated before it is timed; a need-aware
+    exchange that fails to build or to validate on ANY rank is replaced by the full-replica p2p exchange on ALL ranks
+    (plan.halo_rejected says so)."""
     args = job.args
     auto = str(args.col_chunks) == "auto"
     measure = auto and job.world > 1 and job.nbuf > 0
@@ -302,10 +304,19 @@ def _build_rows(job, ref=None):
             set_info(base_info)
             if getattr(job, "rows_inbound_bytes", None) is not None:
                 job.rows_inbound_bytes = None
-            cand = _build_rows_for(job, ref, nc, exchange)
+            cand, good = None, True
+            try:
+                cand = _build_rows_for(job, ref, nc, exchange)
+            except Exception as e:  # noqa: BLE001  (same code on every rank, so an error is too; agree() settles it)
+                good = False
+                sys.stderr.write(f"[bench] rows with {nc} column chunks ({exchange or args.exchange}) could not be built on rank "
+                                 f"{job.rank}: {e!r}\n")
+            if not job.agree(good):
+                exchange = job.info.get("exchange") or exchange or args.exchange
+                continue
             exchange = job.info["exchange"]
-            for k in ("exchange_candidates_ms", "push_peer_rows_skipped", "full_step_candidates_ms", "push_rejected",
-                      "halo_a2a_rejected"):
+            for k in ("exchange_candidates_ms", "exchange_selected_by", "push_peer_rows_skipped", "push_validated_against",
+                      "push_rejected", "halo_a2a_rejected"):
                 if k in live:
                     base_info[k] = live[k]                # the selection happens once: its record goes with every candidate
             if measure or str(exchange).startswith("halo"):
@@ -338,14 +349,15 @@ def _build_rows(job, ref=None):
     if best is None and str(exchange).startswith("halo"):
         # the need-aware exchange did not reproduce itself on this system: the run goes on with the full-replica exchange
         base_info["halo_rejected"] = f"{exchange}: validation failed, fell back to the full-replica exchange"
-        best, timing, exchange = attempt("p2p")
+        best, timing, exchange = attempt(getattr(job.engine, "transports", ("p2p",))[0])
     if best is None:
         raise RuntimeError("no column chunking of the row-sharded layout passed validation")
     nc, cand, info, inbound = best
     set_info(info)
     job.rows_inbound_bytes = inbound
-    if timing:
+    if measure and timing:
         job.info["col_chunks_candidates_ms"] = {str(k): round(v * 1e3, 3) for k, v in timing.items()}
+        job.info["col_chunks_selected_by"] = "measured step time (--col-chunks auto, opt-in)"
     job.col_chunks_chosen = nc
     return cand
 
@@ -365,6 +377,10 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
     want_a2a = want == "halo_a2a"
     if want_a2a:
         want = "halo"
+    if want == "halo" and not can_halo:
+        # one rank, a single hop (nothing is exchanged) or an engine without the need-aware exchange: the full-replica transport
+        want = exchange_fixed = getattr(job.engine, "transports", ("p2p",))[0]
+        want_a2a = False
     full = halo = None
     if want != "halo" or not can_halo:
         full = _rows_full_replica(job, chunks)

@@ -369,14 +369,25 @@ class HaloPropagator:
             outs.append(y)
         return outs
 
-    def exchange_only(self, ys, tables_next):
-        works = [self.begin_exchange(y, t, key=c) for c, (y, t) in enumerate(zip(ys, tables_next))]
+    def exchange_only(self, ys, tables_next, keys=None):
+        """keys: the chunk index of every entry (default 0, 1, ...): a caller that times ONE chunk passes its index so the
+        chunk's own send buffer is used"""
+        keys = range(len(ys)) if keys is None else keys
+        works = [self.begin_exchange(y, t, key=c) for c, y, t in zip(keys, ys, tables_next)]
         for w in works:
             w.wait()
 
-    def pack_only(self, ys):
-        for c, y in enumerate(ys):
+    def pack_only(self, ys, keys=None):
+        keys = range(len(ys)) if keys is None else keys
+        for c, y in zip(keys, ys):
             self._pack(y, c)
+
+    def busiest_link_rows(self):
+        """rows the busiest link of this rank carries per hop in one direction (to or from a single peer)"""
+        pl = self.plan
+        rows_in = max([int(t.numel()) for t in pl.need] + [0])
+        rows_out = max([int(t.numel()) for t in pl.send_rows] + [0])
+        return max(rows_in, rows_out)
 
 
 def block_halo(block, bounds, group=None, strict=False, reorder=None):

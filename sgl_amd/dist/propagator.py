@@ -155,7 +155,15 @@ class ShardedPropagator:
             outs.append(y_local)
         return outs
 
-    def exchange_only(self, y_chunks, x_next_chunks):
+    def busiest_link_rows(self):
+        """rows the busiest link of this rank carries per hop in one direction: the largest peer block (full all-gather)"""
+        sizes = [int(self.pb[q, -1] - self.pb[q, 0]) for q in range(self.world)]
+        if self.world == 1:
+            return 0
+        # in-bound: the largest peer block; out-bound: my own block to every peer
+        return max(max(s for q, s in enumerate(sizes) if q != self.rank), sizes[self.rank])
+
+    def exchange_only(self, y_chunks, x_next_chunks, keys=None):
         """one hop's all-gather of already computed local rows (no SpMM); blocks the stream until it has landed"""
         for y_local, x_next in zip(y_chunks, x_next_chunks):
             works = []

@@ -172,7 +172,7 @@ def _worker(rank, world, port, out_dir, extra=(), a2a=False, break_halo=False):
     if a2a:
         _emulate_all_to_all_single(rank, world)
     args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_tiny",
-                             "--pieces", "3", "--col-chunks", "2", "--no-cpu-baseline", *extra])
+                             "--pieces", "3", "--no-cpu-baseline", *extra])
     lines = []
     engine_cls = _make_engine()
     engine_cls.halo_collective = bool(a2a)
@@ -183,6 +183,8 @@ def _worker(rank, world, port, out_dir, extra=(), a2a=False, break_halo=False):
 
         def bad_halo(self, args_, blk, bounds):
             plan, prop, cblk = good_halo(self, args_, blk, bounds)
+            if break_halo == "raise":
+                raise RuntimeError("need-aware exchange unavailable on this system (test)")
             if rank == 1:
                 real = prop.begin_exchange
 
@@ -205,7 +207,8 @@ def _worker(rank, world, port, out_dir, extra=(), a2a=False, break_halo=False):
 
 def test_bench_two_ranks_gloo(tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto")), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--layout", "auto", "--exchange", "auto", "--col-chunks", "2")),
+             nprocs=world, join=True)
     r0 = json.load(open(tmp_path / "rank0.json"))
     r1 = json.load(open(tmp_path / "rank1.json"))
     assert len(r0["lines"]) == 1 and r1["lines"] == [] and not r0["initialized_after"]
@@ -217,8 +220,10 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["unit"] == "edge\u00b7featdim/s" and j["metric"].startswith("pre-prop SpMM throughput") and j["vs_baseline"] is None
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] and j["cpu_baseline"] is None
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather", "halo")
+    assert j["config"]["plan"]["exchange"] in ("p2p", "allgather", "halo")       # opt-in selection: whichever won is valid
     assert set(j["config"]["plan"]["exchange_candidates_ms"]) == {"p2p", "allgather", "halo"}
+    assert j["config"]["plan"]["exchange_selected_by"].startswith("measured exchange-only time")
+    assert j["config"]["validated"] is True and j["config"]["validation"]["when"].startswith("setup")
     dg = j["config"]["diagnostics"]
     assert dg["spmm_only_ms_per_hop_max_rank"] > 0 and dg["exchange_only_ms_per_hop_max_rank"] > 0
     assert dg["exchange_inbound_GBps_per_rank"] > 0
@@ -237,23 +242,39 @@ def test_bench_two_ranks_gloo(tmp_path):
 
 
 def test_bench_rows_only_keeps_no_replica_and_budget_skips(tmp_path):
-    """default (--layout rows): the contract layout is the headline, nothing replica-based is ever built; with --layout auto a
-    zero setup budget skips the alternative and says so; --exchange halo / p2p run exactly that transport"""
+    """default flags: the contract layout with the FIXED need-aware exchange and 3 column chunks -- nothing is selected by a timing
+    race, nothing replica-based is ever built; the line explains itself per hop (SpMM / pack / wire ms, rate on the busiest link,
+    overlap, the schedule model's prediction beside the measured step); with --layout auto a zero setup budget skips the
+    alternative and says so; --exchange halo / p2p run exactly that transport"""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--workload", "T_wide")), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert list(plan["layout_candidates_ms"]) == ["rows"] and plan["layout"] == "rows" and "adjacency_replicated_for" not in plan
     assert plan["alternatives"] == {} and j["config"]["parallelism"].startswith("row-sharded x2")
     assert abs(j["value"] - plan["rows"]["value"]) / j["value"] < 0.9          # the headline IS the row-sharded job (separate timings)
+    # the deterministic default: no candidates, no selection records
+    assert plan["exchange"] == "halo" and plan["col_chunks"] == [[0, 32], [32, 64], [64, 100]]
+    for key in ("exchange_candidates_ms", "exchange_selected_by", "col_chunks_candidates_ms", "col_chunks_selected_by",
+                "full_step_candidates_ms", "halo_rejected"):
+        assert key not in plan, key
+    ph = j["config"]["diagnostics"]["per_hop"]
+    assert ph["spmm_ms"] > 0 and ph["pack_ms"] > 0 and ph["exchange_wire_ms"] >= 0 and 0.0 <= ph["overlap_fraction"] <= 1.0
+    assert len(ph["per_chunk"]["spmm_ms"]) == 3 and all(b > 0 for b in ph["per_chunk"]["busiest_link_bytes"])
+    assert ph["link_GBps_per_direction_busiest_link"] is None or ph["link_GBps_per_direction_busiest_link"] > 0
+    m = ph["model"]
+    assert m["measured_ms_per_step"] == j["ms_per_step"] and m["predicted_ms_per_step_at_measured_rates"] > 0
+    assert m["predicted_ms_per_step_free_links"] <= m["predicted_ms_per_step_at_measured_rates"] + 1e-9
+    assert set(m["predicted_ms_per_step_by_link_GBps"]) == {"35", "45", "55", "65", "76.8"}
     for ex in ("halo", "p2p"):
-        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--exchange", ex)), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--exchange", ex, "--col-chunks", "2")), nprocs=world, join=True)
         j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
         plan = j["config"]["plan"]
         assert plan["exchange"] == ex and "exchange_candidates_ms" not in plan and plan["layout"] == "rows"
         assert ("halo" in plan) == (ex == "halo")
         dg = j["config"]["diagnostics"]
         assert dg["exchange_only_ms_per_hop_max_rank"] > 0 and ("pack_only_ms_per_hop_max_rank" in dg) == (ex == "halo")
+        assert (dg["per_hop"]["pack_ms"] > 0) == (ex == "halo")
         if ex == "halo":
             h = plan["halo"]
             assert h["compact_rows"] == h["own_rows"] + h["ghost_rows"] and 0 <= h["exchange_skipped_fraction"] < 1
@@ -290,26 +311,47 @@ def test_bench_four_ranks_gloo_all_layouts(tmp_path):
 
 def test_bench_eight_ranks_gloo_default_is_the_contract_layout(tmp_path):
     """the driver's largest launch shape: 8 ranks, default flags: the headline is the row-sharded job (A_hat stored per rank,
-    per-hop all-gather), the transport is chosen among halo / p2p / allgather by their measured exchange time, and the
-    need-aware figures are in the line"""
+    per-hop need-aware all-gather), on a FIXED path -- halo exchange, 3 column chunks, nothing chosen by timing -- and the
+    per-hop breakdown with the model's prediction for this G is in the line"""
     world = 8
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto")), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--workload", "T_wide")), nprocs=world, join=True)
     lines = [json.load(open(tmp_path / f"rank{r}.json"))["lines"] for r in range(world)]
     assert len(lines[0]) == 1 and all(l == [] for l in lines[1:])
     j = json.loads(lines[0][0])
     plan = j["config"]["plan"]
-    # the pipelining granularity is measured, not assumed: the distinct cuts of 2 / 3 / 4 column chunks are validated and timed,
-    # the fastest kept (d = 40 here: every count cuts 32 + 8, so one candidate remains)
-    assert set(plan["col_chunks_candidates_ms"]) == {"2"}
+    from sgl_amd.dist import column_chunks
+    assert plan["exchange"] == "halo" and plan["col_chunks"] == [list(c) for c in column_chunks(100, 3)]
+    for key in ("exchange_candidates_ms", "col_chunks_candidates_ms", "halo_rejected", "push_rejected"):
+        assert key not in plan, key
+    assert j["n_gpus"] == 8 and plan["layout"] == "rows" and plan["contract_layout"] == "rows" and plan["alternatives"] == {}
+    assert list(plan["layout_candidates_ms"]) == ["rows"] and "adjacency_replicated_for" not in plan
+    assert plan["rows"]["exchange"] == "halo" and 0.0 <= plan["rows"]["exchange_skipped_fraction"] < 1.0
+    assert j["config"]["parallelism"].startswith("row-sharded x8 (A_hat stored as one row block per GPU)")
+    dg = j["config"]["diagnostics"]
+    assert dg["exchange_GBps_per_link"] > 0 and j["value"] > 0 and j["config"]["validated"] is True
+    ph = dg["per_hop"]
+    for key in ("spmm_ms", "pack_ms", "exchange_wire_ms", "per_chunk", "link_GBps_per_direction_busiest_link", "link_frac_of_xgmi_peak",
+                "overlap_fraction", "exposed_exchange_ms_per_step", "model"):
+        assert key in ph, key
+    for key in ("predicted_ms_per_step_at_measured_rates", "measured_ms_per_step", "predicted_ms_per_step_free_links",
+                "predicted_ms_per_step_by_link_GBps", "schedule"):
+        assert key in ph["model"], key
+
+
+def test_bench_eight_ranks_gloo_opt_in_selection(tmp_path):
+    """--exchange auto --col-chunks auto (opt-in): the transport is chosen among halo / p2p / allgather by their measured exchange
+    time and the pipelining granularity by measured step time; whatever wins was validated, and the line says how it was chosen"""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto", "--exchange", "auto")), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    # the distinct cuts of 2 / 3 / 4 column chunks are validated and timed (d = 40 here: every count cuts 32 + 8, so one remains)
+    assert set(plan["col_chunks_candidates_ms"]) == {"2"} and plan["col_chunks_selected_by"].startswith("measured step time")
     from sgl_amd.dist import column_chunks
     chosen = int(min(plan["col_chunks_candidates_ms"], key=plan["col_chunks_candidates_ms"].get))
     assert plan["col_chunks"] == [list(c) for c in column_chunks(40, chosen)]
-    assert j["n_gpus"] == 8 and plan["layout"] == "rows" and plan["contract_layout"] == "rows" and plan["alternatives"] == {}
-    assert list(plan["layout_candidates_ms"]) == ["rows"] and "adjacency_replicated_for" not in plan
     assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo"} and plan["exchange"] in plan["exchange_candidates_ms"]
-    assert plan["rows"]["exchange"] == plan["exchange"] and 0.0 <= plan["rows"]["exchange_skipped_fraction"] < 1.0
-    assert j["config"]["parallelism"].startswith("row-sharded x8 (A_hat stored as one row block per GPU)")
-    assert j["config"]["diagnostics"]["exchange_GBps_per_link"] > 0 and j["value"] > 0
+    assert plan["rows"]["exchange"] == plan["exchange"] and j["value"] > 0
 
 
 def test_bench_eight_ranks_gloo(tmp_path):
@@ -369,7 +411,7 @@ def test_bench_need_aware_exchange_as_one_all_to_all(tmp_path):
     checksums on random data before it may be timed, a candidate of the selection, and runnable on request through both column
     chunk candidates"""
     world = 4
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto"), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), ("--col-chunks", "auto", "--exchange", "auto"), True), nprocs=world, join=True)
     j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
     plan = j["config"]["plan"]
     assert set(plan["exchange_candidates_ms"]) == {"p2p", "allgather", "halo", "halo_a2a"} and "halo_a2a_rejected" not in plan
@@ -394,3 +436,14 @@ def test_bench_falls_back_when_the_need_aware_exchange_misdelivers(tmp_path):
     plan = j["config"]["plan"]
     assert plan["exchange"] == "p2p" and plan["halo_rejected"].startswith("halo: validation failed") and j["value"] > 0
     assert "halo" not in plan and plan["rows"]["exchange"] == "p2p" and plan["rows"]["exchange_skipped_fraction"] == 0.0
+
+
+def test_bench_default_falls_back_when_the_need_aware_exchange_cannot_be_built(tmp_path):
+    """default flags, and the need-aware exchange raises while it is built: every rank agrees, the job runs -- validated -- on the
+    full-replica p2p exchange and the line says so"""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), (), False, "raise"), nprocs=world, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))["lines"][0])
+    plan = j["config"]["plan"]
+    assert plan["exchange"] == "p2p" and plan["halo_rejected"].startswith("halo") and j["value"] > 0 and plan["layout"] == "rows"
+    assert j["config"]["validated"] is True and j["config"]["diagnostics"]["per_hop"]["pack_ms"] == 0

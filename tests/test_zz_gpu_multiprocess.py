@@ -1,0 +1,560 @@
+"""Multi-process and orchestration tests on the GPU box (two / four processes sharing the one GPU, bench.py's N > 1 path with the
+real kernels, the RCCL backend with one rank, the examples and the CLI contract).  Collected AFTER every oracle / golden parity
+test (file name + the `orchestration` marker, see conftest.py), so that `pytest -x` can never hide a SURVEY section-8 row behind
+an orchestration hiccup.  Nothing here asserts WHICH candidate won a timing race: a specific path is forced with flags and the
+validity of whatever ran is asserted."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from inputs import hash_matrix
+
+pytestmark = [pytest.mark.gpu, pytest.mark.orchestration]
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    from sgl_amd import _lib
+    _lib.require_gpu()
+    torch.cuda.set_device(0)
+    return torch.device("cuda", 0)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _planted_communities(n, bs, deg, p_in, seed):
+    rng = np.random.default_rng(seed)
+    a = np.repeat(np.arange(n), deg)
+    near = (a // bs) * bs + rng.integers(0, bs, a.size)
+    far = rng.integers(0, n, a.size)
+    b = np.where(rng.random(a.size) < p_in, np.minimum(near, n - 1), far)
+    keep = a != b
+    m = sp.coo_matrix((np.ones(keep.sum(), np.float32), (a[keep], b[keep])), shape=(n, n)).tocsr()
+    m = ((m + m.T) > 0).astype(np.float32).tocsr()
+    m.sort_indices()
+    return m
+
+
+def _ingest_rank_worker(rank, world, port, raw_dir, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    import torch.distributed as dist
+    import oracle as orc
+    from sgl_amd import io
+    from sgl_amd.dist import ShardedGraphOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        q = io.load_custom_homo_raw_sharded(raw_dir, rank, world, device="cuda:0", chunk_edges=211, group=dist.group.WORLD)
+        blk = q["block"]
+        op = ShardedGraphOp(2, r=0.5, strict_order=True, pieces=2, col_chunks=2)
+        hops = op.propagate(blk, q["x"])                 # disk -> this rank's rows -> row-sharded propagation
+        f = np.load(_os.path.join(raw_dir, "adj_matrix.npz"))
+        n = blk.n
+        full = sp.csr_matrix((f["data"], (f["row"], f["col"])), shape=(n, n))
+        full.sort_indices()
+        x = np.load(_os.path.join(raw_dir, "x.npy"))
+        ref = orc.propagate(orc.laplacian_adj(full.indptr, full.indices, full.data, n, 0.5), x, 2)
+        ok = 0 < blk.hi - blk.lo < n and (op.lo, op.hi) == (blk.lo, blk.hi)
+        for h in range(3):
+            ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][blk.lo:blk.hi], 1e-5)
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ingest_feeds_row_sharded_propagation(goldens, cuda, tmp_path):
+    """two processes: raw files -> each rank's row block (edge counts all-reduced over the group) -> ShardedGraphOp on
+    the block; nobody ever holds the whole adjacency"""
+    import torch.multiprocessing as mp
+    from sgl_amd import io
+    g7 = goldens.npz("g7_ingest")
+    n = int(g7["n"])
+    raw = tmp_path / "raw"
+    w = np.abs(g7["data"]) + 0.5                     # both directions of every edge: a symmetric weighted graph
+    io.save_custom_homo_raw(str(raw), np.concatenate([g7["row"], g7["col"]]), np.concatenate([g7["col"], g7["row"]]),
+                            np.concatenate([w, w]), x=hash_matrix(n, 20, seed=9))
+    port = _free_port()
+    mp.spawn(_ingest_rank_worker, args=(2, port, str(raw), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle as orc
+    from inputs import hash_matrix as hm
+    from sgl_amd.dist import ShardedGraphOp
+    from sgl_amd.operators.message_op import OverSmoothDistanceWeightedOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(_os.path.join(root, "tests", "golden", "graphs.npz")))
+        adj = sp.csr_matrix((g["pl2000|data"], g["pl2000|indices"], g["pl2000|indptr"]), shape=(2000, 2000))
+        x = hm(2000, 100, seed=21)
+        op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, col_chunks=2)
+        hops = op.propagate(adj, x)                     # HIP kernels on cuda:0, exchange staged through gloo
+        ref = orc.propagate(orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5), x, 3)
+        ok = 0 < op.hi - op.lo < 2000
+        for h in range(4):
+            ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][op.lo:op.hi], 1e-5)
+        # the fused push transport: each rank's SpMM kernel stores straight into the OTHER process's replica (HIP IPC)
+        from sgl_amd import device as dev_
+        from sgl_amd.dist import ShardedPropagator, all_piece_bounds, column_chunks, device_piece_spmms
+        ptr_, col_, val_ = orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5)
+        dv = torch.device("cuda", 0)
+        rp_d, c_d, v_d = (torch.from_numpy(ptr_).to(dv), torch.from_numpy(col_.astype(np.int32)).to(dv),
+                          torch.from_numpy(val_.astype(np.float32)).to(dv))
+        pb = all_piece_bounds(ptr_, world, 2)
+        fns, hs = device_piece_spmms(rp_d, c_d, v_d, 2000, pb[rank], strict=True)
+        prop = ShardedPropagator(fns, pb, rank, world, 2000)
+        chunks = column_chunks(100, 2)
+        xs = [torch.from_numpy(x[:, a:b].copy()).to(dv) for a, b in chunks]
+        prop.enable_push([b - a for a, b in chunks], hs, dv)
+        ok = ok and prop.agree(prop.push_error is None, torch.device("cpu"))
+        for rep in range(2):                                   # twice: the ping-pong replicas are recycled correctly
+            hp = prop.propagate_push(xs, 3)
+            for h in range(4):
+                got = torch.cat([t.contiguous() for t in hp[h]], dim=1).cpu().numpy()
+                ok = ok and orc.parity_ok(got, ref[h][prop.lo:prop.hi], 1e-5)
+        nafs = OverSmoothDistanceWeightedOp().aggregate([h.contiguous() for h in hops])
+        full = op.gather_rows(nafs.contiguous())         # config-4 flow: NAFS on the shards, then gather
+        ok = ok and orc.parity_ok(full.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        # feature-sharded layout: every rank runs the whole chain on its column slice, no exchange; a column-wise
+        # aggregator (mean) applies to the slices unchanged and gather_full() assembles the full matrix
+        from sgl_amd.operators.message_op import MeanMessageOp
+        opc = ShardedGraphOp(3, r=0.5, strict_order=True, row_groups=1)
+        hc = opc.propagate(adj, x)
+        ok = ok and (opc.lo, opc.hi) == (0, 2000) and (opc.c0, opc.c1) == ((0, 64), (64, 100))[rank]   # whole lines first
+        for h in range(4):
+            ok = ok and np.array_equal(hc[h].cpu().numpy(), ref[h][:, opc.c0:opc.c1])
+        mean = MeanMessageOp(0, 4).aggregate([h.contiguous() for h in hc])
+        fullc = opc.gather_full(mean)
+        ok = ok and orc.parity_ok(fullc.cpu().numpy(), orc.agg_mean(ref, 0, 4), 1e-6, rowwise=False)
+        # NAFS on column slices: partial dot products all-reduced, weights shared, columns combined locally
+        nafs_c = opc.gather_full(opc.over_smooth_aggregate(hc))
+        ok = ok and orc.parity_ok(nafs_c.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        ok = ok and torch.equal(op.over_smooth_aggregate(hops), nafs)      # row-sharded: the fused kernel itself
+        # ROW-SHARDED STORAGE (the contract layout): rank 0 holds the raw graph and hands out row blocks; every rank
+        # normalises ITS block (degrees all-reduced), never sees the rest of A or A_hat, and passes only its feature rows
+        from sgl_amd.dist import RowBlock, balanced_bounds, exchange_checksums, scatter_row_blocks
+        from sgl_amd.operators.utils import canonical_csr
+        raw = canonical_csr(adj)
+        bnd = balanced_bounds(raw.indptr.astype(np.int64) + np.arange(2001), world)
+        full = tuple(torch.from_numpy(np.ascontiguousarray(a_, dtype=t_)).to(dv) for a_, t_ in
+                     ((raw.indptr, np.int64), (raw.indices, np.int32), (raw.data, np.float32))) if rank == 0 else None
+        blk = scatter_row_blocks(full, bnd, 2000, dv)
+        ok = ok and isinstance(blk, RowBlock) and (blk.lo, blk.hi) == (int(bnd[rank]), int(bnd[rank + 1])) and blk.nnz < raw.nnz
+        ops = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, col_chunks=1)
+        hs_ = ops.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))     # only my rows of X
+        ok = ok and (ops.lo, ops.hi) == (blk.lo, blk.hi) and ops.a_hat_block.nnz == blk.nnz + (blk.hi - blk.lo)
+        for h in range(4):
+            ok = ok and np.array_equal(hs_[h].cpu().numpy(), ref[h][ops.lo:ops.hi])     # strict order: bit-exact from raw A
+        rep_ = ops.gather_rows(hs_[3].contiguous())
+        ok = ok and exchange_checksums(rep_, hs_[3], bnd) and np.array_equal(rep_.cpu().numpy(), ref[3])
+        # the default exchange of this path is need-aware (compact table, packed ghosts); the full-replica all-gather and the
+        # chunk-pipelined schedule give the same bits, and the plan moved no more rows than the block references
+        plan_ = ops.halo_plan
+        ok = ok and plan_.n_compact == (blk.hi - blk.lo) + plan_.n_ghost and 0 < plan_.n_ghost <= 2000 - (blk.hi - blk.lo)
+        for kw in (dict(transport="p2p", col_chunks=2), dict(transport="halo", col_chunks=2)):
+            opp = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=2, **kw)
+            hp_ = opp.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+            ok = ok and all(torch.equal(a_, b_) for a_, b_ in zip(hs_, hp_))
+        hf_ = ops.propagate(blk, torch.from_numpy(x).to(dv))                             # full X given: ghosts cut out locally
+        ok = ok and all(torch.equal(a_, b_) for a_, b_ in zip(hs_, hf_))
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_end_to_end(cuda, tmp_path):
+    """two processes, both driving cuda:0 with the HIP kernels, exchanging rows through gloo (staged transport):
+    the row-sharded NAFS flow (BASELINE config 4) end to end with a real multi-process group"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
+def _rccl_world1_worker(rank, port, out_dir):
+    import os as _os
+    _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev_ = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev_)
+    try:
+        ok = True
+        # the calls the multi-GPU paths make, with the argument shapes they use, on the real RCCL backend
+        x = torch.arange(12, dtype=torch.float32, device=dev_).view(3, 4)
+        out = torch.empty_like(x)
+        side = torch.cuda.Stream(device=dev_)
+        side.wait_stream(torch.cuda.current_stream(dev_))
+        with torch.cuda.stream(side):
+            w = dist.all_to_all([out[0:3]], [x[0:3]], async_op=True)         # views of row ranges, async, side stream
+            w.wait()
+            w2 = dist.all_to_all([out[1:2]], [x[2:3]], async_op=True)
+        w2.wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(out[0], x[0]) and torch.equal(out[1], x[2])
+        # the grouped point-to-point batch of the row-sharded exchange (transports._post): row-range views, peer = a rank of
+        # the group (here the rank itself -- the only peer a 1-GPU box offers)
+        got = torch.zeros((5, 4), dtype=torch.float32, device=dev_)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, x[1:3], 0), dist.P2POp(dist.irecv, got[2:4], 0)]):
+            w.wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(got[2:4], x[1:3]) and float(got[0].abs().sum()) == 0.0
+        gathered = torch.empty((3, 4), dtype=torch.float32, device=dev_)
+        dist.all_gather_into_tensor(gathered, x, async_op=True).wait()
+        flag = torch.tensor([1], dtype=torch.int32, device=dev_)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev_)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        objs = [None]
+        dist.all_gather_object(objs, {"w": 25})
+        dist.barrier()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(gathered, x) and int(flag) == 1 and float(t) == 1.5 and objs[0] == {"w": 25}
+        open(_os.path.join(out_dir, "ok.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_accepts_the_calls_the_layouts_make(cuda, tmp_path):
+    """one RCCL rank on the one GPU: all_to_all on lists of row-range views issued asynchronously from a side stream,
+    the grouped isend / irecv batch of the row-sharded exchange, all_gather_into_tensor, the agreement all-reduces, all_gather_object, barrier -- the exact call shapes of
+    sgl_amd/dist/ and bench.py, accepted by the real backend (multi-rank behaviour is covered under gloo)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_rccl_world1_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "ok.txt").read() == "ok"
+
+
+def _partition_worker(rank, world, port, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle as orc
+    from inputs import hash_matrix as hm
+    from sgl_amd import device as dev
+    from sgl_amd.dist import HaloPlan, ShardedGraphOp, balanced_bounds
+    from sgl_amd.io import DeviceAdjacency
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    torch.cuda.set_device(0)
+    dv = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n, bs = 6000, 150
+        adj0 = _planted_communities(n, bs, 14, 0.9, seed=11)
+        shuffle = np.random.default_rng(3).permutation(n)
+        P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
+        adj = (P @ adj0 @ P.T).tocsr()
+        adj.sort_indices()
+        x = hm(n, 36, seed=4)
+        ref = LaplacianGraphOp(3, r=0.5).propagate(adj, x)
+        op = ShardedGraphOp(3, r=0.5, partition="community", col_chunks=2)
+        hops = op.propagate(adj, x)
+        ids = op.node_ids
+        ok = op.partition_info["applied"] is True and ids.numel() == op.hi - op.lo and len(hops) == 4
+        for h in range(4):
+            ok = ok and orc.parity_ok(hops[h].cpu().numpy(), ref[h][ids].cpu().numpy(), 1e-5)
+        full = op.gather_full(hops[3].contiguous(), original_order=True)
+        ok = ok and orc.parity_ok(full.cpu().numpy(), ref[3].cpu().numpy(), 1e-5)
+        # what the partition buys: ghosts of this rank against the cut of the ids as they come
+        da = DeviceAdjacency.from_scipy(adj, device=dv)
+        rp, cc, vv = dev.normalize_adj(da.rowptr, da.col, da.val, n, 0.5, None)
+        rp_h = rp.cpu().numpy()
+        b0 = balanced_bounds(rp_h, world)
+        base = HaloPlan.offline(rank, b0, n, lambda q: cc[int(rp_h[b0[q]]):int(rp_h[b0[q + 1]])])
+        flags = [bool(ok)]
+        ok = ok and op.halo_plan.n_ghost < 0.85 * base.n_ghost      # (2 ranks, 10 % far edges: ~75 %; 50 % at 8 ranks, r03_partition_locality.log)
+        flags.append(bool(ok))
+        # storage ALREADY row-sharded (RowBlock input, own feature rows only): the normalised matrix is assembled once for the plan,
+        # the relabelled blocks and what they return are the same
+        from sgl_amd.dist import scatter_row_blocks
+        from sgl_amd.operators.utils import canonical_csr
+        raw = canonical_csr(adj)
+        bnd = balanced_bounds(raw.indptr.astype(np.int64) + np.arange(n + 1), world)
+        whole = tuple(torch.from_numpy(np.ascontiguousarray(a_, dtype=t_)).to(dv) for a_, t_ in
+                      ((raw.indptr, np.int64), (raw.indices, np.int32), (raw.data, np.float32))) if rank == 0 else None
+        blk = scatter_row_blocks(whole, bnd, n, dv)
+        opb = ShardedGraphOp(3, r=0.5, partition="community", col_chunks=2)
+        hb = opb.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+        ok = ok and torch.equal(opb.node_ids, ids) and all(torch.equal(a_, b_) for a_, b_ in zip(hb, hops))
+        flags.append(bool(ok))
+        # "auto" keeps the ids when there is nothing to gain (the same graph in its natural order)
+        adj0c = adj0.tocsr()
+        adj0c.sort_indices()
+        opa = ShardedGraphOp(2, r=0.5, partition="auto", col_chunks=1)
+        ha = opa.propagate(adj0c, x)
+        refa = LaplacianGraphOp(2, r=0.5).propagate(adj0c, x)
+        ok = ok and opa.partition_info["applied"] is False and torch.equal(opa.node_ids.cpu(), torch.arange(opa.lo, opa.hi))
+        ok = ok and all(torch.equal(ha[h], refa[h][opa.lo:opa.hi]) for h in range(3))     # not relabelled: bit-identical
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write(
+            f"ok {op.halo_plan.n_ghost} {base.n_ghost}" if ok else f"mismatch {flags} {op.halo_plan.n_ghost} {base.n_ghost} {opa.partition_info}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_community_aware_partition_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """ShardedGraphOp(partition="community"): the problem is relabelled in the plan-time community order before it is cut into row
+    blocks, so a block references mostly its own rows -- the need-aware exchange receives less than half the rows the plain cut
+    needs on a planted-community graph with shuffled ids -- the hop shards carry their original node ids, gather_full undoes the
+    relabelling, values agree with the single-GPU operator to 1e-5; "auto" leaves a graph alone whose ids already follow its
+    communities (and is then bit-identical)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_partition_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [open(tmp_path / f"rank{r}.txt").read() for r in range(2)]
+    assert all(o.startswith("ok") for o in outs), outs
+    with pytest.raises(ValueError):
+        from sgl_amd.dist import ShardedGraphOp
+        ShardedGraphOp(2, partition="community", strict_order=True).propagate(_planted_communities(300, 30, 6, 0.9, seed=1), hash_matrix(300, 8, seed=1))
+
+
+def _grid_rank_worker(rank, world, port, out_dir):
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _sys.path.insert(0, _os.path.join(root, "tests", "golden"))
+    import torch.distributed as dist
+    import oracle as orc
+    from inputs import hash_matrix as hm
+    from sgl_amd.dist import ShardedGraphOp
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = dict(np.load(_os.path.join(root, "tests", "golden", "graphs.npz")))
+        adj = sp.csr_matrix((g["pl2000|data"], g["pl2000|indices"], g["pl2000|indptr"]), shape=(2000, 2000))
+        x = hm(2000, 50, seed=23)
+        ref = orc.propagate(orc.laplacian_adj(adj.indptr, adj.indices, adj.data, 2000, 0.5), x, 3)
+        ok = True
+        for transport in (None, "staged"):                    # relayed over all 4 ranks / direct inside the pair
+            op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport=transport)
+            hops = op.propagate(adj, x)
+            ok = ok and op.c1 - op.c0 in (32, 18) and 0 < op.hi - op.lo < 2000
+            for h in range(4):
+                ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
+            full = op.gather_full(hops[3])
+            ok = ok and np.array_equal(full.cpu().numpy(), ref[3])
+            nafs_g = op.gather_full(op.over_smooth_aggregate(hops))
+            ok = ok and orc.parity_ok(nafs_g.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
+        # the RCCL variant issues both relay phases from a side stream; RCCL refuses several ranks on one device, so
+        # run that code path with the transfers themselves staged through the host
+        import sgl_amd.dist.transports as sdist
+        orig = sdist._post
+        sdist._post = lambda group, sends, recvs, staged=False: orig(group, sends, recvs, True)
+        op = ShardedGraphOp(3, r=0.5, strict_order=True, pieces=3, row_groups=2, transport="relay")
+        hops = op.propagate(adj, x)
+        ok = ok and op._prop._transport._side is not None            # the side-stream branch really ran
+        for h in range(4):
+            ok = ok and np.array_equal(hops[h].cpu().numpy(), ref[h][op.lo:op.hi, op.c0:op.c1])
+        open(_os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_ranks_on_one_gpu_grid_layout(cuda, tmp_path):
+    """2 row blocks x 2 column slices with four processes driving cuda:0: the pair exchange relayed through the
+    other pair (two-phase, host-staged here because gloo cannot move device memory) and the direct variant"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_grid_rank_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(4)] == ["ok"] * 4
+
+
+def test_python_examples_run_end_to_end(cuda):
+    """the Python examples as a user would start them (small sizes): quick-start SGC, GAMLP label reuse, row-sharded NAFS flow"""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for script, extra, expect in (("sgc_synthetic.py", ["--nodes", "4000", "--feat", "64", "--epochs", "5"], "test acc"),
+                                  ("nafs_row_sharded.py", ["--nodes", "200000", "--hops", "3", "--feat", "64"], "NAFS row-sharded x1")):
+        r = subprocess.run([_sys.executable, os.path.join(root, "examples", script), *extra], capture_output=True, text=True, timeout=600,
+                           env=env)
+        assert r.returncode == 0 and expect in r.stdout, (script, r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("launcher", ["python", "torchrun"])
+def test_bench_cli_prints_exactly_one_json_line(cuda, launcher):
+    """the driver's contract: `python bench.py ...` (and the same under torch.distributed.run with one rank) writes ONE
+    line to stdout -- the JSON -- whatever the libraries print; the small workload keeps it to seconds"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29653"]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "S1_small"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(j["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and j["cpu_baseline"]["value"] > 0
+    # the single-GPU line validates what its own timed steps left behind
+    v = j["config"]["validation"]
+    assert j["config"]["validated"] is True and v["sampled_rows"] > 0 and v["sampled_rows_fp64_ok"] is True
+    assert v["strict_vs_fast_max_row_rel_l2"] <= 1e-5
+
+
+def _bench_worker(rank, world, port, out_dir, extra=(), halo=True):
+    import json as _json
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+
+    class OneGpuGlooEngine(bench.GpuEngine):
+        """both ranks on cuda:0; gloo cannot move device memory, so the process-group transport is the host-staged one"""
+        backend = "gloo"
+        transports = ("staged",)
+        relay_transport = "relay_staged"
+        probe_links = False                   # the link micro-benchmark moves device tensors through the process group
+        halo_collective = False               # gloo has no all_to_all_single
+
+        def init_kwargs(self):
+            return {}
+
+    if not halo:
+        OneGpuGlooEngine.block_halo = None    # keep the need-aware exchange out of the candidates (the push test)
+    tiny = {"T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3)}
+    args = bench.parse_args(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "T_small", "--no-cpu-baseline",
+                             *extra])
+    lines = []
+    bench.run(args, engine_cls=OneGpuGlooEngine, workloads=tiny, emit=lines.append)
+    with open(_os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        _json.dump(lines, f)
+
+
+def test_bench_need_aware_exchange_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """bench.py's DEFAULT N>1 path with REAL HIP kernels and two processes: the contract layout (rows) with the fixed need-aware
+    exchange (compact tables, pack kernel, packed ghost ranges; host-staged here) and 3 column chunks -- no timing race anywhere --
+    validated by exact bit-checksums + sampled rows, and the per-hop breakdown is in the line.  Then the opt-in selection
+    (--exchange auto): whichever candidate wins must be a valid one; WHICH one wins is not asserted."""
+    import torch.multiprocessing as mp
+    for extra in ((), ("--exchange", "halo", "--col-chunks", "1"), ("--exchange", "auto", "--col-chunks", "2")):
+        port = _free_port()
+        mp.spawn(_bench_worker, args=(2, port, str(tmp_path), extra), nprocs=2, join=True)
+        j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
+        plan = j["config"]["plan"]
+        assert j["n_gpus"] == 2 and j["value"] > 0 and plan["layout"] == "rows" and plan["alternatives"] == {}
+        assert "layout_rejected" not in plan and "adjacency_replicated_for" not in plan and "halo_rejected" not in plan
+        assert j["config"]["validated"] is True
+        if "auto" in extra:
+            assert set(plan["exchange_candidates_ms"]) == {"staged", "halo"} and plan["exchange"] in plan["exchange_candidates_ms"]
+        else:
+            assert plan["exchange"] == "halo" and "exchange_candidates_ms" not in plan and "col_chunks_candidates_ms" not in plan
+            assert plan["col_chunks"] == ([[0, 32], [32, 64], [64, 100]] if not extra else [[0, 100]])
+        if plan["exchange"] == "halo":
+            h = plan["halo"]
+            assert h["compact_rows"] == h["own_rows"] + h["ghost_rows"] and 0 < h["ghost_rows"] <= 20_000 - h["own_rows"]
+            assert plan["rows"]["exchange_skipped_fraction"] == h["exchange_skipped_fraction_mean"]
+            dg = j["config"]["diagnostics"]
+            assert dg["pack_only_ms_per_hop_max_rank"] > 0
+            ph = dg["per_hop"]
+            assert ph["spmm_ms"] > 0 and ph["pack_ms"] > 0 and 0.0 <= ph["overlap_fraction"] <= 1.0
+            assert ph["model"]["measured_ms_per_step"] == j["ms_per_step"] and ph["model"]["predicted_ms_per_step_at_measured_rates"] > 0
+
+
+def _papers_worker(rank, world, port, out_dir, exchange="staged"):
+    import json as _json
+    import os as _os
+    import sys as _sys
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import bench
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        engine = bench.GpuEngine(0)
+        args = bench.parse_args(["--gpus", str(world), "--pieces", "2", "--col-chunks", "2"])
+        wl = dict(n=300_000, d=128, k=3, hashed=True, mean_deg=20.0, d_max=3000)
+        out = bench.papers_section(args, engine, rank, world, exchange, wl=wl)
+        with open(_os.path.join(out_dir, f"papers{rank}.json"), "w") as f:
+            _json.dump(out, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_papers_section_with_two_ranks_on_one_gpu(cuda, tmp_path):
+    """the papers100M-shaped section of bench.py (hashed row blocks generated per rank, in-place hops, column chunks pipelined
+    across hops, bit-checksum + sampled-row validation) with two real processes and the HIP kernels, at a small size"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_papers_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [json.load(open(tmp_path / f"papers{r}.json")) for r in range(2)]
+    for o in outs:
+        assert o["validated"] is True and o["n_gpus"] == 2 and o["value"] > 0 and o["nnz"] > 5_000_000
+        assert "2 column chunks pipelined" in o["parallelism"] and o["roofline"]["frac"] > 0
+    assert outs[0]["nnz"] == outs[1]["nnz"]
+    # the same section with the need-aware exchange: own feature rows only, ghosts fetched, compact tables
+    port = _free_port()
+    mp.spawn(_papers_worker, args=(2, port, str(tmp_path), "halo"), nprocs=2, join=True)
+    halo = [json.load(open(tmp_path / f"papers{r}.json")) for r in range(2)]
+    for o, full in zip(halo, outs):
+        assert o["validated"] is True and o["nnz"] == full["nnz"] and o["value"] > 0
+        assert "need-aware all-gather (halo)" in o["parallelism"] and o["halo"]["ghost_rows"] < 300_000 - o["halo"]["own_rows"]
+
+
+def test_bench_push_transport_and_feature_sharded_layout_on_request(cuda, tmp_path):
+    """opt-in paths of bench.py's N>1 job with REAL HIP kernels and two processes, each FORCED by its flag (nothing here depends on
+    which candidate is faster): --exchange push maps the peer replicas (HIP IPC), must reproduce the process-group result of a
+    whole k-hop step before it may run, then runs; --layout cols runs the communication-free feature-sharded layout, validated
+    against the single-GPU chain on a gathered replica"""
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path), ("--exchange", "push", "--col-chunks", "2"), False), nprocs=2, join=True)
+    lines = json.load(open(tmp_path / "rank0.json"))
+    assert len(lines) == 1 and json.load(open(tmp_path / "rank1.json")) == []
+    j = json.loads(lines[0])
+    plan = j["config"]["plan"]
+    assert j["n_gpus"] == 2 and j["value"] > 0 and plan["layout"] == "rows" and j["config"]["validated"] is True
+    # either the fused transport validated and ran, or the line says why the process-group transport ran instead
+    assert (plan["exchange"] == "push" and plan["push_validated_against"] == "staged") or \
+           (plan["exchange"] == "staged" and plan["push_rejected"] in ("mapping failed", "result mismatch")), plan
+    assert "full_step_candidates_ms" not in plan and "exchange_candidates_ms" not in plan
+    mp.spawn(_bench_worker, args=(2, _free_port(), str(tmp_path), ("--layout", "cols"), False), nprocs=2, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
+    plan = j["config"]["plan"]
+    assert plan["layout"] == "cols" and list(plan["layout_candidates_ms"]) == ["cols"] and "layout_rejected" not in plan
+    assert j["config"]["parallelism"].startswith("feature-sharded x2") and j["value"] > 0
+
+
+def test_bench_grid_layout_with_four_ranks_on_one_gpu(cuda, tmp_path):
+    """bench.py --layout grid with real kernels: 2 x 2 grid, relayed exchange, validated against the single-GPU chain"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(4, port, str(tmp_path), ("--layout", "grid")), nprocs=4, join=True)
+    j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
+    assert j["n_gpus"] == 4 and j["value"] > 0 and j["config"]["plan"]["layout"] == "grid"
+    assert "layout_rejected" not in j["config"]["plan"]
