@@ -13,6 +13,8 @@ Fixture families:
   g3_agg.npz   every MessageOp.aggregate output (+ parameter / input gradients for learnable ops)
   g4_models.npz  SGC / GAMLP / NAFS / ... preprocess + model_forward outputs with saved params
   g5_errors.json the exception contract of propagate / aggregate
+  g6 / g7 / g8   consumers of the SpMM (label propagation, C&S, NAFS task), ingest, hop-range quirks
+  g9_config5.npz BASELINE config 5 at its own hop count: PPR / Laplacian k = 10, every MessageOp over H = 11 hops (d = 16, 128)
 Dense inputs are regenerated from tests/golden/inputs.py (integer hash), not stored.
 """
 import importlib.util
@@ -483,6 +485,105 @@ def gen_g8():
     np.savez_compressed(os.path.join(HERE, "g8_ranges.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+# G9: BASELINE config 5 (PaSca op sweep: Laplacian + PPR, k = 10, all MessageOps -- search/search_models.py:19-46) at ITS hop
+#     count: k = 10 propagation of both graph ops, and every MessageOp over H = 11 hop matrices (jk's parameter shape depends on
+#     K: learnable_weighted_messahe_op.py:56-57), d = 16 and d = 128
+# ------------------------------------------------------------------------------------------
+G9_PROP = [
+    # key, graph, kind, r, alpha, d, K, hops stored
+    ("ppr0.1_k10_pl256", "pl256", "ppr", 0.5, 0.1, 16, 10, (1, 2, 5, 10)),
+    ("ppr0.2_k10_pl256", "pl256", "ppr", 0.5, 0.2, 16, 10, (1, 2, 5, 10)),
+    ("ppr0.3_k10_pl256", "pl256", "ppr", 0.5, 0.3, 16, 10, (1, 2, 5, 10)),
+    ("ppr0.15_k1_pl256", "pl256", "ppr", 0.5, 0.15, 16, 1, (1,)),
+    ("ppr0.2_k10_d128_pl256", "pl256", "ppr", 0.5, 0.2, 128, 10, (10,)),
+    ("ppr0.1_k10_pl2000", "pl2000", "ppr", 0.5, 0.1, 8, 10, (10,)),
+    ("ppr0.2_k10_pl2000", "pl2000", "ppr", 0.5, 0.2, 8, 10, (10,)),
+    ("ppr0.3_k10_pl2000", "pl2000", "ppr", 0.5, 0.3, 8, 10, (10,)),
+    ("lap_k10_pl2000", "pl2000", "lap", 0.5, None, 8, 10, (10,)),
+    ("ppr0.2_k10_dir40", "dir40", "ppr", 0.3, 0.2, 5, 10, (1, 10)),
+]
+G9_AGG = {16: 64, 128: 16}          # feat_dim -> rows
+G9_K = 10
+G9_DFEAT = (0, 5, 10)               # input gradients stored in full for these hops; fp64 sums for all
+
+
+def g9_feats(d, requires_grad=False):
+    n = G9_AGG[d]
+    feats = [torch.from_numpy(hash_matrix(n, d, seed=300 + h).copy()) for h in range(G9_K + 1)]
+    feats = [(feats[0] * (1.0 - 0.08 * h) + feats[h] * (0.08 * h)).contiguous() for h in range(G9_K + 1)]
+    if requires_grad:
+        feats = [f.clone().requires_grad_(True) for f in feats]
+    return feats
+
+
+def gen_g9():
+    out, meta = {}, {"prop": {}, "agg": {"dims": {str(d): n for d, n in G9_AGG.items()}, "K": G9_K, "dfeat_stored": list(G9_DFEAT)}}
+    for key, gname, kind, r, a, d, K, keep in G9_PROP:
+        g = GRAPHS[gname]
+        seed = 900 + len(key) + d
+        x = hash_matrix(g.shape[0], d, seed=seed)
+        op = LaplacianGraphOp(K, r=r) if kind == "lap" else PprGraphOp(K, r=r, alpha=a)
+        feats = op.propagate(g, x)
+        assert len(feats) == K + 1
+        for h in keep:
+            out[f"prop|{key}|h{h}"] = feats[h].numpy().copy()
+        out[f"prop|{key}|sums"] = np.array([f.numpy().astype(np.float64).sum() for f in feats])
+        meta["prop"][key] = dict(graph=gname, kind=kind, r=r, alpha=a, d=d, K=K, keep=list(keep), seed=seed)
+    H = G9_K + 1
+    import_models()                                    # ProjectedConcatMessageOp needs sgl.models.simple_models
+    for d, n in G9_AGG.items():
+        P = f"agg|d{d}|"
+        feats = g9_feats(d)
+        for j, f in enumerate(feats):
+            out[P + f"feat{j}"] = f.numpy().copy()
+        out[P + "last"] = LastMessageOp().aggregate(feats).numpy().copy()
+        for (s, e) in ((0, H), (1, H - 1)):
+            tag = f"{s}_{e}"
+            out[P + f"concat|{tag}"] = ConcatMessageOp(s, e).aggregate(feats).numpy().copy()
+            out[P + f"mean|{tag}"] = MeanMessageOp(s, e).aggregate(feats).numpy().copy()
+            out[P + f"sum|{tag}"] = SumMessageOp(s, e).aggregate(feats).numpy().copy()
+            out[P + f"max|{tag}"] = MaxMessageOp(s, e).aggregate(feats).numpy().copy()
+            out[P + f"min|{tag}"] = MinMessageOp(s, e).aggregate(feats).numpy().copy()
+        for (s, e) in ((0, H), (1, H)):
+            out[P + f"simple_weighted|alpha0.85|{s}_{e}"] = SimpleWeightedMessageOp(s, e, "alpha", 0.85).aggregate(feats).numpy().copy()
+        out[P + "over_smooth"] = OverSmoothDistanceWeightedOp().aggregate(feats).numpy().copy()
+        gout = torch.from_numpy(hash_matrix(n, d, seed=778).copy())
+
+        def record(tag, op):
+            fg = g9_feats(d, requires_grad=True)
+            y = op.aggregate(fg)
+            (y * gout).sum().backward()
+            out[tag + "|out"] = y.detach().numpy().copy()
+            for k, v in state_arrays(op).items():
+                out[tag + "|param|" + k] = v
+            for k, p_ in op.named_parameters():
+                out[tag + "|grad|" + k] = p_.grad.numpy().copy()
+            grads = [(f.grad if f.grad is not None else torch.zeros_like(f)).numpy() for f in fg]
+            for j in G9_DFEAT:
+                out[tag + f"|dfeat{j}"] = grads[j].copy()
+            out[tag + "|dfeat_sums"] = np.array([gr.astype(np.float64).sum() for gr in grads])
+            out[tag + "|dfeat_abs_sums"] = np.array([np.abs(gr.astype(np.float64)).sum() for gr in grads])
+
+        for kind, args in (("simple", (G9_K,)), ("simple_allow_neg", (G9_K,)), ("gate", (d,)), ("ori_ref", (d,)), ("jk", (G9_K, d))):
+            for (s, e) in ((0, H), (1, H)):
+                torch.manual_seed(4321 + len(kind) + s + d)
+                record(P + f"learnable|{kind}|{s}_{e}", LearnableWeightedMessageOp(s, e, kind, *args))
+        torch.manual_seed(98 + d)
+        record(P + f"iterate|0_{H}", IterateLearnableWeightedMessageOp(0, H, "recursive", d))
+        torch.manual_seed(6 + d)
+        pc = ProjectedConcatMessageOp(0, H, d, 8, 2)
+        pc.eval()
+        with torch.no_grad():
+            y = pc.aggregate(g9_feats(d))
+        out[P + f"proj_concat|0_{H}|out"] = y.numpy().copy()
+        for k, v in state_arrays(pc).items():
+            out[P + f"proj_concat|0_{H}|param|" + k] = v
+    np.savez_compressed(os.path.join(HERE, "g9_config5.npz"), **out)
+    with open(os.path.join(HERE, "g9_config5.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one family without touching the others
         globals()["gen_" + sys.argv[2]]()
@@ -499,6 +600,7 @@ def main():
     gen_g6()
     gen_g7()
     gen_g8()
+    gen_g9()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

@@ -1398,6 +1398,105 @@ def test_iterate_and_projected_concat(goldens, cuda):
     assert rep["ok"], rep
 
 
+# ---- BASELINE config 5 at its own hop count (G9: PPR / Laplacian k = 10; every MessageOp over H = 11 hop matrices) ----------------
+def test_config5_ppr_and_laplacian_k10_match_reference_goldens(goldens, cuda):
+    """PprGraphOp(10, r, alpha in {.1, .2, .3}) and LaplacianGraphOp(10) (search_models.py:19-46, ppr_graph_op.py:13-21) against
+    hops recorded from the reference: strict order bit-for-bit from raw A, the default order within the SURVEY 8(c) tolerance;
+    the fused propagate_reduce path (last / mean over all 11 hops) on top of the same propagation"""
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    from sgl_amd.operators.message_op import LastMessageOp, MeanMessageOp
+    g9 = goldens.npz("g9_config5")
+    meta = goldens.json("g9_config5")["prop"]
+    n_exact = n_total = n_ppr10 = 0
+    for key, m in meta.items():
+        g = goldens.graph(m["graph"])
+        x = hash_matrix(g.shape[0], m["d"], seed=m["seed"])
+        norm = oracle.sym_norm_csr(g.indptr, g.indices, g.data, g.shape[0], m["r"], m["alpha"])
+        scales = oracle.propagate((norm[0], norm[1], np.abs(norm[2])), np.abs(x), m["K"])
+        n_ppr10 += m["kind"] == "ppr" and m["K"] == 10
+        for strict in (True, False):
+            mk = (lambda: LaplacianGraphOp(m["K"], r=m["r"], strict_order=strict)) if m["kind"] == "lap" else \
+                 (lambda: PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"], strict_order=strict))
+            hops = mk().propagate(g, x)
+            assert len(hops) == m["K"] + 1
+            for h in m["keep"]:
+                rep = oracle.parity_report(hops[h].cpu().numpy(), g9[f"prop|{key}|h{h}"], TOL, scale=scales[h])
+                assert rep["ok"], (key, strict, h, rep)
+                if strict:
+                    n_total += 1
+                    n_exact += rep["bit_equal"]
+            sums = np.array([f.double().sum().item() for f in hops])
+            assert np.allclose(sums, g9[f"prop|{key}|sums"], rtol=1e-4, atol=1e-3), key
+            if strict and m["K"] == 10:
+                last = mk().propagate_reduce(g, x, **LastMessageOp().fused_spec(11))
+                assert torch.equal(last, hops[10])
+                mean = mk().propagate_reduce(g, x, **MeanMessageOp(0, 11).fused_spec(11))
+                assert torch.equal(mean, MeanMessageOp(0, 11).aggregate(hops))
+    assert n_ppr10 >= 7 and n_exact == n_total
+    print(f"config 5 propagation: {n_exact}/{n_total} golden hop matrices (PPR / Laplacian, k = 10) reproduced bit-for-bit")
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_config5_every_message_op_over_eleven_hops(goldens, cuda, d):
+    """every op of sgl/operators/message_op/ over H = 11 hop matrices (k = 10) against reference-generated goldens: stateless ops
+    bit-exact, weighted / NAFS within tolerance, the five learnable kinds (jk: Linear(d + 11 d, 1), learnable_weighted_messahe_op.py:
+    56-57) + the iterate op with parameter and input gradients, projected concat"""
+    from sgl_amd.operators import message_op as mo
+    g9 = goldens.npz("g9_config5")
+    P, H = f"agg|d{d}|", 11
+    n = goldens.json("g9_config5")["agg"]["dims"][str(d)]
+
+    def feats(requires_grad=False):
+        fs = [torch.from_numpy(g9[P + f"feat{j}"]).to(cuda) for j in range(H)]
+        return [f.clone().requires_grad_(True) for f in fs] if requires_grad else fs
+
+    fs = feats()
+    assert np.array_equal(mo.LastMessageOp().aggregate(fs).cpu().numpy(), g9[P + "last"])
+    for (s, e) in ((0, H), (1, H - 1)):
+        for name, cls in (("concat", mo.ConcatMessageOp), ("mean", mo.MeanMessageOp), ("sum", mo.SumMessageOp),
+                          ("max", mo.MaxMessageOp), ("min", mo.MinMessageOp)):
+            assert np.array_equal(cls(s, e).aggregate(fs).cpu().numpy(), g9[P + f"{name}|{s}_{e}"]), (name, s, e)
+    for (s, e) in ((0, H), (1, H)):
+        y = mo.SimpleWeightedMessageOp(s, e, "alpha", 0.85).aggregate(fs).cpu().numpy()
+        assert oracle.parity_ok(y, g9[P + f"simple_weighted|alpha0.85|{s}_{e}"], 1e-6)
+    rep = oracle.parity_report(mo.OverSmoothDistanceWeightedOp().aggregate(fs).cpu().numpy(), g9[P + "over_smooth"], TOL)
+    assert rep["ok"], rep
+    gout = torch.from_numpy(hash_matrix(n, d, seed=778)).to(cuda)
+    stored = goldens.json("g9_config5")["agg"]["dfeat_stored"]
+
+    def check_learnable(tag, op):
+        op.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(v) for k, v in g9.items() if k.startswith(tag + "|param|")})
+        op = op.to(cuda)
+        fg = feats(requires_grad=True)
+        y = op.aggregate(fg)
+        rep = oracle.parity_report(y.detach().cpu().numpy(), g9[tag + "|out"], TOL)
+        assert rep["ok"], (tag, rep)
+        (y * gout).sum().backward()
+        for name, p in op.named_parameters():
+            gref = g9[tag + "|grad|" + name].reshape(1, -1)
+            rep = oracle.parity_report(p.grad.cpu().numpy().reshape(1, -1), gref, 2e-3 if gref.size == 1 else 1e-4, rowwise=False)
+            assert rep["ok"], (tag, name, rep)
+        grads = [(f.grad if f.grad is not None else torch.zeros_like(f)).cpu().numpy() for f in fg]
+        for j in stored:
+            rep = oracle.parity_report(grads[j], g9[tag + f"|dfeat{j}"], 1e-4, rowwise=False)
+            assert rep["ok"], (tag, j, rep)
+        sums = np.array([gr.astype(np.float64).sum() for gr in grads])
+        assert np.allclose(sums, g9[tag + "|dfeat_sums"], rtol=0, atol=2e-4 * np.maximum(g9[tag + "|dfeat_abs_sums"], 1e-6)), tag
+
+    for kind, args in (("simple", (10,)), ("simple_allow_neg", (10,)), ("gate", (d,)), ("ori_ref", (d,)), ("jk", (10, d))):
+        for (s, e) in ((0, H), (1, H)):
+            check_learnable(P + f"learnable|{kind}|{s}_{e}", mo.LearnableWeightedMessageOp(s, e, kind, *args))
+    check_learnable(P + f"iterate|0_{H}", mo.IterateLearnableWeightedMessageOp(0, H, "recursive", d))
+    tag = P + f"proj_concat|0_{H}"
+    pc = mo.ProjectedConcatMessageOp(0, H, d, 8, 2)
+    pc.load_state_dict({k[len(tag) + 7:]: torch.from_numpy(v) for k, v in g9.items() if k.startswith(tag + "|param|")})
+    pc = pc.to(cuda).eval()
+    with torch.no_grad():
+        y = pc.aggregate(feats())
+    rep = oracle.parity_report(y.cpu().numpy(), g9[tag + "|out"], 1e-4)
+    assert rep["ok"], rep
+
+
 def test_gather_rows(cuda):
     from sgl_amd.device import alloc_rows, gather_rows
     for d in (100, 147, 3, 500):

@@ -201,3 +201,57 @@ def test_hop_range_quirks_match_reference(goldens):
         for a_, s_ in ((0.85, 0), (0.3, 1)):
             got = oracle.agg_simple_weighted(hops, s_, 5, "alpha", a_)
             assert oracle.parity_ok(got, g8[f"prop|{name}|simple_weighted|alpha{a_}|{s_}_5"], 1e-6)
+
+
+# ---- G9: BASELINE config 5 at its own hop count (PPR / Laplacian k = 10; every MessageOp over H = 11 hops) ---------------------
+def test_g9_ppr_and_laplacian_k10_bit_exact(goldens):
+    g9 = goldens.npz("g9_config5")
+    meta = goldens.json("g9_config5")["prop"]
+    assert sum(1 for m in meta.values() if m["kind"] == "ppr" and m["K"] == 10) >= 7
+    for key, m in meta.items():
+        g = goldens.graph(m["graph"])
+        n = g.shape[0]
+        x = hash_matrix(n, m["d"], seed=m["seed"])
+        norm = oracle.sym_norm_csr(g.indptr, g.indices, g.data, n, m["r"], m["alpha"])
+        feats = oracle.propagate(norm, x, m["K"])
+        for h in m["keep"]:
+            assert np.array_equal(feats[h], g9[f"prop|{key}|h{h}"]), f"{key} hop {h} not bit-equal to reference"
+        sums = np.array([f.astype(np.float64).sum() for f in feats])
+        assert np.array_equal(sums, g9[f"prop|{key}|sums"]), key
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_g9_every_message_op_over_eleven_hops(goldens, d):
+    g9 = goldens.npz("g9_config5")
+    P, H = f"agg|d{d}|", 11
+    feats = [g9[P + f"feat{j}"] for j in range(H)]
+    assert np.array_equal(oracle.agg_last(feats), g9[P + "last"])
+    for (s, e) in ((0, H), (1, H - 1)):
+        tag = f"{s}_{e}"
+        assert np.array_equal(oracle.agg_concat(feats, s, e), g9[P + f"concat|{tag}"])
+        assert np.array_equal(oracle.agg_sum(feats, s, e), g9[P + f"sum|{tag}"])
+        assert np.array_equal(oracle.agg_mean(feats, s, e), g9[P + f"mean|{tag}"])
+        assert np.array_equal(oracle.agg_max(feats, s, e), g9[P + f"max|{tag}"])
+        assert np.array_equal(oracle.agg_min(feats, s, e), g9[P + f"min|{tag}"])
+    for (s, e) in ((0, H), (1, H)):
+        y = oracle.agg_simple_weighted(feats, s, e, "alpha", 0.85)
+        assert oracle.parity_ok(y, g9[P + f"simple_weighted|alpha0.85|{s}_{e}"], 1e-6)
+    assert oracle.parity_ok(oracle.agg_over_smooth_distance(feats), g9[P + "over_smooth"], 1e-6)
+    for kind in ("simple", "simple_allow_neg", "gate", "ori_ref", "jk"):
+        for (s, e) in ((0, H), (1, H)):
+            tag = P + f"learnable|{kind}|{s}_{e}"
+            if kind in ("simple", "simple_allow_neg"):
+                p = g9[tag + "|param|_LearnableWeightedMessageOp__learnable_weight"]
+                assert p.shape == (H,)
+                y = oracle.agg_learnable_weighted(feats, s, e, kind, param=p)
+            else:
+                w = g9[tag + "|param|_LearnableWeightedMessageOp__learnable_weight.weight"]
+                b = g9[tag + "|param|_LearnableWeightedMessageOp__learnable_weight.bias"]
+                assert w.shape == (1, {"gate": d, "ori_ref": 2 * d, "jk": (H + 1) * d}[kind])      # jk: Linear(d + (K+1) d, 1)
+                y = oracle.agg_learnable_weighted(feats, s, e, kind, weight=w, bias=b)
+            rep = oracle.parity_report(y, g9[tag + "|out"], 1e-5)
+            assert rep["ok"], (tag, rep)
+    w = g9[P + f"iterate|0_{H}|param|_IterateLearnableWeightedMessageOp__learnable_weight.weight"]
+    b = g9[P + f"iterate|0_{H}|param|_IterateLearnableWeightedMessageOp__learnable_weight.bias"]
+    rep = oracle.parity_report(oracle.agg_iterate_learnable(feats, 0, H, w, b), g9[P + f"iterate|0_{H}|out"], 1e-5)
+    assert rep["ok"], rep
