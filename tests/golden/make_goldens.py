@@ -14,6 +14,7 @@ Fixture families:
   g4_models.npz  SGC / GAMLP / NAFS / ... preprocess + model_forward outputs with saved params
   g5_errors.json the exception contract of propagate / aggregate
   g6 / g7 / g8   consumers of the SpMM (label propagation, C&S, NAFS task), ingest, hop-range quirks
+  g10_label_reuse.npz BASELINE config 3: the label use / reuse loop around preprocess, through the reference's task code
   g9_config5.npz BASELINE config 5 at its own hop count: PPR / Laplacian k = 10, every MessageOp over H = 11 hops (d = 16, 128)
 Dense inputs are regenerated from tests/golden/inputs.py (integer hash), not stored.
 """
@@ -584,6 +585,99 @@ def gen_g9():
         json.dump(meta, f, indent=1)
 
 
+# ------------------------------------------------------------------------------------------
+# G10: BASELINE config 3 -- the label use / label reuse loop around model.preprocess (GAMLP, d + C = 147 columns, K = 5), run
+#      through the REFERENCE'S OWN task code (tasks/node_classification_with_label_use.py:58-137) with training and evaluation
+#      stubbed out (they are dense-head work, outside SURVEY section 8) and ONE adaptation without which the reference loop cannot
+#      run on Linux at all: its add_labels (tasks/utils.py:33-36) returns float64 and csr_sparse_dense_matmul's ctypes signature
+#      accepts float32 only (operators/utils.py:16-26) -> ArgumentError on the first preprocess.  The adaptation casts to float32.
+# ------------------------------------------------------------------------------------------
+def gen_g10():
+    mods = import_models()
+    pkg = types.ModuleType("sgl.tasks")
+    pkg.__path__ = [REF + "/sgl/tasks"]
+    sys.modules.setdefault("sgl.tasks", pkg)
+    for m in ["matplotlib", "matplotlib.pyplot", "munkres"]:
+        try:
+            importlib.import_module(m)
+        except ImportError:
+            sys.modules[m] = MagicMock()
+    import sgl.tasks.node_classification_with_label_use as lu
+    orig_add = lu.add_labels
+    lu.add_labels = lambda f, y, idx, C: orig_add(f, y, idx, C).astype(np.float32)
+    lu.train = lambda *a, **k: (0.0, 0.0)
+    lu.evaluate = lambda *a, **k: (0.0, 0.0)
+    lu.accuracy = lambda *a, **k: 0.0
+
+    g = GRAPHS["pl2000"]
+    n, d, C, K = g.shape[0], 100, 47, 5
+    rng = np.random.default_rng(77)
+    perm = rng.permutation(n)
+    labels = torch.from_numpy((rng.integers(0, C, n)).astype(np.int64))
+
+    class Data:
+        num_node = n
+
+    class DS:
+        x = hash_matrix(n, d, seed=1010)
+        y = labels
+        adj = g
+        num_node = n
+        num_classes = C
+        data = Data
+        train_idx = perm[: int(0.3 * n)].tolist()
+        val_idx = perm[int(0.3 * n): int(0.5 * n)].tolist()
+        test_idx = perm[int(0.5 * n):].tolist()
+
+    torch.manual_seed(11)
+    model = mods["gamlp"].GAMLP(K, d + C, C, 64, 2)
+    model.eval()                      # the state label reuse runs in: the previous epoch's evaluate() left the model in eval mode
+    out = {"n": n, "d": d, "C": C, "K": K, "train_idx": np.asarray(DS.train_idx), "val_idx": np.asarray(DS.val_idx),
+           "test_idx": np.asarray(DS.test_idx), "labels": labels.numpy()}
+    for k, v in state_arrays(model).items():
+        out["param|" + k] = v
+    sub = np.arange(0, n, 20)
+    out["sub_rows"] = sub
+    calls = []
+    real_pre = model.preprocess
+
+    def spy(adj, features):
+        assert features.dtype == np.float32 and features.shape == (n, d + C)
+        i = len(calls)
+        out[f"call{i}|label_cols_sub"] = features[sub, d:].copy()
+        out[f"call{i}|feature_colsum"] = features.astype(np.float64).sum(0)
+        real_pre(adj, features)
+        out[f"call{i}|hop_sums"] = np.array([f.numpy().astype(np.float64).sum() for f in model._processed_feat_list])
+        calls.append(i)
+    model.preprocess = spy
+    masks = []
+    real_add = lu.add_labels
+
+    def spy_add(f, y, idx, C_):
+        masks.append(np.asarray(idx).copy())
+        return real_add(f, y, idx, C_)
+    lu.add_labels = spy_add
+
+    task = object.__new__(lu.NodeClassificationWithLabelUse)
+    P = "_NodeClassificationWithLabelUse__"
+    for k, v in dict(dataset=DS, labels=labels, model=model, optimizer=None, epochs=3, loss_fn=None, device=torch.device("cpu"),
+                     seed=42, mask_rate=0.5, use_labels=True, reuse_start_epoch=0, label_iters=2, label_reuse_batch_size=700,
+                     mini_batch=False).items():
+        setattr(task, P + k, v)
+    task._execute()
+    assert len(calls) == 3 + 2 * 2 and len(masks) == 3
+    for e, mk in enumerate(masks):
+        out[f"epoch{e}|train_labels_idx"] = mk
+    hops = model._processed_feat_list
+    for h in (1, 3, 5):
+        out[f"final|hop{h}_sub"] = hops[h].numpy()[sub].copy()
+    with torch.no_grad():
+        logits = model.model_forward(range(n), torch.device("cpu"))
+    out["final|logits_sub"] = logits.numpy()[sub].copy()
+    out["final|logits_colsum"] = logits.numpy().astype(np.float64).sum(0)
+    np.savez_compressed(os.path.join(HERE, "g10_label_reuse.npz"), **out)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # regenerate one family without touching the others
         globals()["gen_" + sys.argv[2]]()
@@ -601,6 +695,7 @@ def main():
     gen_g7()
     gen_g8()
     gen_g9()
+    gen_g10()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

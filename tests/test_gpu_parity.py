@@ -1562,6 +1562,64 @@ def test_models_match_reference_goldens(goldens, cuda):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_label_reuse_loop_matches_reference_task(goldens, cuda):
+    """BASELINE config 3's loop (tasks/node_classification_with_label_use.py:58-137: label use every epoch, label reuse from epoch 1
+    on, `preprocess` re-run after every write-back) on the device -- sgl_amd.tricks.add_labels / label_reuse, GAMLP with the
+    reference's saved parameters, d + C = 147 columns, K = 5 -- against G10, which the reference's own task code recorded: after
+    EVERY preprocess call the label columns (sampled rows), the column sums of the feature matrix and the fp64 sums of all six hop
+    matrices; at the end hop 1 / 3 / 5 rows and the logits.  Nothing leaves the GPU inside the loop."""
+    from sgl_amd.models.homo import GAMLP
+    from sgl_amd.tricks import add_labels, label_reuse
+    g10 = goldens.npz("g10_label_reuse")
+    n, d, C, K = (int(g10[k]) for k in ("n", "d", "C", "K"))
+    g = goldens.graph("pl2000")
+    x = torch.from_numpy(hash_matrix(n, d, seed=1010)).to(cuda)
+    labels = torch.from_numpy(g10["labels"]).to(cuda)
+    sub = torch.from_numpy(g10["sub_rows"]).to(cuda)
+    model = GAMLP(K, d + C, C, 64, 2)
+    model.load_state_dict({k[len("param|"):]: torch.from_numpy(v) for k, v in g10.items() if k.startswith("param|")})
+    model = model.to(cuda).eval()
+    train = set(g10["train_idx"].tolist())
+    calls = []
+    real_pre = model.preprocess
+
+    def spy(adj, features):
+        i = len(calls)
+        assert features.is_cuda and features.dtype == torch.float32          # the loop never went through the host
+        got_cols = features[sub, d:].cpu().numpy()
+        rep = oracle.parity_report(got_cols, g10[f"call{i}|label_cols_sub"], 1e-4, rowwise=False)
+        assert rep["ok"], ("label columns before preprocess call", i, rep)
+        cs = features.double().sum(0).cpu().numpy()
+        assert np.allclose(cs, g10[f"call{i}|feature_colsum"], rtol=1e-4, atol=1e-2), i
+        real_pre(adj, features)
+        sums = np.array([h.double().sum().item() for h in model._processed_feat_list])
+        assert len(sums) == K + 1 and np.allclose(sums, g10[f"call{i}|hop_sums"], rtol=1e-4, atol=1e-2), (i, sums, g10[f"call{i}|hop_sums"])
+        calls.append(i)
+    model.preprocess = spy
+    feats = None
+    for epoch in range(3):
+        lab_idx = g10[f"epoch{epoch}|train_labels_idx"]
+        feats = add_labels(x, labels, torch.from_numpy(lab_idx), C, out=feats, device=cuda)
+        model.preprocess(g, feats)
+        if epoch > 0:
+            train_pred = np.array(sorted(train - set(lab_idx.tolist())))
+            # the reference's order: train nodes whose labels are hidden this epoch, then validation, then test nodes
+            mask = np.isin(g10["train_idx"], lab_idx)
+            unlabeled = np.concatenate([g10["train_idx"][~mask], g10["val_idx"], g10["test_idx"]])
+            assert set(unlabeled[: (~mask).sum()].tolist()) == set(train_pred.tolist())
+            label_reuse(model, g, feats, unlabeled, C, 2, device=cuda, batch_size=700)
+    assert len(calls) == 7
+    hops = model._processed_feat_list
+    for h in (1, 3, 5):
+        rep = oracle.parity_report(hops[h][sub].cpu().numpy(), g10[f"final|hop{h}_sub"], 5e-5)
+        assert rep["ok"], (h, rep)
+    with torch.no_grad():
+        logits = model.model_forward(range(n), cuda)
+    rep = oracle.parity_report(logits[sub].cpu().numpy(), g10["final|logits_sub"], 1e-4, rowwise=False)
+    assert rep["ok"], rep
+    assert np.allclose(logits.double().sum(0).cpu().numpy(), g10["final|logits_colsum"], rtol=1e-3, atol=1e-2)
+
+
 def test_spmm_axpb_clamp_epilogue(cuda):
     """fused Y = clamp(alpha * A X + RES): regular rows in the main kernel, split rows in the fix-up kernel"""
     a = long_row_graph()

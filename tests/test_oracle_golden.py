@@ -255,3 +255,24 @@ def test_g9_every_message_op_over_eleven_hops(goldens, d):
     b = g9[P + f"iterate|0_{H}|param|_IterateLearnableWeightedMessageOp__learnable_weight.bias"]
     rep = oracle.parity_report(oracle.agg_iterate_learnable(feats, 0, H, w, b), g9[P + f"iterate|0_{H}|out"], 1e-5)
     assert rep["ok"], rep
+
+
+def test_g10_label_use_features_and_their_propagation(goldens):
+    """G10 (BASELINE config 3, recorded through the reference's own task loop): the epochs' fresh [x || one-hot] matrices
+    (tasks/utils.py:33-36) and their K = 5 pre-propagation are pure path work -- the oracle reproduces the recorded column sums
+    and hop sums exactly; the label-reuse iterations in between involve the dense head and are checked on the GPU."""
+    g10 = goldens.npz("g10_label_reuse")
+    n, d, C, K = (int(g10[k]) for k in ("n", "d", "C", "K"))
+    g = goldens.graph("pl2000")
+    norm = oracle.laplacian_adj(g.indptr, g.indices, g.data, n, 0.5)
+    x = hash_matrix(n, d, seed=1010)
+    labels, sub = g10["labels"], g10["sub_rows"]
+    for epoch, call in ((0, 0), (1, 1), (2, 4)):
+        idx = g10[f"epoch{epoch}|train_labels_idx"]
+        onehot = np.zeros((n, C), dtype=np.float32)
+        onehot[idx, labels[idx]] = 1
+        f = np.concatenate([x, onehot], axis=1)
+        assert np.array_equal(f[sub, d:], g10[f"call{call}|label_cols_sub"])
+        assert np.array_equal(f.astype(np.float64).sum(0), g10[f"call{call}|feature_colsum"])
+        hops = oracle.propagate(norm, f, K)
+        assert np.array_equal(np.array([h.astype(np.float64).sum() for h in hops]), g10[f"call{call}|hop_sums"]), call

@@ -391,6 +391,8 @@ def test_python_examples_run_end_to_end(cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for script, extra, expect in (("sgc_synthetic.py", ["--nodes", "4000", "--feat", "64", "--epochs", "5"], "test acc"),
+                                  ("gamlp_label_reuse_synthetic.py", ["--workload", "S1_small", "--epochs", "2", "--label-iters", "1",
+                                                                      "--prop-steps", "3"], "label use + reuse per epoch"),
                                   ("nafs_row_sharded.py", ["--nodes", "200000", "--hops", "3", "--feat", "64"], "NAFS row-sharded x1")):
         r = subprocess.run([_sys.executable, os.path.join(root, "examples", script), *extra], capture_output=True, text=True, timeout=600,
                            env=env)
