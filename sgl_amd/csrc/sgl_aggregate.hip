@@ -336,6 +336,24 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
 // (v_permlane32_swap exchanges; 8 waves, but 0.57 / 0.48 vs 0.67 / 0.62) -- profiles/r03_aggregators_{online_gate,hop_split}_experiment.log.
 #define ROWREG_MIN_BLOCKS(HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((HMAX) * (CH) <= 16) ? 4 : 2))
 
+// ---- lanes x chunks of a register-resident row kernel ------------------------------------------------------------------------
+// A row of d floats is ceil(d / 4) 16-byte slots; LPR lanes take CH slots each (slot (c * LPR + l) of the row for lane l, chunk c),
+// 64 / LPR rows per wavefront.  Power-of-two groups leave slots idle when the row is not a power of two wide, and idle slots still
+// cost their share of every load and VALU instruction: d = 147 (BASELINE config 3: 100 features + 47 label columns = 37 slots) on
+// 32 lanes x 2 chunks idles 27 of 64.  Narrow groups with more chunks per lane fit such rows far better -- 8 lanes x 5 chunks
+// (40 slots, 8 rows per wavefront, every load instruction of a lane group is one whole 128-byte line) or 16 x 3 (48 slots) -- at
+// the price of CH x HMAX hop vectors in registers, so they are instantiated for few hops only (<= 6 / <= 12) and chosen when they
+// at least halve the idle slots.  Measured at d = 147 (profiles/r04_aggregators_layouts.log): 16 x 3 is as fast as 32 x 2 at 6 hops
+// and 12-15 % faster at 11 (row-dot 0.597 -> 0.661 of peak, gate 0.539 -> 0.613, NAFS 0.536 -> 0.612); 8 x 5 (151 VGPRs, 3 waves
+// per SIMD) pays only in the jk-score kernel (0.585 -> 0.657 at 6 hops) and is instantiated for that kernel alone.  At 6 hops the
+// gate / NAFS kernels are NOT issue-bound -- halving their VALU instructions and quartering their wavefronts changed nothing
+// (profiles/r04_agg_pmc.md) -- what they lost against the plain sum was the partly written last line of the output row
+// (store_row above).
+struct RowLayout {
+    int lpr, ch;
+};
+
+
 // ---- per-row scalars, one hop per lane -------------------------------------------------------------------------------------
 // After the row reductions every lane of a row's group holds all H per-hop scalars.  Evaluating sigmoid / softmax / the IEEE
 // divisions hop after hop costs H instruction sequences per WAVEFRONT (every lane repeats them): ~1 050 VALU instructions at
@@ -370,12 +388,41 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Output row of a register-resident row kernel.  dw = the columns the kernel writes: exactly d, or -- when the tail of the row's
+// pitch is padding (out_cols() below) -- the whole pitch, pad columns as zeros.  Why: a row of d = 147 floats on a
+// 160-float pitch ends 52 bytes short of its last 128-byte line, and a line that is only partly written costs a read-modify-write in
+// the ECC-protected HBM: the output write of the gate / NAFS kernels ran at 2.7 TB/s at d = 147 against 5.8 TB/s at d = 160
+// (profiles/r04_aggregators.log; the element-wise kernels always streamed whole pitches).
+template <int LPR, int CH>
+__device__ __forceinline__ void store_row(float *__restrict__ orow, const f4 (&acc)[CH], const int l, const bool live, const int d,
+                                          const int dw) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 4;
+        if (live && col < dw) {
+            f4 v = acc[c];
+            if (col + 4 <= dw) {                    // whole vector; what lies beyond d is padding the kernel owns: zeros
+                if (col + 4 > d) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e >= d) v[e] = 0.f;
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(orow + col));
+            } else {                                // dw == d, the vector straddles it: never write past the caller's d columns
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < dw) orow[col + e] = v[e];
+            }
+        }
+    }
+}
+
 // Fused NAFS: one pass over the H hop rows held in registers -> cosine scores -> softmax -> weighted sum.
 // LPR lanes per row, CH float4 chunks per lane (d <= LPR*4*CH), H <= HMAX.  Same arithmetic as the two-pass path.
 template <int LPR, int CH, int HMAX>
 __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
                                                          const int64_t ldo, float *__restrict__ wout, const int64_t ldw,
-                                                         const int64_t n, const int d) {
+                                                         const int64_t n, const int d, const int dw) {
     constexpr int RPB = 256 / LPR;
     const int l = threadIdx.x % LPR;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -477,18 +524,7 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_k
                     for (int e = 0; e < 4; ++e) acc[c][e] = __fadd_rn(acc[c][e], __fmul_rn(w, x[h][c][e]));
             }
     }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-        if (on[c]) {
-            const int col = (c * LPR + l) * 4;
-            if (col + 4 <= d) {
-                __builtin_nontemporal_store(acc[c], reinterpret_cast<f4 *>(out + r * ldo + col));
-            } else {  // the vector straddling column d: never write past the caller's d columns
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < d) out[r * ldo + col + e] = acc[c][e];
-            }
-        }
+    store_row<LPR, CH>(out + r * ldo, acc, l, live, d, dw);
 }
 
 // Fused learnable gate (LearnableWeightedMessageOp 'gate', learnable_weighted_messahe_op.py:67-71 + two_dim_weighted_add): one
@@ -501,7 +537,7 @@ template <int LPR, int CH, int HMAX>
 __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
                                                          const float bias, float *__restrict__ out, const int64_t ldo,
                                                          float *__restrict__ wout, const int64_t ldw, float *__restrict__ gout,
-                                                         const int64_t ldg, const int64_t n, const int d) {
+                                                         const int64_t ldg, const int64_t n, const int d, const int dw) {
     constexpr int RPB = 256 / LPR;
     const int l = threadIdx.x % LPR;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -600,18 +636,7 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_k
                     for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
             }
     }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-        if (on[c]) {
-            const int col = (c * LPR + l) * 4;
-            if (col + 4 <= d) {
-                __builtin_nontemporal_store(acc[c], reinterpret_cast<f4 *>(out + r * ldo + col));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < d) out[r * ldo + col + e] = acc[c][e];
-            }
-        }
+    store_row<LPR, CH>(out + r * ldo, acc, l, live, d, dw);
 }
 
 // Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in ONE pass over the hop list:
@@ -626,6 +651,16 @@ __global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, con
                                                               float *__restrict__ p, const int64_t ldp, float *__restrict__ a,
                                                               const int64_t n, const int d) {
     constexpr int RPB = 256 / LPR;
+    constexpr int SLOTS = LPR * CH;                 // 16-byte slots of a row this layout reaches
+    // U is the same for every row: staged in LDS once per block (H x SLOTS vectors, a few KB) instead of H x CH global loads per
+    // lane -- those doubled the kernel's L1 accesses and made it the slowest of the row kernels (jk scores at d = 147: 0.48 of
+    // peak against 0.69 for the plain row-dot; profiles/r04_agg_pmc.md: TCP_TOTAL_CACHE_ACCESSES 3.8e8 against 1.9e8)
+    __shared__ f4 us[HMAX][SLOTS];
+    for (int i = threadIdx.x; i < HMAX * SLOTS; i += 256) {
+        const int h = i / SLOTS, col = (i - h * SLOTS) * 4;
+        us[h][i - h * SLOTS] = (h < n_hops && ((u_mask >> h) & 1ull) && col < d) ? load_masked<4>(u + (int64_t)h * ldu, col, d)
+                                                                                  : (f4){0.f, 0.f, 0.f, 0.f};
+    }
     const int l = threadIdx.x % LPR;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = row < n;
@@ -640,6 +675,7 @@ __global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, con
         for (int h = 0; h < HMAX; ++h)
             x[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
     }
+    __syncthreads();
     float acc[HMAX];
     float shared = 0.f;
 #pragma unroll
@@ -652,12 +688,9 @@ __global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, con
         if (h < n_hops && ((u_mask >> h) & 1ull)) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int col = (c * LPR + l) * 4;
-                if (col < d) {
-                    const f4 uv = load_masked<4>(u + (int64_t)h * ldu, col, d);
+                const f4 uv = us[h][c * LPR + l];   // zeros beyond d
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) shared = __builtin_fmaf(uv[e], x[h][c][e], shared);
-                }
+                for (int e = 0; e < 4; ++e) shared = __builtin_fmaf(uv[e], x[h][c][e], shared);
             }
         }
     }
@@ -744,18 +777,24 @@ constexpr int kConcatTile = 1024;
 constexpr int kConcatRows = 8;     // rows per block: R independent 16-byte loads in flight per thread (a block with one is latency-bound)
 __global__ __launch_bounds__(256) void hop_concat_lds_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
                                                              const int64_t ldo, const int64_t n, const int d,
-                                                             const int tiles_per_row) {
+                                                             const int tiles_per_row, const int width_w) {
     __shared__ float tile[kConcatRows][kConcatTile];
-    const int width = d * n_hops;
+    const int width = d * n_hops;                   // width_w >= width: the columns written (pad columns of the pitch as zeros,
+                                                    // see out_cols(): a partly written last line costs a read-modify-write)
     const int64_t rb = blockIdx.x / tiles_per_row;                      // row block
     const int o0 = (int)(blockIdx.x - rb * tiles_per_row) * kConcatTile;
-    const int o1 = min(o0 + kConcatTile, width);
+    const int o1 = max(min(o0 + kConcatTile, width), o0);
+    const int o1w = min(o0 + kConcatTile, width_w);
     const int64_t row0 = rb * kConcatRows;
     const int rows = (int)min<int64_t>(kConcatRows, n - row0);
     // segments of the tile: hop h covers output floats [max(o0, h d), min(o1, (h+1) d))
-    const int h0 = o0 / d, h1 = (o1 - 1) / d;
+    const int h0 = o0 / d, h1 = (o1 > o0) ? (o1 - 1) / d : h0 - 1;
     int done = 0;                                   // aligned source vectors of the previous segments
     const int t = threadIdx.x;
+    for (int j = o1 - o0 + t; j < o1w - o0; j += 256) {                  // the pad columns of this tile: zeros
+#pragma unroll
+        for (int r = 0; r < kConcatRows; ++r) tile[r][j] = 0.f;
+    }
     for (int h = h0; h <= h1; ++h) {
         const int k0 = max(o0 - h * d, 0), k1 = min(o1 - h * d, d);       // source floats [k0, k1) of hop h
         const int a0 = k0 & ~3;
@@ -783,12 +822,12 @@ __global__ __launch_bounds__(256) void hop_concat_lds_kernel(const Hops hx, cons
     for (int r = 0; r < kConcatRows; ++r) {
         if (r >= rows) break;
         float *orow = out + (row0 + r) * ldo + o0;
-        if (o0 + c + 4 <= o1) {
+        if (o0 + c + 4 <= o1w) {
             *reinterpret_cast<f4 *>(orow + c) = *reinterpret_cast<const f4 *>(&tile[r][c]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (o0 + c + e < o1) orow[c + e] = tile[r][c + e];
+                if (o0 + c + e < o1w) orow[c + e] = tile[r][c + e];
         }
     }
 }
@@ -799,17 +838,21 @@ __global__ __launch_bounds__(256) void hop_concat_lds_kernel(const Hops hx, cons
 // accesses only need dword alignment) or, at the boundaries, element by element.
 
 __global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
-                                                             const int64_t ldo, const int64_t n, const int d) {
+                                                             const int64_t ldo, const int64_t n, const int d, const int width_w) {
     // d >= 4.  One thread per aligned 16-byte vector of the output row.  Its floats sit at a dword-aligned position of
     // ONE source row, except in the vector that straddles a hop boundary (H per row, i.e. in nearly every wavefront:
     // that path must stay cheap -- no divisions, no element-wise recomputation of the hop index).
     const int width = d * n_hops;
-    const int vecs = (width + 3) / 4;
+    const int vecs = (width_w + 3) / 4;             // width_w >= width: pad columns of the pitch are written as zeros (out_cols())
     const int64_t total = n * (int64_t)vecs;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t row = i / vecs;
         const int c = (int)(i - row * vecs) * 4;
+        if (c >= width) {                           // a vector of padding
+            *reinterpret_cast<f4 *>(out + row * ldo + c) = (f4){0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         const int h = c / d;
         const int k = c - h * d;
         const int rem = d - k;                      // floats of this vector that belong to hop h (>= 1)
@@ -837,6 +880,11 @@ __global__ __launch_bounds__(256) void hop_concat_any_kernel(const Hops hx, cons
 #pragma unroll
                 for (int e = 1; e < 4; ++e)
                     if (e >= rem) r[e] = nx[e - rem];
+                *reinterpret_cast<f4 *>(op) = r;
+            } else if (c + 4 <= width_w) {          // last vector of the row, its tail is padding: zeros
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (e >= rem) r[e] = 0.f;
                 *reinterpret_cast<f4 *>(op) = r;
             } else {                                // last vector of the row: only the floats inside the row
 #pragma unroll
@@ -984,6 +1032,79 @@ int pick_lpr(int64_t d, int vec) {
     return lpr;
 }
 
+// Columns a row-producing kernel writes into an output of pitch ldo (a multiple of 4 floats): the tail of a pitch that is shorter
+// than one 128-byte line beyond d can only be the row's own padding (sgl_amd.device.alloc_rows, or any caller that pads rows to
+// whole vectors / lines) -- it is written too, as zeros, so that every line of the row is written whole; a wider gap means d_out is
+// a column slice of something larger, and nothing beyond column d is touched.  `room` = the columns the lane layout reaches.
+int out_cols(int64_t d, int64_t ldo, int64_t room) {
+    int64_t dw = (ldo % 4 == 0 && ldo - d < 32 && sgl::tuning("row_whole_lines", 1) != 0) ? ldo : d;
+    if (dw > room) dw = room > d ? room : d;
+    return (int)dw;
+}
+
+RowLayout pick_row_layout(int64_t d, int n_hops, bool allow_8x5 = false) {
+    RowLayout r;
+    r.lpr = pick_lpr(d, 4);
+    r.ch = (d > r.lpr * 4) ? 2 : 1;
+    if (r.lpr == 64 && r.ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0) {   // 2 rows per wavefront
+        r.lpr = 32;
+        r.ch = 2;
+    }
+    if (sgl::tuning("row_narrow_groups", 1) != 0 && d <= r.lpr * 4 * r.ch) {
+        const int slots = (int)((d + 3) / 4);
+        static const int cand[2][3] = {{16, 3, 12}, {8, 5, 6}};       // lanes, chunks, most hops instantiated
+        const int64_t mode = sgl::tuning("row_narrow_groups", 1);       // 1: both candidates, 2: 16 x 3 only, 3: 8 x 5 only (measurements)
+        for (const auto &c : cand) {
+            const int idle = c[0] * c[1] - slots;
+            if (((mode == 2 || !allow_8x5) && c[0] == 8) || (mode == 3 && c[0] == 16)) continue;
+            if (idle >= 0 && n_hops <= c[2] && 2 * idle <= r.lpr * r.ch - slots) {
+                r.lpr = c[0];
+                r.ch = c[1];
+            }
+        }
+    }
+    return r;
+}
+
+// KH(L, C): all even hop counts up to 16; KH12 / KH6: the narrow-group layouts, instantiated up to 12 / 6 hop vectors
+#define SGL_ROWREG_DISPATCH(KH, KH12, KH6, lay)                        \
+    do {                                                               \
+        if ((lay).lpr == 8 && (lay).ch == 5) KH6(8, 5);                \
+        else if ((lay).lpr == 16 && (lay).ch == 3) KH12(16, 3);        \
+        else if ((lay).lpr == 32 && (lay).ch == 2) KH(32, 2);          \
+        else if ((lay).ch == 2) KH(64, 2);                             \
+        else if ((lay).lpr == 8) KH(8, 1);                             \
+        else if ((lay).lpr == 16) KH(16, 1);                           \
+        else if ((lay).lpr == 32) KH(32, 1);                           \
+        else KH(64, 1);                                                \
+    } while (0)
+#define SGL_HOPS_UP_TO_16(K, L, C)                 \
+    do {                                           \
+        if (n_hops <= 2) K(L, C, 2);               \
+        else if (n_hops <= 4) K(L, C, 4);          \
+        else if (n_hops <= 6) K(L, C, 6);          \
+        else if (n_hops <= 8) K(L, C, 8);          \
+        else if (n_hops <= 10) K(L, C, 10);        \
+        else if (n_hops <= 12) K(L, C, 12);        \
+        else if (n_hops <= 14) K(L, C, 14);        \
+        else K(L, C, 16);                          \
+    } while (0)
+#define SGL_HOPS_UP_TO_12(K, L, C)                 \
+    do {                                           \
+        if (n_hops <= 2) K(L, C, 2);               \
+        else if (n_hops <= 4) K(L, C, 4);          \
+        else if (n_hops <= 6) K(L, C, 6);          \
+        else if (n_hops <= 8) K(L, C, 8);          \
+        else if (n_hops <= 10) K(L, C, 10);        \
+        else K(L, C, 12);                          \
+    } while (0)
+#define SGL_HOPS_UP_TO_6(K, L, C)                  \
+    do {                                           \
+        if (n_hops <= 2) K(L, C, 2);               \
+        else if (n_hops <= 4) K(L, C, 4);          \
+        else K(L, C, 6);                           \
+    } while (0)
+
 #define SGL_LAUNCH_CHECK(what)                                                                                  \
     do {                                                                                                        \
         hipError_t _e = hipGetLastError();                                                                      \
@@ -1057,14 +1178,9 @@ static void launch_rowdot(int lpr, int g_unaligned, hipStream_t st, const Hops &
                           const float *g, int64_t ldg, float *dw, int64_t lddw, int64_t n, int d) {
     if constexpr (VEC == 4) {
         // the row's H hop vectors fit in registers: one load of dOut, all loads in flight, interleaved butterflies
-        int ch = (d > lpr * 4) ? 2 : 1;
-        const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;   // 2 rows per wavefront
-        if (two_rows) {
-            lpr = 32;
-            ch = 2;
-        }
-        if (n_hops <= 16 && d <= lpr * 4 * ch) {
-            const unsigned grid = (unsigned)((n + (256 / lpr) - 1) / (256 / lpr));
+        const RowLayout lay = pick_row_layout(d, n_hops);
+        if (n_hops <= 16 && d <= lay.lpr * 4 * lay.ch) {
+            const unsigned grid = (unsigned)((n + (256 / lay.lpr) - 1) / (256 / lay.lpr));
 #define SGL_RR(L, C, HM)                                                                                                        \
     do {                                                                                                                       \
         if (g_unaligned)                                                                                                       \
@@ -1072,23 +1188,12 @@ static void launch_rowdot(int lpr, int g_unaligned, hipStream_t st, const Hops &
         else                                                                                                                   \
             hipLaunchKernelGGL((hop_rowdot_reg_kernel<L, C, HM, false>), dim3(grid), dim3(256), 0, st, hx, n_hops, g, ldg, dw, lddw, n, d); \
     } while (0)
-#define SGL_RR_H(L, C)                                 \
-    do {                                               \
-        if (n_hops <= 2) SGL_RR(L, C, 2);              \
-        else if (n_hops <= 4) SGL_RR(L, C, 4);         \
-        else if (n_hops <= 6) SGL_RR(L, C, 6);         \
-        else if (n_hops <= 8) SGL_RR(L, C, 8);         \
-        else if (n_hops <= 10) SGL_RR(L, C, 10);       \
-        else if (n_hops <= 12) SGL_RR(L, C, 12);       \
-        else if (n_hops <= 14) SGL_RR(L, C, 14);       \
-        else SGL_RR(L, C, 16);                         \
-    } while (0)
-            if (two_rows) SGL_RR_H(32, 2);
-            else if (ch == 2) SGL_RR_H(64, 2);
-            else if (lpr == 8) SGL_RR_H(8, 1);
-            else if (lpr == 16) SGL_RR_H(16, 1);
-            else if (lpr == 32) SGL_RR_H(32, 1);
-            else SGL_RR_H(64, 1);
+#define SGL_RR_H(L, C) SGL_HOPS_UP_TO_16(SGL_RR, L, C)
+#define SGL_RR_H12(L, C) SGL_HOPS_UP_TO_12(SGL_RR, L, C)
+#define SGL_RR_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
+            SGL_ROWREG_DISPATCH(SGL_RR_H, SGL_RR_H12, SGL_RR_H6, lay);
+#undef SGL_RR_H6
+#undef SGL_RR_H12
 #undef SGL_RR_H
 #undef SGL_RR
             return;
@@ -1250,14 +1355,16 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
         const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && sgl::tuning("concat_lds", 1) != 0 &&
-               sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((d * n_hops + kConcatTile - 1) / kConcatTile), 256)) {
+               sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((out_cols(d * n_hops, ldo, INT32_MAX) + kConcatTile - 1) / kConcatTile), 256)) {
         // any d, long rows: assembled in LDS, every source vector read once
-        const int tiles = (int)((d * n_hops + kConcatTile - 1) / kConcatTile);
+        const int width_w = out_cols(d * n_hops, ldo, INT32_MAX);
+        const int tiles = (int)((width_w + kConcatTile - 1) / kConcatTile);
         hipLaunchKernelGGL(hop_concat_lds_kernel, dim3((unsigned)((n + kConcatRows - 1) / kConcatRows * tiles)), dim3(256), 0, st, hx,
-                           n_hops, d_out, ldo, n, (int)d, tiles);
+                           n_hops, d_out, ldo, n, (int)d, tiles, width_w);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops)) {   // any d: aligned 16-byte stores, aligned 16-byte loads + select
-        const int grid = stream_grid(n * ((d * n_hops + 3) / 4));
-        hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+        const int width_w = out_cols(d * n_hops, ldo, INT32_MAX);
+        const int grid = stream_grid(n * (((int64_t)width_w + 3) / 4));
+        hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d, width_w);
     } else {
         const int grid = stream_grid(n * d * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
@@ -1283,28 +1390,16 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     // single-pass kernel: the H hop rows of a node fit in registers (H <= 16, d <= 512, 16-byte lanes)
     const bool out_vec4 = d_out && (ldo % 4 == 0) && aligned_to(d_out, 16);
     if (vec4 && out_vec4 && n_hops <= 16 && d <= 512 && sgl::tuning("nafs_fused", 1) != 0) {
-        const int ch = (d > lpr * 4) ? 2 : 1;
-        const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;   // 2 rows per wavefront
-        const int64_t nblocks = two_rows ? (n + 7) / 8 : blocks;
+        const RowLayout lay = pick_row_layout(d, n_hops);
+        const int64_t nblocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
 #define SGL_NF(L, C, HM) \
-    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d)
-#define SGL_NF_H(L, C)                                 \
-    do {                                               \
-        if (n_hops <= 2) SGL_NF(L, C, 2);              \
-        else if (n_hops <= 4) SGL_NF(L, C, 4);         \
-        else if (n_hops <= 6) SGL_NF(L, C, 6);         \
-        else if (n_hops <= 8) SGL_NF(L, C, 8);         \
-        else if (n_hops <= 10) SGL_NF(L, C, 10);       \
-        else if (n_hops <= 12) SGL_NF(L, C, 12);       \
-        else if (n_hops <= 14) SGL_NF(L, C, 14);       \
-        else SGL_NF(L, C, 16);                         \
-    } while (0)
-        if (two_rows) SGL_NF_H(32, 2);
-        else if (ch == 2) SGL_NF_H(64, 2);
-        else if (lpr == 8) SGL_NF_H(8, 1);
-        else if (lpr == 16) SGL_NF_H(16, 1);
-        else if (lpr == 32) SGL_NF_H(32, 1);
-        else SGL_NF_H(64, 1);
+    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
+#define SGL_NF_H(L, C) SGL_HOPS_UP_TO_16(SGL_NF, L, C)
+#define SGL_NF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_NF, L, C)
+#define SGL_NF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
+        SGL_ROWREG_DISPATCH(SGL_NF_H, SGL_NF_H12, SGL_NF_H6, lay);
+#undef SGL_NF_H6
+#undef SGL_NF_H12
 #undef SGL_NF_H
 #undef SGL_NF
         SGL_LAUNCH_CHECK("sgl_nafs_f32(fused)");
@@ -1394,16 +1489,6 @@ SGL_EXPORT int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_row
 // ---- learnable gates -------------------------------------------------------------------------------------------------------
 // register-resident row kernels: H <= 16, d <= 512, 16-byte aligned rows.  Anything else -> SGL_ERR_UNSUPPORTED and the caller
 // takes the two-pass route (sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32).
-#define SGL_ROWREG_DISPATCH(KERNEL_H, lpr, ch, two_rows) \
-    do {                                                  \
-        if (two_rows) KERNEL_H(32, 2);                    \
-        else if (ch == 2) KERNEL_H(64, 2);                \
-        else if (lpr == 8) KERNEL_H(8, 1);                \
-        else if (lpr == 16) KERNEL_H(16, 1);              \
-        else if (lpr == 32) KERNEL_H(32, 1);              \
-        else KERNEL_H(64, 1);                             \
-    } while (0)
-
 SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
                                 float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
                                 int64_t d, void *stream) {
@@ -1418,25 +1503,17 @@ SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64
     if (!(vec4 && n_hops <= 16 && d <= 512 && ldo % 4 == 0 && aligned_to(d_out, 16)))
         return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: needs <= 16 hops, d <= 512 and 16-byte aligned rows (use the two-pass route)");
     hipStream_t st = sgl::as_stream(stream);
-    const int lpr = pick_lpr(d, 4);
-    const int ch = (d > lpr * 4) ? 2 : 1;
-    const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;
-    const int64_t blocks = two_rows ? (n + 7) / 8 : (n + (256 / lpr) - 1) / (256 / lpr);
+    const RowLayout lay = pick_row_layout(d, n_hops);
+    const int64_t blocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
     if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: too many rows for one launch (shard the matrix)");
 #define SGL_GF(L, C, HM) \
-    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d)
-#define SGL_GF_H(L, C)                                 \
-    do {                                               \
-        if (n_hops <= 2) SGL_GF(L, C, 2);              \
-        else if (n_hops <= 4) SGL_GF(L, C, 4);         \
-        else if (n_hops <= 6) SGL_GF(L, C, 6);         \
-        else if (n_hops <= 8) SGL_GF(L, C, 8);         \
-        else if (n_hops <= 10) SGL_GF(L, C, 10);       \
-        else if (n_hops <= 12) SGL_GF(L, C, 12);       \
-        else if (n_hops <= 14) SGL_GF(L, C, 14);       \
-        else SGL_GF(L, C, 16);                         \
-    } while (0)
-    SGL_ROWREG_DISPATCH(SGL_GF_H, lpr, ch, two_rows);
+    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
+#define SGL_GF_H(L, C) SGL_HOPS_UP_TO_16(SGL_GF, L, C)
+#define SGL_GF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_GF, L, C)
+#define SGL_GF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
+    SGL_ROWREG_DISPATCH(SGL_GF_H, SGL_GF_H12, SGL_GF_H6, lay);
+#undef SGL_GF_H6
+#undef SGL_GF_H12
 #undef SGL_GF_H
 #undef SGL_GF
     SGL_LAUNCH_CHECK("sgl_hop_gate_f32");
@@ -1459,26 +1536,18 @@ SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const in
     if (!(vec4 && n_hops <= 16 && d <= 512 && d > 0))
         return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_rowdot2_f32: needs <= 16 hops, 0 < d <= 512 and 16-byte aligned rows");
     hipStream_t st = sgl::as_stream(stream);
-    const int lpr = pick_lpr(d, 4);
-    const int ch = (d > lpr * 4) ? 2 : 1;
-    const bool two_rows = lpr == 64 && ch == 1 && d > 128 && sgl::tuning("row_lpr32x2", 1) != 0;
-    const int64_t blocks = two_rows ? (n + 7) / 8 : (n + (256 / lpr) - 1) / (256 / lpr);
+    const RowLayout lay = pick_row_layout(d, n_hops, true);
+    const int64_t blocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
     if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_rowdot2_f32: too many rows for one launch (shard the matrix)");
     float *a_out = u_mask ? d_a : nullptr;
 #define SGL_R2(L, C, HM) \
     hipLaunchKernelGGL((hop_rowdot2_reg_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_u, ldu, (unsigned long long)u_mask, d_vec, h0, h1, d_p, ldp, a_out, n, (int)d)
-#define SGL_R2_H(L, C)                                 \
-    do {                                               \
-        if (n_hops <= 2) SGL_R2(L, C, 2);              \
-        else if (n_hops <= 4) SGL_R2(L, C, 4);         \
-        else if (n_hops <= 6) SGL_R2(L, C, 6);         \
-        else if (n_hops <= 8) SGL_R2(L, C, 8);         \
-        else if (n_hops <= 10) SGL_R2(L, C, 10);       \
-        else if (n_hops <= 12) SGL_R2(L, C, 12);       \
-        else if (n_hops <= 14) SGL_R2(L, C, 14);       \
-        else SGL_R2(L, C, 16);                         \
-    } while (0)
-    SGL_ROWREG_DISPATCH(SGL_R2_H, lpr, ch, two_rows);
+#define SGL_R2_H(L, C) SGL_HOPS_UP_TO_16(SGL_R2, L, C)
+#define SGL_R2_H12(L, C) SGL_HOPS_UP_TO_12(SGL_R2, L, C)
+#define SGL_R2_H6(L, C) SGL_HOPS_UP_TO_6(SGL_R2, L, C)
+    SGL_ROWREG_DISPATCH(SGL_R2_H, SGL_R2_H12, SGL_R2_H6, lay);
+#undef SGL_R2_H6
+#undef SGL_R2_H12
 #undef SGL_R2_H
 #undef SGL_R2
     SGL_LAUNCH_CHECK("sgl_hop_rowdot2_f32");

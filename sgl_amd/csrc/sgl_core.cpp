@@ -33,6 +33,9 @@ static std::map<std::string, int64_t> &tune_map() {
         {"agg_blocks", 0},       // 0 = one 16-byte element per thread (grid capped at 2^22 blocks); > 0 caps the grid of the streaming aggregators (grid-stride)
         {"nafs_fused", 1},       // 0 = force the two-pass NAFS path
         {"row_lpr32x2", 1},      // row-wise kernels, 128 < d <= 256: 32 lanes x 2 chunks per row (2 rows per wavefront)
+        {"row_whole_lines", 1},    // gate / NAFS / concat outputs: the pad columns of a row pitch (< one line beyond d) are written as zeros
+        {"row_narrow_groups", 1},  // row-wise kernels: 16 lanes x 3 / 8 lanes x 5 chunks when that at least halves the idle lane slots
+                                   // (0 = off, 1 = both, 2 = 16 x 3 only, 3 = 8 x 5 only)
         {"concat_lds", 1},       // any-width concat of rows >= 256 floats: assemble the output row in LDS (0 = funnel-select kernel)
     };
     return m;

@@ -913,6 +913,7 @@ def gather_rows(x, idx, out=None):
         idx = torch.from_numpy(np.ascontiguousarray(host))
     # device indices are range-checked inside the kernel (it traps on a bad index): no host round trip
     idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
+    own_out = out is None
     if out is None:
         out = alloc_rows(idx.numel(), d, x.device)
     else:
@@ -925,6 +926,11 @@ def gather_rows(x, idx, out=None):
     dp = round_up(d, 4)
     d_copy = dp if (d != dp and n_rows > 1 and idx.numel() > 1 and x.stride(0) % 4 == 0 and x.stride(0) >= dp
                     and out.stride(0) >= dp and out.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0) else d
+    # our own output on the source's pitch: copy whole pitches, pad columns included -- every line of the output is then written
+    # whole (a row of 147 floats on a 160-float pitch would otherwise end in a partly written line: a read-modify-write in HBM)
+    if (own_out and n_rows > 1 and idx.numel() > 1 and out.stride(0) == x.stride(0) and d < x.stride(0) < d + 32
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+        d_copy = x.stride(0)
     with torch.cuda.device(x.device):
         check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d_copy,
                                         current_stream_ptr()), "sgl_gather_rows_f32")

@@ -34,6 +34,10 @@ def main():
     n = int(os.environ.get("AGG_N", 2_449_029))
     if os.environ.get("AGG_LPR32X2"):
         _lib.set_tuning("row_lpr32x2", int(os.environ["AGG_LPR32X2"]))
+    if os.environ.get("AGG_NARROW"):      # row layouts of the register-resident kernels: 0 = power-of-two groups only, 1 = auto, 2 / 3 = one candidate
+        _lib.set_tuning("row_narrow_groups", int(os.environ["AGG_NARROW"]))
+    if os.environ.get("AGG_WHOLE"):       # 0: row outputs end at column d (a partly written last line), 1: pad columns written too
+        _lib.set_tuning("row_whole_lines", int(os.environ["AGG_WHOLE"]))
     if os.environ.get("AGG_BLOCKS"):
         _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)

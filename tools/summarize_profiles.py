@@ -76,13 +76,13 @@ if means:
             table = {table["workload"]: table}
     except Exception:  # noqa: BLE001
         table = {}
-    table[workload] = {"workload": workload, "hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write,
+    table[workload] = dict(table.get(workload, {}), **{"workload": workload, "hbm_bytes_per_launch": hbm, "fetch_size_kb": fetch, "write_size_kb": write,
                        "source": f"profiles/{tag}_{workload}_pmc_spmm_kernel.md", "kernel": kname,
                        "kernel_avg_ms_rocprof": kernel_avg_ms,
-                       "kernel_stats": f"profiles/{tag}_{workload}_kernel_stats.csv"}
+                       "kernel_stats": f"profiles/{tag}_{workload}_kernel_stats.csv"})    # other keys of the entry are kept
     json.dump(table, open(tfile, "w"), indent=1)
 for name in ("sweep.log", "bench.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
-print(sorted(os.listdir(dst)))
+print(f"{tag} {workload}: summaries written to profiles/")
