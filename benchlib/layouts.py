@@ -84,7 +84,7 @@ def _build_grid(job, ref, row_groups):
         ybufs = [torch.empty((prop.hi - prop.lo, xs.shape[1]), dtype=xs.dtype, device=xs.device) for _ in range(K)]
 
         def step():
-            return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs)   # every buffer preallocated: no allocator traffic
+            return prop.propagate(xs, K, x_buffers=bufs, y_buffers=ybufs, hops_in_buffers=job.nbuf >= K - 1)   # every buffer preallocated
         return prop, step
 
     counts = [int(t) for t in str(job.args.grid_pieces).split(",") if t.strip()]

@@ -409,7 +409,7 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
         job.rows_inbound_bytes = float(mx[1]) * job.d * 4
 
         def step():
-            return prop.propagate_chunked(tables, K, buffers=hbufs, y_buffers=ybufs)
+            return prop.propagate_chunked(tables, K, buffers=hbufs, y_buffers=ybufs, hops_in_buffers=job.nbuf >= K - 1)
 
         def check():
             hops = step()
@@ -439,10 +439,10 @@ def _build_rows_for(job, ref, n_chunks, exchange_fixed=None):
             return prop.propagate_push(x_chunks, K)
     elif len(chunks) == 1:
         def step():
-            return [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0], y_buffers=ybufs[0])]
+            return [[t] for t in prop.propagate(x0, K, x_buffers=cbufs[0], y_buffers=ybufs[0], hops_in_buffers=job.nbuf >= K - 1)]
     else:
         def step():
-            return prop.propagate_chunked(x_chunks, K, buffers=cbufs, y_buffers=ybufs)
+            return prop.propagate_chunked(x_chunks, K, buffers=cbufs, y_buffers=ybufs, hops_in_buffers=job.nbuf >= K - 1)
 
     def check():
         hops = step()

@@ -315,6 +315,8 @@ int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, floa
 /* Learnable gate in one pass (LearnableWeightedMessageOp 'gate', message_op/learnable_weighted_messahe_op.py:67-71 followed by
  * two_dim_weighted_add, operators/utils.py:105-116):  G[n,h] = sigmoid(<X_h[n], vec> + bias),  W[n,:] = softmax_h(G[n,:]),
  * out[n] = sum_h W[n,h] X_h[n].  Every hop element is read once.  d_vec: round_up(d, 4) floats, 16-byte aligned, zero beyond d.
+ * bias = NaN means "the bias is on the device": it is read from d_vec[round_up(d, 4)] by the kernel (no host synchronisation,
+ * the launch can be captured in a hipGraph and replayed while the parameter changes).
  * d_w_out / d_g_out (optional, [n, n_hops]) receive W and G (the backward needs both).  Register-resident rows: n_hops <= 16,
  * d <= 512, 16-byte aligned rows -- otherwise SGL_ERR_UNSUPPORTED (callers then use sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32). */
 int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,

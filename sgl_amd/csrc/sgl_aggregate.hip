@@ -535,7 +535,8 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_k
 // backward needs besides the hops).
 template <int LPR, int CH, int HMAX>
 __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
-                                                         const float bias, float *__restrict__ out, const int64_t ldo,
+                                                         const float bias_arg, const float *__restrict__ bias_ptr,
+                                                         float *__restrict__ out, const int64_t ldo,
                                                          float *__restrict__ wout, const int64_t ldw, float *__restrict__ gout,
                                                          const int64_t ldg, const int64_t n, const int d, const int dw) {
     constexpr int RPB = 256 / LPR;
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_k
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = row < n;
     const int64_t r = live ? row : 0;
+    const float bias = bias_ptr ? *bias_ptr : bias_arg;       // a bias that lives on the device is read here: no host round trip
     f4 x[HMAX][CH], vv[CH];
     bool on[CH];
 #pragma unroll
@@ -1506,8 +1508,11 @@ SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64
     const RowLayout lay = pick_row_layout(d, n_hops);
     const int64_t blocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
     if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: too many rows for one launch (shard the matrix)");
+    // bias = NaN: the bias is the float that follows the padded vector on the device (d_vec[round_up(d, 4)]) -- a caller whose
+    // bias is a device tensor (a torch parameter) needs neither a device-to-host synchronisation nor a new value per launch
+    const float *bias_ptr = (bias != bias) ? d_vec + (d + 3) / 4 * 4 : nullptr;
 #define SGL_GF(L, C, HM) \
-    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
+    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, bias_ptr, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
 #define SGL_GF_H(L, C) SGL_HOPS_UP_TO_16(SGL_GF, L, C)
 #define SGL_GF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_GF, L, C)
 #define SGL_GF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */

@@ -728,9 +728,14 @@ def hop_scores(feats, v):
     return _HopScores.apply(v, *feats)
 
 
-def _padded_vec(v, d, device):
-    vp = torch.zeros(round_up(max(d, 1), 4), dtype=torch.float32, device=device)
+def _padded_vec(v, d, device, tail=None):
+    """v zero-padded to whole 16-byte vectors; `tail`: one more float stored right after the padding (the gate's bias: the kernel
+    reads it from there, so a bias that is a device tensor never travels to the host)"""
+    dp = round_up(max(d, 1), 4)
+    vp = torch.zeros(dp + (4 if tail is not None else 0), dtype=torch.float32, device=device)
     vp[:d] = v.detach().to(torch.float32).view(-1)
+    if tail is not None:
+        vp[dp:dp + 1] = tail.detach().to(device=device, dtype=torch.float32).reshape(-1)[:1]
     return vp
 
 
@@ -745,13 +750,13 @@ class _GateFused(torch.autograd.Function):
         n, d = feats_d[0].shape
         H = len(feats_d)
         dev_ = feats_d[0].device
-        vp = _padded_vec(v, d, dev_)
+        vp = _padded_vec(v, d, dev_, tail=b)                  # [v | 0-pad | bias]: bias = NaN below = "read it from the device"
         result = alloc_rows(n, d, dev_)
         w = torch.empty((n, H), dtype=torch.float32, device=dev_)
         g = torch.empty((n, H), dtype=torch.float32, device=dev_)
         ptrs, lds = _lib.hop_arrays(feats_d)
         with torch.cuda.device(dev_):
-            check(lib().sgl_hop_gate_f32(H, ptrs, lds, ptr(vp), float(b.detach().reshape(-1)[0]), ptr(result), _ld(result), ptr(w), H,
+            check(lib().sgl_hop_gate_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), ptr(w), H,
                                          ptr(g), H, n, d, current_stream_ptr()), "sgl_hop_gate_f32")
         ctx.save_for_backward(v.detach(), w, g, *feats_d)
         ctx.b_shape = tuple(b.shape)

@@ -302,13 +302,14 @@ class HaloPropagator:
         return x_full.index_select(0, ids)
 
     # ---- the hop loop ----------------------------------------------------------------------------------------------
-    def propagate_chunked(self, tables, prop_steps, buffers=None, y_buffers=None, in_place=False):
+    def propagate_chunked(self, tables, prop_steps, buffers=None, y_buffers=None, in_place=False, hops_in_buffers=False):
         """tables: list of C compact tables [n_compact, w_c] (the column chunks of hop 0).  Software-pipelined like
         ShardedPropagator.propagate_chunked: while chunk c's rows travel, chunk c+1 is multiplied, and hop h+1 of chunk c
         waits only for chunk c's own exchange.  Returns hops[h][c] = LOCAL shard [n_own, w_c]; with in_place only the last
         hop is retained (earlier entries are views the hop after next overwrites).  `buffers[c]`: the caller's tables for the
-        exchanged hops; with prop_steps - 1 (or more) of them per chunk, hops 1..K-1 are views of their own rows (valid until
-        the caller reuses the tables) and nothing is copied."""
+        exchanged hops.  hops_in_buffers (opt-in, needs prop_steps - 1 or more tables per chunk): hops 1..K-1 are returned as
+        VIEWS of the own rows of those tables -- valid until the caller reuses the tables -- and nothing is copied; without the
+        flag the returned hops are separate matrices whatever buffers are passed."""
         C = len(tables)
         n_own = self.plan.n_own
         hops = [[t[:n_own] for t in tables]]
@@ -317,7 +318,8 @@ class HaloPropagator:
         # the CALLER's tables, one per exchanged hop: nothing is overwritten inside a step, so the hop matrices can simply BE the
         # own rows of those tables (no copy into the table, no separate output); with fewer (ping-pong) tables or our own
         # temporaries the hops are separate matrices, as before
-        keep_in_tables = buffers is not None and all(len(b) >= prop_steps - 1 for b in buffers)
+        from .propagator import ShardedPropagator
+        keep_in_tables = ShardedPropagator._hops_in_buffers(hops_in_buffers, buffers, prop_steps)
         if buffers is None:
             buffers = [[torch.empty_like(t) for _ in range(min(2, max(prop_steps - 1, 0)))] for t in tables]
         cur = list(tables)
@@ -351,9 +353,9 @@ class HaloPropagator:
             hops.append(outs)
         return hops
 
-    def propagate(self, table, prop_steps, buffers=None, y_buffers=None, in_place=False):
+    def propagate(self, table, prop_steps, buffers=None, y_buffers=None, in_place=False, hops_in_buffers=False):
         hops = self.propagate_chunked([table], prop_steps, None if buffers is None else [buffers],
-                                      None if y_buffers is None else [y_buffers], in_place)
+                                      None if y_buffers is None else [y_buffers], in_place, hops_in_buffers)
         return [h[0] for h in hops]
 
     def _exchanging(self):

@@ -72,12 +72,21 @@ class ShardedPropagator:
         """does a hop need an exchange?"""
         return self._transport.exchanging()
 
+    @staticmethod
+    def _hops_in_buffers(flag, buffers, prop_steps):
+        """the explicit aliasing request (see propagate_chunked) checked against the buffers it needs"""
+        if not flag:
+            return False
+        if buffers is None or not all(len(b) >= prop_steps - 1 for b in buffers):
+            raise ValueError("hops_in_buffers=True needs prop_steps - 1 caller-owned buffers per chunk (one per exchanged hop)")
+        return True
+
     def _aux_stream(self, device):
         if getattr(self, "_aux", None) is None:
             self._aux = torch.cuda.Stream(device=device)
         return self._aux
 
-    def propagate(self, x_full, prop_steps, x_buffers=None, y_buffers=None, in_place=False):
+    def propagate(self, x_full, prop_steps, x_buffers=None, y_buffers=None, in_place=False, hops_in_buffers=False):
         """x_full: [N, d] replica of the input features on this rank's device (row-major, contiguous).
         Returns the list of K+1 LOCAL hop shards [hi-lo, d] (hop 0 is a view of x_full).
         in_place: hops 1..K-1 are written straight into this rank's rows of the next replica (no separate shard, no
@@ -91,7 +100,7 @@ class ShardedPropagator:
         hops = [x_full[self.lo:self.hi]]
         if prop_steps == 0:
             return hops
-        keep_in_replicas = x_buffers is not None and len(x_buffers) >= prop_steps - 1     # see propagate_chunked
+        keep_in_replicas = self._hops_in_buffers(hops_in_buffers, None if x_buffers is None else [x_buffers], prop_steps)
         if x_buffers is None:
             x_buffers = [torch.empty_like(x_full) for _ in range(min(2, max(prop_steps - 1, 0)))]
         cur = x_full
@@ -306,7 +315,7 @@ class ShardedPropagator:
             hops.append(outs)
         return hops
 
-    def propagate_chunked(self, x_chunks, prop_steps, buffers=None, y_buffers=None, in_place=False):
+    def propagate_chunked(self, x_chunks, prop_steps, buffers=None, y_buffers=None, in_place=False, hops_in_buffers=False):
         """Software-pipelined variant: the feature block is held as C column chunks (separate contiguous [N, w_c]
         matrices, see column_chunks()).  SpMM is separable over columns, so while chunk c's new rows are in flight
         to the peers, chunk c+1 is being multiplied, and hop h+1 of chunk c only waits for chunk c's own exchange:
@@ -319,8 +328,11 @@ class ShardedPropagator:
         x_chunks: list of C replicas [N, w_c]; returns hops[h][c] = LOCAL shard [hi-lo, w_c].
         y_buffers[c][h-1]: optional preallocated outputs (see propagate).
         in_place: as in propagate() -- hops 1..K-1 are produced directly in this rank's rows of the next replica (views that
-        the hop after next overwrites); only the last hop is retained.  With prop_steps - 1 (or more) caller-owned `buffers` per
-        chunk nothing is overwritten inside a step: the hops are those views and nothing is copied."""
+        the hop after next overwrites); only the last hop is retained.
+        hops_in_buffers: OPT-IN aliasing for callers that own one buffer per exchanged hop (prop_steps - 1 or more per chunk):
+        nothing is overwritten inside a step, so hops 1..K-1 are returned as VIEWS of this rank's rows of those buffers and
+        nothing is copied -- they stay valid only until the caller reuses the buffers (e.g. calls this again with them).
+        Without the flag the returned hops are separate matrices whatever buffers are passed."""
         C = len(x_chunks)
         n = x_chunks[0].shape[0]
         assert n == self.n and self.pieces >= 1
@@ -328,7 +340,7 @@ class ShardedPropagator:
         if prop_steps == 0:
             return hops
         # (the caller's replicas, one per exchanged hop: the hop shards can simply be this rank's rows of them -- no copy)
-        keep_in_replicas = buffers is not None and all(len(b) >= prop_steps - 1 for b in buffers)
+        keep_in_replicas = self._hops_in_buffers(hops_in_buffers, buffers, prop_steps)
         if buffers is None:
             buffers = [[torch.empty_like(x) for _ in range(min(2, max(prop_steps - 1, 0)))] for x in x_chunks]
         cur = list(x_chunks)

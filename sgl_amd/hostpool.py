@@ -12,7 +12,10 @@ import threading
 
 import torch
 
-_CAP_BYTES = int(float(os.environ.get("SGL_HOST_POOL_GB", "12")) * (1 << 30))
+# Page-locked memory is a machine-wide resource: the default cap is 4 GB (the three hop matrices of a products-sized k = 3 call are
+# 2.9 GB); a job that returns more per call raises it with SGL_HOST_POOL_GB.  Buffers nobody references any more that did not fit
+# the last request are released by trim(), which GraphOp.propagate calls when a host-output call ends.
+_CAP_BYTES = int(float(os.environ.get("SGL_HOST_POOL_GB", "4")) * (1 << 30))
 _ROUND = 2 << 20
 
 _lock = threading.Lock()
@@ -21,9 +24,11 @@ _pooled_bytes = 0
 stats = {"reused": 0, "allocated": 0, "declined": 0}
 
 
+_USE_COUNT = getattr(torch._C, "_storage_Use_Count", None)      # private API, looked up once: without it the pool declines everything
+
+
 def _use_count(storage):
-    fn = getattr(torch._C, "_storage_Use_Count", None)
-    return None if fn is None else int(fn(storage._cdata))
+    return None if _USE_COUNT is None else int(_USE_COUNT(storage._cdata))
 
 
 def take(shape, dtype=torch.float32, pinned=True):
@@ -62,11 +67,23 @@ def take(shape, dtype=torch.float32, pinned=True):
         return torch.empty(0, dtype=dtype).set_(st, 0, tuple(int(s) for s in shape))
 
 
-def trim():
-    """release every pooled buffer that is not in use"""
+def trim(keep_sizes=()):
+    """release every pooled buffer that is not in use (except buckets whose rounded size is in keep_sizes: what the call that just
+    ended used -- the next call of the same shape finds them warm)"""
     global _pooled_bytes
     with _lock:
         for size, lst in list(_buckets.items()):
+            if size in keep_sizes:
+                continue
             keep = [st for st in lst if (_use_count(st) or 2) > 1]
             _pooled_bytes -= size * (len(lst) - len(keep))
             _buckets[size] = keep
+
+
+def bucket_size(shape, dtype=torch.float32, pinned=True):
+    """the bucket a request of this shape falls into (for trim(keep_sizes=...))"""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    nbytes = n * torch.empty(0, dtype=dtype).element_size()
+    return (nbytes + _ROUND - 1) // _ROUND * _ROUND + (0 if pinned else 1)

@@ -45,14 +45,46 @@ class BaseSGAPModel(nn.Module):
     # `_processed_feat_list` is part of the de-facto interface (the reference's distributed tasks and search code read it:
     # sgl/tasks/node_classification_dist.py:69, sgl/search/auto_search_dist.py:80).  When preprocess() folded the aggregation into
     # the SpMM epilogue no hop list was kept; it is then produced ON DEMAND, the first time somebody asks for it.
+    # An incidental read (an `is None` check, an attribute walk) must not trigger K SpMMs over matrices that were folded precisely
+    # because the K+1 hop matrices would not fit: the lazy path only runs when they take at most half of the free device memory;
+    # otherwise the attribute reads None and materialize_hops(force=True) is the explicit way to get the list.
     @property
     def _processed_feat_list(self):
         hops = self.__dict__.get("_hop_list")
+        if hops is None and self.__dict__.get("_hop_source") is not None and self._hops_fit():
+            hops = self.materialize_hops()
+        return hops
+
+    def materialize_hops(self, force=False):
+        """The hop list [X, A_hat X, ..., A_hat^K X] of the last preprocess() when its aggregation was folded into the SpMM
+        epilogue (no list was kept): propagated now, once, and kept.  Raises if the K+1 matrices would take more than half of
+        the free device memory unless force=True.  Returns the list (None if preprocess() has not run)."""
+        hops = self.__dict__.get("_hop_list")
         src = self.__dict__.get("_hop_source")
         if hops is None and src is not None:
+            if not force and not self._hops_fit():
+                raise RuntimeError("materialize_hops: the K+1 hop matrices of the folded pre-propagation would take more than half "
+                                   "of the free device memory; pass force=True to propagate them anyway")
             hops = self._pre_graph_op.propagate(*src)
             self.__dict__["_hop_list"], self.__dict__["_hop_source"] = hops, None
         return hops
+
+    def _hops_fit(self):
+        src = self.__dict__.get("_hop_source")
+        try:
+            n, d = src[1].shape
+            need = (self._pre_graph_op._prop_steps + 1) * n * dev.row_pitch(d) * 4
+            free, _ = torch.cuda.mem_get_info(torch.device(self._pre_graph_op._opt("device")))
+            return need <= free // 2
+        except (RuntimeError, AssertionError, ValueError, TypeError, AttributeError):
+            return True                                   # nothing to ask (small CPU-side jobs): keep the round-3 behaviour
+
+    # the inputs of a folded preprocess() (adjacency, features) are kept only to serve the lazy hop list: they are not part of the
+    # model and do not travel with torch.save(model) / copy.deepcopy(model) (the reference's search code pickles whole models)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_hop_source"] = None
+        return state
 
     @_processed_feat_list.setter
     def _processed_feat_list(self, hops):

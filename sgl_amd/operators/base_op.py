@@ -326,6 +326,9 @@ class GraphOp:
             keep.append(ypad)
             prev = ypad
         side.synchronize()                                # the results are complete when the call returns (reference contract)
+        self._phase_done("hops")                          # (the downloads overlap the hops on this path: one phase)
+        # buffers of other shapes that nobody references any more go back to the system; this call's bucket stays warm
+        hostpool.trim(keep_sizes=(hostpool.bucket_size((n, d)),))
         return out
 
 

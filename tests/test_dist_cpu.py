@@ -248,9 +248,20 @@ def _halo_worker(rank, world, port, K, d, out_dir, graph, bounds_override):
                 ok = ok and all(np.array_equal(hops[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
         # caller-owned tables, one per exchanged hop: the hop matrices ARE the own rows of those tables (nothing copied, all kept)
         bufs = [torch.empty_like(t_own) for _ in range(K - 1)]
-        hops_v = prop.propagate(t_own.clone(), K, buffers=bufs)
+        hops_v = prop.propagate(t_own.clone(), K, buffers=bufs, hops_in_buffers=True)
         ok = ok and all(np.array_equal(hops_v[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
         ok = ok and all(hops_v[h + 1].data_ptr() == bufs[h].data_ptr() for h in range(K - 1) if plan.n_own)
+        # ... only when asked for: without the flag the hops are separate matrices whatever buffers are passed (a caller that reuses
+        # its buffers across calls keeps its earlier results), and the flag without enough buffers is an error
+        hops_c = prop.propagate(t_own.clone(), K, buffers=bufs)
+        ok = ok and all(np.array_equal(hops_c[h].numpy(), ref[h][lo:hi]) for h in range(K + 1))
+        ok = ok and all(hops_c[h + 1].data_ptr() != bufs[h].data_ptr() for h in range(K - 1) if plan.n_own)
+        if K >= 3:
+            try:
+                prop.propagate(t_own.clone(), K, buffers=bufs[:1], hops_in_buffers=True)
+                ok = False
+            except ValueError:
+                pass
         # the pack step in own-row order (every row read once, written to each peer's share) fills the same send buffer
         ok = ok and torch.equal(plan.send_idx[plan.pack_dst], plan.pack_src) and bool((plan.pack_src[1:] >= plan.pack_src[:-1]).all())
         prop.pack_mode = "scatter"

@@ -698,6 +698,21 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     mb = SSGC(3, d, 5)
     mb.preprocess(a, x)
     assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)
+    # the inputs kept for the lazy list do not travel with a pickled / copied model, and a list that would not fit is never produced
+    # by an incidental read: the attribute reads None, materialize_hops() refuses unless forced
+    import copy
+    import pickle
+    mc = SGC(3, d, 5)
+    mc.preprocess(a, x)
+    assert mc.__dict__["_hop_source"] is not None
+    for clone in (copy.deepcopy(mc), pickle.loads(pickle.dumps(mc))):
+        assert clone.__dict__["_hop_source"] is None and clone._processed_feat_list is None
+        assert torch.equal(clone._processed_feature.cpu(), mc._processed_feature.cpu())
+    mc._hops_fit = lambda: False
+    assert mc._processed_feat_list is None and mc.__dict__["_hop_list"] is None
+    with pytest.raises(RuntimeError):
+        mc.materialize_hops()
+    assert len(mc.materialize_hops(force=True)) == 4 and mc._processed_feat_list is not None
 
 
 def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
@@ -1181,6 +1196,18 @@ def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
         yd, wd = dev.hop_gate([f.contiguous().clone() for f in feats], v.detach(), b.detach(), return_weights=True)
         assert torch.allclose(wd, w.detach(), rtol=1e-5, atol=1e-6)
         assert oracle.parity_ok(yd.cpu().numpy(), y.detach().cpu().numpy(), 2e-6, rowwise=False)
+    # the C entry point with the bias as a host float (the wrapper passes NaN = "read it from the device, after the padded vector":
+    # no host synchronisation): bit-identical, and the output's pad columns are written as zeros (whole-line stores)
+    vp = dev._padded_vec(v, d, cuda)
+    yh = dev.alloc_rows(n, d, cuda, zero_pad=False)
+    dev.padded_parent(yh).fill_(7.0)
+    ptrs, lds = _lib.hop_arrays([f.detach() for f in fx])
+    _lib.check(_lib.lib().sgl_hop_gate_f32(H, ptrs, lds, _lib.ptr(vp), float(b.detach().cpu()), _lib.ptr(yh), yh.stride(0) if n > 1 else d,
+                                           None, 0, None, 0, n, d, _lib.current_stream_ptr()), "sgl_hop_gate_f32")
+    assert torch.equal(yh, y.detach())
+    if n > 1 and yh.stride(0) != d:
+        pad = dev.padded_parent(yh)[:, d:]
+        assert bool((pad == 0).all()) == (yh.stride(0) - d < 32)
     # (a) two-pass route, same kernels' arithmetic for the dots and the FMA sum
     sc = dev.hop_scores(feats, v.detach()) + b.detach()
     w2 = torch.softmax(torch.sigmoid(sc), dim=1)

@@ -466,3 +466,47 @@ def test_community_order_on_cpu_tensors():
     before = np.mean(np.abs(coo.row - coo.col) < 2 * bs)
     after = np.mean(np.abs(o[coo.row] - o[coo.col]) < 2 * bs)
     assert before < 0.3 and after > 0.8, (before, after, info)
+
+
+def test_hop_cache_digest_separates_moves_and_swaps():
+    """the device-tensor fingerprint of the on-disk hop cache (sgl_amd/hopcache.py): a collision is a cache hit that returns another
+    input's hop matrices, so single-element moves, swaps of two values and reorderings must change the key (the round-3 digest was a
+    plain position-weighted sum and collided in 22 of 3000 single-element moves: ADVICE r3)"""
+    import torch
+    from sgl_amd.hopcache import _bits_digest, _tensor_digest
+    g = torch.Generator().manual_seed(0)
+    base = torch.zeros(4096)
+    digests, positions = set(), set()
+    for _ in range(3000):
+        p = int(torch.randint(0, 4096, (1,), generator=g))
+        x = base.clone()
+        x[p] = 1.0
+        positions.add(p)
+        digests.add(_tensor_digest(x))
+    assert len(digests) == len(positions)                      # one digest per position of the 1.0: no two one-hot tensors collide
+    x = torch.randn(4096, generator=g)
+    d0 = _tensor_digest(x)
+    for _ in range(3000):
+        i, j = torch.randint(0, 4096, (2,), generator=g).tolist()
+        if x[i] != x[j]:
+            y = x.clone()
+            y[i], y[j] = x[j], x[i]
+            assert _tensor_digest(y) != d0
+    # +a at one place and -a at another (what cancels in a linear digest), a reversal, a changed length
+    y = x.clone()
+    y[10] += 0.5
+    y[2000] -= 0.5
+    assert _tensor_digest(y) != d0 and _tensor_digest(x.flip(0)) != d0 and _tensor_digest(x[:-1]) != d0
+    assert _tensor_digest(x.clone()) == d0 and d0.bit_length() > 64
+    # chunked evaluation gives the same value as one pass (the sum is order-free)
+    import sgl_amd.hopcache as hc
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (70_000,), dtype=torch.int64, generator=g).to(torch.int32)
+    whole = _bits_digest(bits)
+    total = torch.zeros(2, dtype=torch.int64)
+    for s in range(0, bits.numel(), 9_999):
+        part = bits[s:s + 9_999].to(torch.int64) & 0xFFFFFFFF
+        keyed = part + torch.arange(s, s + part.numel(), dtype=torch.int64) * hc._s64(0x9E3779B97F4A7C15)
+        total[0] += hc._mix64(keyed).sum()
+        total[1] += hc._mix64(keyed ^ hc._s64(0xD6E8FEB86659FD93)).sum()
+    lo, hi = (int(v) & 0xFFFFFFFFFFFFFFFF for v in total.tolist())
+    assert whole == (hi << 64) | lo

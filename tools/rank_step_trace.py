@@ -68,7 +68,7 @@ def main():
     prop.begin_exchange = no_network
 
     def step():
-        return prop.propagate_chunked(tables, K, buffers=bufs, y_buffers=ylast)
+        return prop.propagate_chunked(tables, K, buffers=bufs, y_buffers=ylast, hops_in_buffers=True)
 
     for _ in range(3):
         step()
