@@ -70,6 +70,16 @@ class GraphOp:
         self._hop_cache = None
         self._adj_key = None
 
+    # The cached device adjacency (a library handle + device arrays), its identity record, the side stream and the on-disk cache
+    # object belong to THIS process: a pickled / deep-copied operator (torch.save(model), the reference's search code) carries the
+    # settings only and rebuilds them on its next propagate().
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_adj", "_adj_key", "_hop_cache", "_download_stream", "_prepared", "last_trace"):
+            if k in state:
+                state[k] = None
+        return state
+
     # ---- effective settings (ctor kwarg, else sgl_amd.config) ------------------------------------
     def _opt(self, name):
         v = getattr(self, "_" + name)

@@ -50,21 +50,9 @@ def timed(fn, reps=5, warm=2):
 
 
 def simulate(spmm, pack, xfer, k=K):
-    """ms per step of the chunk-pipelined schedule.  spmm[c], pack[c]: ms on the compute stream; xfer[c]: ms one grouped exchange
-    of chunk c occupies the links (all peers in parallel: the busiest link decides).  One compute resource, one link resource;
-    hop h of chunk c starts when the compute stream is free AND chunk c's exchange of hop h-1 has landed."""
-    C = len(spmm)
-    t_comp = t_link = 0.0
-    landed = [0.0] * C
-    for h in range(1, k + 1):
-        for c in range(C):
-            start = max(t_comp, landed[c])
-            t_comp = start + spmm[c]
-            if h < k:
-                t_comp += pack[c]
-                t_link = max(t_link, t_comp) + xfer[c]
-                landed[c] = t_link
-    return t_comp
+    """ms per step of the chunk-pipelined schedule: the model bench.py prints next to a measured N-rank step (benchlib/model.py)"""
+    from benchlib.model import simulate as sim
+    return sim(spmm, pack, xfer, k)
 
 
 def rank_measurements(rowptr, col, val, rp_host, bounds, r, n, d, x0, chunks, device):
