@@ -407,6 +407,9 @@ __device__ __forceinline__ void store_row(float *__restrict__ orow, const f4 (&a
                     for (int e = 0; e < 4; ++e)
                         if (col + e >= d) v[e] = 0.f;
                 }
+                // non-temporal: with plain (write-back) stores these kernels are 7-20 % slower at every width -- also at widths whose
+                // rows share lines with their neighbours (d = 100: 0.906 -> 0.935 ms, d = 147: 1.98 -> 2.42 ms, d = 128: 1.51 -> 1.65 ms;
+                // profiles/r04_aggregators_plain_stores_experiment.log)
                 __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(orow + col));
             } else {                                // dw == d, the vector straddles it: never write past the caller's d columns
 #pragma unroll
