@@ -66,6 +66,18 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
            "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}{compacted}, one hop, median of {len(times)} reps, "
                      f"OpenMP static schedule, {threads} threads on {cores} physical cores of {cpu_model}",
            "ms_per_hop_sample": t * 1e3}
+    # the build's OWN restatement of the same loop (oracle/spmm_ref.c: bit-equal to the reference binary, tests/test_oracle_golden.py)
+    # beside it whenever the headline figure is the reference's compiled kernel: both travel, the line says which is which
+    if kind == "reference":
+        try:
+            oracle.oracle_spmm(rp, c, v, xh, n_rows=rows)
+            t0 = time.perf_counter()
+            oracle.oracle_spmm(rp, c, v, xh, n_rows=rows)
+            tp = time.perf_counter() - t0
+            out["port"] = {"value": nnz_s * d / tp, "unit": "edge\u00b7featdim/s", "cores": cores, "threads": threads, "kind": "port",
+                           "sample": "the same rows through oracle/liboracle_spmm.so (this repository's C restatement), one rep"}
+        except Exception as e:  # noqa: BLE001
+            out["port"] = {"value": None, "sample": f"failed: {e}"}
     # B2 of BASELINE.md: the reference's non-Linux branch `adj.dot(x)` (base_op.py:34), scipy, single thread, on a
     # smaller slice of the same rows (bounded: a few seconds)
     try:

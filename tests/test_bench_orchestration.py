@@ -404,6 +404,8 @@ def test_cpu_baseline_leg_reports_reference_kernel_cores_and_scipy():
     assert out["value"] > 0 and out["kind"] in ("reference", "port") and out["unit"] == "edge\u00b7featdim/s"
     assert 1 <= out["cores"] <= out["threads"] and "physical cores" in out["sample"]
     assert out["scipy_dot"]["value"] and out["scipy_dot"]["cores"] == 1
+    # the reference's compiled kernel and this repository's restatement of it are both reported, each under its own kind
+    assert (out["kind"] == "reference") == ("port" in out) and (out["kind"] != "reference" or out["port"]["value"] > 0)
 
 
 def test_bench_need_aware_exchange_as_one_all_to_all(tmp_path):
