@@ -98,7 +98,9 @@ typedef struct sgl_csr sgl_csr_t;
  * Wraps caller-owned device arrays (NOT copied; they must outlive the handle) and builds the execution plan
  * (copies the row pointers to the host once: this call synchronises `stream`).
  * item_nnz / long_row_nnz: 0 = library default (items of 512 non-zeros from 1e8 non-zeros per launch, 256 below, fewer for
- * matrices too small to fill the chip; rows above 2048 non-zeros are cut). */
+ * matrices too small to fill the chip; rows above 2048 non-zeros are cut -- above 512 / 128 / 32 for matrices of fewer than
+ * 2^22 / 2^20 / 2^18 non-zeros, whose longest row would otherwise be the whole launch; the threshold depends on nnz only, so
+ * two handles of one matrix cut the same rows at the same places). */
 int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
                    const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
                    int32_t long_row_nnz, void *stream);

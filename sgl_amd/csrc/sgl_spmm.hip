@@ -524,9 +524,15 @@ SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, i
         // products-sized graph, neutral on the whole of it).  Results do not depend on the item size.
         const int64_t want_items = 256 * 4 * 8;
         const int64_t cap = nnz >= sgl::kSmallLaunchNnz ? sgl::kDefaultItemNnz : sgl::kDefaultItemNnz / 2;
-        item_nnz = (int32_t)std::min<int64_t>(cap, std::max<int64_t>(32, nnz / want_items));
+        item_nnz = (int32_t)std::min<int64_t>(cap, std::max<int64_t>(16, nnz / want_items));
     }
-    if (long_row_nnz == 0) long_row_nnz = sgl::kDefaultLongRowNnz;
+    // Where a row is cut into pieces.  A row is ONE sequential chain of gathers in one wavefront; on a small matrix the whole
+    // launch is only a few such chains long, so its longest row IS the launch (Pubmed-sized S0: a 171-nnz hub row of 2 KB gathers
+    // took 62 us per hop whatever the item size; cut at 32 non-zeros the hop takes 44 us, 0.52 -> 0.73 of the roofline,
+    // profiles/r04_small_graph_sweep.log).  The threshold depends on the matrix (its nnz) only -- never on the plan -- so any two
+    // plans of one matrix still cut the same rows at the same places and agree bit for bit; strict order never cuts.
+    if (long_row_nnz == 0)
+        long_row_nnz = nnz < (1 << 18) ? 32 : nnz < (1 << 20) ? 128 : nnz < (1 << 22) ? 512 : sgl::kDefaultLongRowNnz;
     if (flags & SGL_CSR_STRICT_ORDER) long_row_nnz = -1;
     sgl::Plan plan;
     int rc = sgl::build_plan(plan, h_rowptr.data(), n_rows, item_nnz, long_row_nnz);

@@ -105,6 +105,20 @@ def main():
                        pieces=c.info()["n_pieces"])
                 del c
 
+    if "small" in exps:
+        # small graphs (Pubmed-sized: launch- and latency-bound): item size x gathers in flight, eager and as a replayed hipGraph
+        xin = dev.padded_parent(dev.upload_rows(x0, device)) if dev.row_pitch(d) != d else x0
+        for item_nnz, long_nnz in ((8, 0), (16, 0), (32, 0), (64, 0), (128, 0), (32, 128), (32, 64), (32, 32), (16, 32), (16, 16), (8, 16)):
+            for unroll in (0, 2):
+                set_knobs(spmm_unroll=unroll)
+                c = dev.DeviceCSR(rowptr, col, val, (n, n), item_nnz=item_nnz, long_row_nnz=long_nnz)
+                outs = [dev.padded_parent(dev.alloc_rows(n, d, device)) for _ in range(K)]
+                g = c.capture_chain(xin, outs)
+                report("small", time_hops(g.replay), K, item_nnz=item_nnz, long_nnz=long_nnz, unroll=unroll, items=c.info()["n_items"],
+                       pieces=c.info()["n_pieces"], graph=1)
+                del g, c, outs
+        set_knobs()
+
     deg = rowptr[1:] - rowptr[:-1]
     if "colblock" in exps or "relabel" in exps:
         rows = torch.repeat_interleave(torch.arange(n, device=device), deg)
