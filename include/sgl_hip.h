@@ -302,18 +302,23 @@ int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx
 int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops);
 int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,
                            int64_t lddo, float *d_dw, float *d_scratch, int64_t n, int64_t d, void *stream);
-/* Row outputs and padding (sgl_hop_concat_f32, sgl_nafs_f32, sgl_hop_gate_f32): when the output pitch is a multiple of 4 floats
- * and exceeds the row length by less than one 128-byte line (0 <= ldo - width < 32 floats), columns [width, ldo) of d_out are
- * the row's own padding and are WRITTEN AS ZEROS, so that every line of a row is written whole (a partly written line costs a
- * read-modify-write in ECC-protected HBM: 2.7 instead of 5.8 TB/s at d = 147 on a 160-float pitch).  With a larger gap (d_out is a
- * column slice of a wider matrix) nothing beyond column `width` is touched. */
+/* Row outputs and padding: sgl_hop_concat_padded_f32 / sgl_nafs_padded_f32 / sgl_hop_gate_padded_f32 take `pad_cols` = the number of
+ * columns after the row (after column n_hops * d resp. d) that are the row's OWN padding inside its pitch ldo.  They are WRITTEN AS
+ * ZEROS, so that every 128-byte line of a row is written whole: a partly written line costs a read-modify-write in the ECC-protected
+ * HBM (output stream 2.7 instead of 5.8 TB/s at d = 147 on a 160-float pitch).  width + pad_cols <= ldo, both multiples of 4.  The
+ * kernels never guess: the un-suffixed entry points are pad_cols = 0 and touch nothing beyond the row (the vector that straddles
+ * column d is then written element by element). */
 /* out[:, h*d:(h+1)*d] = X_h */
 int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
                        int64_t n, int64_t d, void *stream);
+int sgl_hop_concat_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                              int64_t pad_cols, int64_t n, int64_t d, void *stream);
 /* NAFS: W[n,h] = softmax_h( <X_0[n],X_h[n]> / (|X_h[n]|+1e-10) / (|X_0[n]|+1e-10) ), out = sum_h W[n,h] X_h[n]
  * d_w_out (optional, [n, n_hops] leading dimension ldw) receives W. */
 int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
                  float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
+int sgl_nafs_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo, int64_t pad_cols,
+                        float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
 /* Learnable gate in one pass (LearnableWeightedMessageOp 'gate', message_op/learnable_weighted_messahe_op.py:67-71 followed by
  * two_dim_weighted_add, operators/utils.py:105-116):  G[n,h] = sigmoid(<X_h[n], vec> + bias),  W[n,:] = softmax_h(G[n,:]),
  * out[n] = sum_h W[n,h] X_h[n].  Every hop element is read once.  d_vec: round_up(d, 4) floats, 16-byte aligned, zero beyond d.
@@ -323,6 +328,9 @@ int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, floa
  * d <= 512, 16-byte aligned rows -- otherwise SGL_ERR_UNSUPPORTED (callers then use sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32). */
 int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
                      int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n, int64_t d, void *stream);
+int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
+                            int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
+                            int64_t d, void *stream);
 /* Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in one pass over the hop list:
  *   P[n, h - h0] = <X_h[n], vec>  for h in [h0, h1);   A[n] = sum over the hops j with bit j of u_mask set of <X_j[n], U[j, :]>
  * (the reference concatenates [ref || x_h] with ref = feat_list[0] or hstack(feat_list) and applies one Linear: the ref part is

@@ -89,8 +89,13 @@ PROTOTYPES = {
     "sgl_hop_wsum1d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                        c_int64, c_void_p]),
     "sgl_hop_concat_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_hop_concat_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "sgl_nafs_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
                              c_void_p]),
+    "sgl_nafs_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                    c_void_p]),
+    "sgl_hop_gate_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                        c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
     "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

@@ -388,8 +388,8 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
-// Output row of a register-resident row kernel.  dw = the columns the kernel writes: exactly d, or -- when the tail of the row's
-// pitch is padding (out_cols() below) -- the whole pitch, pad columns as zeros.  Why: a row of d = 147 floats on a
+// Output row of a register-resident row kernel.  dw = the columns the kernel writes: exactly d, or -- when the caller declared the
+// tail of the row's pitch to be padding (out_cols() below) -- d + pad, the pad columns as zeros.  Why: a row of d = 147 floats on a
 // 160-float pitch ends 52 bytes short of its last 128-byte line, and a line that is only partly written costs a read-modify-write in
 // the ECC-protected HBM: the output write of the gate / NAFS kernels ran at 2.7 TB/s at d = 147 against 5.8 TB/s at d = 160
 // (profiles/r04_aggregators.log; the element-wise kernels always streamed whole pitches).
@@ -1037,14 +1037,22 @@ int pick_lpr(int64_t d, int vec) {
     return lpr;
 }
 
-// Columns a row-producing kernel writes into an output of pitch ldo (a multiple of 4 floats): the tail of a pitch that is shorter
-// than one 128-byte line beyond d can only be the row's own padding (sgl_amd.device.alloc_rows, or any caller that pads rows to
-// whole vectors / lines) -- it is written too, as zeros, so that every line of the row is written whole; a wider gap means d_out is
-// a column slice of something larger, and nothing beyond column d is touched.  `room` = the columns the lane layout reaches.
-int out_cols(int64_t d, int64_t ldo, int64_t room) {
-    int64_t dw = (ldo % 4 == 0 && ldo - d < 32 && sgl::tuning("row_whole_lines", 1) != 0) ? ldo : d;
-    if (dw > room) dw = room > d ? room : d;
+// Columns a row-producing kernel writes: the d data columns plus the `pad` columns after them that the CALLER declared to be the
+// row's own padding (the *_padded_f32 entry points; sgl_amd.device passes the tail of the pitch of the outputs it allocates) --
+// written as zeros, so that every line of the row is written whole.  The kernels never guess: with pad = 0 nothing beyond column
+// d is touched.  `room` = the columns the lane layout reaches.
+int out_cols(int64_t d, int64_t pad, int64_t room) {
+    int64_t dw = sgl::tuning("row_whole_lines", 1) != 0 ? d + pad : d;
+    if (dw > room) dw = room > d ? room / 4 * 4 : d;
+    if (dw > d && dw % 4 != 0) dw = d;              // (validated by the entry points: d + pad is a whole number of vectors)
     return (int)dw;
+}
+
+int check_pad(const char *who, int64_t width, int64_t pad, int64_t ldo) {
+    if (pad < 0 || width + pad > ldo) return sgl::fail(SGL_ERR_INVALID, "%s: pad_cols=%lld does not fit the output pitch", who, (long long)pad);
+    if (pad > 0 && ((width + pad) % 4 != 0 || ldo % 4 != 0))
+        return sgl::fail(SGL_ERR_INVALID, "%s: padded rows must be whole 16-byte vectors (width + pad_cols and ldo multiples of 4)", who);
+    return SGL_OK;
 }
 
 RowLayout pick_row_layout(int64_t d, int n_hops, bool allow_8x5 = false) {
@@ -1345,9 +1353,13 @@ SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const
     return SGL_OK;
 }
 
-SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
-                                  int64_t n, int64_t d, void *stream) {
+SGL_EXPORT int sgl_hop_concat_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                                         int64_t pad_cols, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_concat_f32: bad sizes");
+    {
+        const int prc = check_pad("sgl_hop_concat_padded_f32", d * (n_hops > 0 ? n_hops : 0), pad_cols, ldo);
+        if (prc != SGL_OK) return prc;
+    }
     Hops hx;
     bool vec4 = (d % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_out, 16);
     int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
@@ -1360,14 +1372,14 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
         const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && sgl::tuning("concat_lds", 1) != 0 &&
-               sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((out_cols(d * n_hops, ldo, INT32_MAX) + kConcatTile - 1) / kConcatTile), 256)) {
+               sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((out_cols(d * n_hops, pad_cols, INT32_MAX) + kConcatTile - 1) / kConcatTile), 256)) {
         // any d, long rows: assembled in LDS, every source vector read once
-        const int width_w = out_cols(d * n_hops, ldo, INT32_MAX);
+        const int width_w = out_cols(d * n_hops, pad_cols, INT32_MAX);
         const int tiles = (int)((width_w + kConcatTile - 1) / kConcatTile);
         hipLaunchKernelGGL(hop_concat_lds_kernel, dim3((unsigned)((n + kConcatRows - 1) / kConcatRows * tiles)), dim3(256), 0, st, hx,
                            n_hops, d_out, ldo, n, (int)d, tiles, width_w);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops)) {   // any d: aligned 16-byte stores, aligned 16-byte loads + select
-        const int width_w = out_cols(d * n_hops, ldo, INT32_MAX);
+        const int width_w = out_cols(d * n_hops, pad_cols, INT32_MAX);
         const int grid = stream_grid(n * (((int64_t)width_w + 3) / 4));
         hipLaunchKernelGGL(hop_concat_any_kernel, dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d, width_w);
     } else {
@@ -1378,9 +1390,18 @@ SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int
     return SGL_OK;
 }
 
-SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
-                            float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream) {
+SGL_EXPORT int sgl_hop_concat_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                                  int64_t n, int64_t d, void *stream) {
+    return sgl_hop_concat_padded_f32(n_hops, h_x, h_ldx, d_out, ldo, 0, n, d, stream);
+}
+
+SGL_EXPORT int sgl_nafs_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                                   int64_t pad_cols, float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_nafs_f32: bad sizes");
+    {
+        const int prc = check_pad("sgl_nafs_padded_f32", d, d_out ? pad_cols : 0, d_out ? ldo : d);
+        if (prc != SGL_OK) return prc;
+    }
     SGL_REQUIRE(d_w_out && ldw >= n_hops, "sgl_nafs_f32: the [n, n_hops] weight buffer is required");
     Hops hx;
     bool vec4 = true;   // 16-byte row accesses with a masked tail: needs only 4-float row pitches
@@ -1398,7 +1419,7 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
         const RowLayout lay = pick_row_layout(d, n_hops);
         const int64_t nblocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
 #define SGL_NF(L, C, HM) \
-    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
+    hipLaunchKernelGGL((nafs_fused_kernel<L, C, HM>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, d_w_out, ldw, n, (int)d, out_cols(d, pad_cols, (L) * (C) * 4))
 #define SGL_NF_H(L, C) SGL_HOPS_UP_TO_16(SGL_NF, L, C)
 #define SGL_NF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_NF, L, C)
 #define SGL_NF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
@@ -1432,6 +1453,11 @@ SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *
     if (!d_out) return SGL_OK;  // weights only
     // out = sum_h W[:,h] * X_h accumulated in hop order from 0 with rounded products (over_smooth_distance_op.py:27-31)
     return wsum2d_impl(false, n_hops, h_x, h_ldx, d_w_out, ldw, d_out, ldo, n, d, stream);
+}
+
+SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
+                            float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream) {
+    return sgl_nafs_padded_f32(n_hops, h_x, h_ldx, d_out, ldo, 0, d_w_out, ldw, n, d, stream);
 }
 
 static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, const int64_t *d_dst,
@@ -1494,10 +1520,14 @@ SGL_EXPORT int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_row
 // ---- learnable gates -------------------------------------------------------------------------------------------------------
 // register-resident row kernels: H <= 16, d <= 512, 16-byte aligned rows.  Anything else -> SGL_ERR_UNSUPPORTED and the caller
 // takes the two-pass route (sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32).
-SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
-                                float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
-                                int64_t d, void *stream) {
+SGL_EXPORT int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
+                                       float *d_out, int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out,
+                                       int64_t ldg, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_gate_f32: bad sizes");
+    {
+        const int prc = check_pad("sgl_hop_gate_padded_f32", d, pad_cols, ldo);
+        if (prc != SGL_OK) return prc;
+    }
     Hops hx;
     bool vec4 = aligned_to(d_vec, 16);
     int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
@@ -1515,7 +1545,7 @@ SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64
     // bias is a device tensor (a torch parameter) needs neither a device-to-host synchronisation nor a new value per launch
     const float *bias_ptr = (bias != bias) ? d_vec + (d + 3) / 4 * 4 : nullptr;
 #define SGL_GF(L, C, HM) \
-    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, bias_ptr, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, ldo, (L) * (C) * 4))
+    hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, bias_ptr, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, pad_cols, (L) * (C) * 4))
 #define SGL_GF_H(L, C) SGL_HOPS_UP_TO_16(SGL_GF, L, C)
 #define SGL_GF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_GF, L, C)
 #define SGL_GF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
@@ -1526,6 +1556,12 @@ SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64
 #undef SGL_GF
     SGL_LAUNCH_CHECK("sgl_hop_gate_f32");
     return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
+                                float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
+                                int64_t d, void *stream) {
+    return sgl_hop_gate_padded_f32(n_hops, h_x, h_ldx, d_vec, bias, d_out, ldo, 0, d_w_out, ldw, d_g_out, ldg, n, d, stream);
 }
 
 SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_u, int64_t ldu,

@@ -65,6 +65,16 @@ def alloc_rows(n, d, device, zero_pad=True):
     return buf[:, :d] if ld != d else buf
 
 
+def own_pad(t):
+    """pad columns of an output WE allocated with alloc_rows (the tail of its pitch): what the *_padded_f32 entry points may write
+    as zeros so that every line of a row is written whole; 0 for anything that is not a padded [n, d] view with 16-byte rows"""
+    n, d = t.shape
+    if n <= 1:
+        return 0
+    ld = t.stride(0)
+    return ld - d if (ld > d and ld % 4 == 0 and t.stride(1) == 1 and t.data_ptr() % 16 == 0) else 0
+
+
 def padded_parent(t):
     """For a [n, d] view created by alloc_rows return the [n, ld] parent view (pad columns included)."""
     n, d = t.shape
@@ -590,7 +600,8 @@ def hop_concat(feats):
     out = alloc_rows(n, H * d, feats[0].device)
     ptrs, lds = _lib.hop_arrays(feats)
     with torch.cuda.device(feats[0].device):
-        check(lib().sgl_hop_concat_f32(H, ptrs, lds, ptr(out), _ld(out), n, d, current_stream_ptr()), "sgl_hop_concat_f32")
+        check(lib().sgl_hop_concat_padded_f32(H, ptrs, lds, ptr(out), _ld(out), own_pad(out), n, d, current_stream_ptr()),
+              "sgl_hop_concat_padded_f32")
     return out
 
 
@@ -756,8 +767,8 @@ class _GateFused(torch.autograd.Function):
         g = torch.empty((n, H), dtype=torch.float32, device=dev_)
         ptrs, lds = _lib.hop_arrays(feats_d)
         with torch.cuda.device(dev_):
-            check(lib().sgl_hop_gate_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), ptr(w), H,
-                                         ptr(g), H, n, d, current_stream_ptr()), "sgl_hop_gate_f32")
+            check(lib().sgl_hop_gate_padded_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), own_pad(result), ptr(w), H,
+                                                ptr(g), H, n, d, current_stream_ptr()), "sgl_hop_gate_padded_f32")
         ctx.save_for_backward(v.detach(), w, g, *feats_d)
         ctx.b_shape = tuple(b.shape)
         ctx.mark_non_differentiable(w)
@@ -876,7 +887,8 @@ def nafs_aggregate(feats, return_weights=False):
     w = torch.empty((n, H), dtype=torch.float32, device=feats[0].device)
     ptrs, lds = _lib.hop_arrays(feats)
     with torch.cuda.device(out.device):
-        check(lib().sgl_nafs_f32(H, ptrs, lds, ptr(out), _ld(out), ptr(w), H, n, d, current_stream_ptr()), "sgl_nafs_f32")
+        check(lib().sgl_nafs_padded_f32(H, ptrs, lds, ptr(out), _ld(out), own_pad(out), ptr(w), H, n, d, current_stream_ptr()),
+              "sgl_nafs_padded_f32")
     return (out, w) if return_weights else out
 
 

@@ -1207,7 +1207,14 @@ def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
     assert torch.equal(yh, y.detach())
     if n > 1 and yh.stride(0) != d:
         pad = dev.padded_parent(yh)[:, d:]
-        assert bool((pad == 0).all()) == (yh.stride(0) - d < 32)
+        assert bool((pad == 7.0).all())                      # the un-suffixed entry point touches nothing beyond column d ...
+        _lib.check(_lib.lib().sgl_hop_gate_padded_f32(H, ptrs, lds, _lib.ptr(vp), float(b.detach().cpu()), _lib.ptr(yh), yh.stride(0),
+                                                      dev.own_pad(yh), None, 0, None, 0, n, d, _lib.current_stream_ptr()),
+                   "sgl_hop_gate_padded_f32")
+        assert torch.equal(yh, y.detach()) and bool((pad == 0).all())      # ... the padded one writes the declared pad as zeros
+        with pytest.raises(_lib.SglHipError):                # a pad that does not fit the pitch is refused
+            _lib.check(_lib.lib().sgl_hop_gate_padded_f32(H, ptrs, lds, _lib.ptr(vp), 0.0, _lib.ptr(yh), yh.stride(0),
+                                                          yh.stride(0), None, 0, None, 0, n, d, _lib.current_stream_ptr()), "pad")
     # (a) two-pass route, same kernels' arithmetic for the dots and the FMA sum
     sc = dev.hop_scores(feats, v.detach()) + b.detach()
     w2 = torch.softmax(torch.sigmoid(sc), dim=1)
