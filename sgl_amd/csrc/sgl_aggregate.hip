@@ -335,6 +335,10 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
 // online softmax without a score array (0.58 vs 0.67) and one row per wavefront with the hops split over the half-waves
 // (v_permlane32_swap exchanges; 8 waves, but 0.57 / 0.48 vs 0.67 / 0.62) -- profiles/r03_aggregators_{online_gate,hop_split}_experiment.log.
 #define ROWREG_MIN_BLOCKS(HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((HMAX) * (CH) <= 16) ? 4 : 2))
+// 12 hop vectors per lane (H = 11: BASELINE configs 4 / 5) sit right at a register boundary: the gate needs 70-73 VGPRs depending on
+// what its epilogue carries; held to 72 (7 waves per SIMD, where it was measured in round 3: one register more costs a whole
+// wavefront of occupancy and ~4 % at d = 128, H = 11).  Only where that does not spill (groups of >= 16 lanes).
+#define GATE_MIN_BLOCKS(LPR, HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((CH) == 1 && (HMAX) <= 12 && (LPR) >= 16) ? 7 : ROWREG_MIN_BLOCKS(HMAX, CH)))
 
 // ---- lanes x chunks of a register-resident row kernel ------------------------------------------------------------------------
 // A row of d floats is ceil(d / 4) 16-byte slots; LPR lanes take CH slots each (slot (c * LPR + l) of the row for lane l, chunk c),
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_k
 // two-pass path up to the rounding of expf.  wout [n, H] = the softmax weights, gout [n, H] = the sigmoid outputs (what the
 // backward needs besides the hops).
 template <int LPR, int CH, int HMAX>
-__global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
+__global__ __launch_bounds__(256, GATE_MIN_BLOCKS(LPR, HMAX, CH)) void gate_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec,
                                                          const float bias_arg, const float *__restrict__ bias_ptr,
                                                          float *__restrict__ out, const int64_t ldo,
                                                          float *__restrict__ wout, const int64_t ldw, float *__restrict__ gout,

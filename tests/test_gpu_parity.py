@@ -1294,11 +1294,19 @@ def test_concat_any_width_lds_tiles(cuda, d, H):
     want = np.hstack(host)
     got = dev.hop_concat(feats)
     assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
+    # the pad columns of the output's own pitch are written (as zeros): every line of a row is written whole
+    assert dev.own_pad(got) == got.stride(0) - d * H and not bool(dev.padded_parent(got)[:, d * H:].any())
     _lib.set_tuning("concat_lds", 0)
     try:
-        assert torch.equal(dev.hop_concat(feats), got)
+        funnel = dev.hop_concat(feats)
+        assert torch.equal(funnel, got) and not bool(dev.padded_parent(funnel)[:, d * H:].any())
     finally:
         _lib.set_tuning("concat_lds", 1)
+    # the un-suffixed C entry point (pad_cols = 0) touches nothing beyond the row -- an output may be a slice of a wider matrix
+    wide = torch.full((n, d * H + 8), 7.0, device=cuda)
+    ptrs, lds = _lib.hop_arrays(feats)
+    _lib.check(_lib.lib().sgl_hop_concat_f32(H, ptrs, lds, _lib.ptr(wide), wide.stride(0), n, d, _lib.current_stream_ptr()), "sgl_hop_concat_f32")
+    assert np.array_equal(wide[:, :d * H].cpu().numpy(), want) and bool((wide[:, d * H:] == 7.0).all())
 
 
 @pytest.mark.parametrize("d", [147, 7, 100, 500, 1, 5, 12, 13, 33])
