@@ -2023,6 +2023,18 @@ def test_products_scale_properties(cuda):
     # (5) k-step propagation through the operator API reproduces repeated SpMM
     hop2 = strict.spmm(ys)
     assert torch.equal(hop2, strict.spmm(strict.spmm(x)))
+    # (6) BASELINE config 3's width at the same size: d + C = 147 columns on the 160-float pitch (five whole lines per gathered row):
+    #     the sampled rows bit-exact in strict order, the default order within tolerance over ALL rows, pad columns stay zero
+    del z, lhs, rhs, rs, ones, hop2
+    x147 = dev.upload_rows(synthetic.features_torch(n, 147, seed=3, device=cuda), cuda)
+    xp = dev.padded_parent(x147)                           # what GraphOp.propagate multiplies: the whole pitch, pad columns zero
+    assert xp.shape == (n, 160)
+    y147s, y147 = strict.spmm(xp), fast.spmm(xp)
+    ref147 = oracle.oracle_spmm(sub_ptr, sub_col, sub_val, x147.cpu().numpy())
+    assert np.array_equal(y147s[rows.to(cuda)][:, :147].cpu().numpy(), ref147)
+    dn = (y147 - y147s).norm(dim=1)
+    assert float((dn / y147s.norm(dim=1).clamp_min(1e-30)).max()) <= TOL
+    assert not bool(y147s[:, 147:].any()) and not bool(y147[:, 147:].any())
 
 
 def test_hashed_generator_device_equals_host_mirror(cuda):
