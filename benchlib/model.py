@@ -49,9 +49,10 @@ def explain(spmm, pack, xfer, link_bytes, k, measured_step_ms, world, single_gpu
     the run itself: per-chunk SpMM, pack and wire (exchange minus pack) milliseconds, the bytes the busiest link carries per
     chunk and hop.  Returns the dict bench.py prints under config.diagnostics.per_hop."""
     spmm, pack, xfer = [float(v) for v in spmm], [float(v) for v in pack], [float(v) for v in xfer]
-    compute_only = k * sum(spmm)
-    exchange_total = (k - 1) * (sum(pack) + sum(xfer))
-    exposed = max(measured_step_ms - compute_only, 0.0)
+    # what the compute stream does whatever the links deliver: K hops of SpMM and the K - 1 pack passes between them
+    compute_stream = k * sum(spmm) + (k - 1) * sum(pack)
+    wire_total = (k - 1) * sum(xfer)
+    exposed = max(measured_step_ms - compute_stream, 0.0)
     wire = sum(xfer)
     rate = (sum(link_bytes) / (wire * 1e-3) / 1e9) if wire > 0 else None
     out = {
@@ -59,8 +60,9 @@ def explain(spmm, pack, xfer, link_bytes, k, measured_step_ms, world, single_gpu
         "per_chunk": {"spmm_ms": spmm, "pack_ms": pack, "exchange_wire_ms": xfer, "busiest_link_bytes": [int(b) for b in link_bytes]},
         "link_GBps_per_direction_busiest_link": rate,
         "link_frac_of_xgmi_peak": (rate / XGMI_PEAK_GBPS_PER_DIRECTION) if rate else None,
-        # share of the step's exchange work (pack + wire of the K-1 exchanged hops) hidden behind the K hops of SpMM
-        "overlap_fraction": (min(max(1.0 - exposed / exchange_total, 0.0), 1.0) if exchange_total > 0 else None),
+        # share of the step's wire time (the K - 1 exchanged hops) that the pipelined schedule hid behind compute-stream work
+        "overlap_fraction": (min(max(1.0 - exposed / wire_total, 0.0), 1.0) if wire_total > 0 else None),
+        "compute_stream_ms_per_step": compute_stream,
         "exposed_exchange_ms_per_step": exposed,
     }
     model = {"schedule": "compute stream: spmm(c), pack(c) per chunk; one grouped exchange per chunk and hop on the links; hop h+1 "
