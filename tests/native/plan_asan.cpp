@@ -1,7 +1,7 @@
 // Host side of the C ABI under AddressSanitizer + UBSan ("race detection / sanitizers"): the
 // execution-plan builder, its export, the tuning table and the error path, driven with adversarial row-pointer vectors.
-// Built by tests/test_host_cpu.py from sgl_amd/csrc/sgl_core.cpp with g++ -fsanitize=address,undefined; any heap overflow,
-// use-after-free, leak or undefined behaviour makes the process exit non-zero.
+// Built by tests/test_host_cpu.py from sgl_amd/csrc/sgl_core.cpp with g++ -fsanitize=address,undefined and again with
+// -fsanitize=thread; any heap overflow, use-after-free, leak, undefined behaviour or data race makes the process exit non-zero.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +88,23 @@ int main() {
         });
     for (auto &x : th) x.join();
     CHECK(sgl_set_tuning("spmm_unroll", 0) == SGL_OK);
+    // plans built, exported and destroyed from several threads at once, good and bad inputs interleaved: the builder shares no
+    // state, the error message is per thread (under -fsanitize=thread any race between these fails the run)
+    th.clear();
+    for (int t = 0; t < 6; ++t)
+        th.emplace_back([t] {
+            std::mt19937_64 r2(100 + t);
+            for (int i = 0; i < 40; ++i) {
+                const int64_t n = 1 + r2() % 800;
+                std::vector<int64_t> rp(n + 1, 0);
+                for (int64_t k = 0; k < n; ++k) rp[k + 1] = rp[k] + (int64_t)(r2() % 30) + ((r2() % 211 == 0) ? 5000 : 0);
+                one_plan(rp, (int)(r2() % 300), (i & 1) ? 64 : 0);
+                sgl_plan_t *q = nullptr;
+                std::vector<int64_t> bad2 = {0, 9, 2};
+                CHECK(sgl_plan_build(&q, bad2.data(), 2, 0, 0) != SGL_OK && q == nullptr && strstr(sgl_last_error(), "row") != nullptr);
+            }
+        });
+    for (auto &x : th) x.join();
     CHECK(sgl_version() >= 100);
     printf("plan_asan: OK\n");
     return 0;

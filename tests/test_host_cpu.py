@@ -326,23 +326,26 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert int(out[0]) > 0 and out[1] == "1" and out[2] == "msg"          # bad arguments -> error code + message, no abort
 
 
-def test_host_side_under_address_and_ub_sanitizers(tmp_path):
-    """SURVEY section 5 (sanitizers): the host side of the C ABI -- plan builder / export / error path / tuning table --
-    rebuilt with g++ -fsanitize=address,undefined and driven with adversarial inputs (tests/native/plan_asan.cpp);
-    leaks, overflows, use-after-free and undefined behaviour all fail the run."""
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_host_side_under_address_and_ub_sanitizers(tmp_path, sanitizer):
+    """SURVEY section 5 (sanitizers / race detection): the host side of the C ABI -- plan builder / export / error path / tuning
+    table -- rebuilt with g++ -fsanitize=address,undefined and with -fsanitize=thread and driven with adversarial inputs from
+    one and from several threads (tests/native/plan_asan.cpp); leaks, overflows, use-after-free, undefined behaviour and data
+    races all fail the run."""
     import shutil
     import subprocess
     gxx = shutil.which("g++")
     if gxx is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
         pytest.skip("needs g++ and the HIP headers")
     exe = str(tmp_path / "plan_asan")
-    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    cmd = [gxx, "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", *(["-fno-sanitize-recover=undefined"] if "undefined" in sanitizer else []),
            "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
            os.path.join(ROOT, "tests", "native", "plan_asan.cpp"), os.path.join(ROOT, "sgl_amd", "csrc", "sgl_core.cpp"),
            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=1:exitcode=66")
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "plan_asan: OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
