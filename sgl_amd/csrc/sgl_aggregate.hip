@@ -841,6 +841,76 @@ __global__ __launch_bounds__(256) void hop_concat_lds_kernel(const Hops hx, cons
     }
 }
 
+// Whole rows per block (rows of <= kConcatRowCap floats): a block assembles R = kConcatLds / W complete output rows (W = the columns
+// written, pad included) and its 256 threads share the work FLAT -- phase 1 over all (row, hop, aligned source vector) triples,
+// phase 2 over all (row, aligned output vector) pairs -- so no thread idles because a 1024-float tile is only partly used (a
+// 1617-float row cut into 1024 + 593 keeps 42 % of the second tile's threads idle).  Measured against the tile kernel
+// (profiles/r04_concat_rows_vs_tiles.log): d = 147, H = 11 6.94 -> 6.41-6.56 ms, d = 501, H = 5 10.4 -> 10.0-10.3 ms, equal at
+// d = 147, H = 6 (882 of 1024), 5 % SLOWER at d = 250, H = 4 where the row is exactly one tile -- so it runs where the tiles would
+// be less than 85 % full.  Same loads, same LDS placement, same stores as the tile kernel: bit-identical.
+constexpr int kConcatLds = 8192;                    // floats of LDS per block (32 KB)
+constexpr int kConcatRowCap = 4096;                 // widest row this kernel takes (then 2 rows per block)
+__global__ __launch_bounds__(256) void hop_concat_rows_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
+                                                              const int64_t ldo, const int64_t n, const int d, const int width_w,
+                                                              const int W, const int R) {
+    __shared__ float tile[kConcatLds];
+    const int width = d * n_hops;
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int rows = (int)min<int64_t>(R, n - row0);
+    const int t = threadIdx.x;
+    const int nv = (d + 3) >> 2;                    // aligned 16-byte vectors of one source row
+    for (int i = t; i < rows * (W - width); i += 256) {                  // pad columns: zeros
+        const int r = i / (W - width);
+        tile[r * W + width + (i - r * (W - width))] = 0.f;
+    }
+    // phase 1: (row r, hop h, vector j) -> consecutive threads take consecutive vectors of one source row (coalesced)
+    const int per_row = n_hops * nv;
+    const int total = rows * per_row;
+    constexpr int U = 4;                            // independent loads in flight per thread
+    for (int base = t; base < total; base += 256 * U) {
+        f4 x[U];
+        int o[U], k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 256;
+            x[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            o[u] = -1;
+            k[u] = 0;
+            if (i < total) {
+                const int r = i / per_row;
+                const int rem = i - r * per_row;
+                const int h = rem / nv;
+                const int j = rem - h * nv;
+                x[u] = *reinterpret_cast<const f4 *>(hx.p[h] + (row0 + r) * hx.ld[h] + 4 * j);   // inside the row's 4-float pitch
+                o[u] = r * W + h * d + 4 * j;
+                k[u] = d - 4 * j;                   // floats of this vector that belong to the row (>= 1)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (o[u] >= 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < k[u]) tile[o[u] + e] = x[u][e];
+            }
+    }
+    __syncthreads();
+    // phase 2: (row r, output vector v): aligned 16-byte LDS reads and global stores
+    const int wv = (width_w + 3) >> 2;
+    for (int i = t; i < rows * wv; i += 256) {
+        const int r = i / wv;
+        const int c = (i - r * wv) * 4;
+        float *orow = out + (row0 + r) * ldo;
+        if (c + 4 <= width_w) {
+            *reinterpret_cast<f4 *>(orow + c) = *reinterpret_cast<const f4 *>(&tile[r * W + c]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < width_w) orow[c + e] = tile[r * W + c + e];
+        }
+    }
+}
+
 // The same for ANY d (d % 4 != 0: the hops' segments start at arbitrary 4-byte offsets of the output row): one thread per
 // ALIGNED 16-byte vector of the output row; its four floats are consecutive in one source row except where the vector
 // straddles a hop boundary, so they are fetched with one dword-aligned 16-byte load (legal on gfx950: vector memory
@@ -1375,6 +1445,18 @@ SGL_EXPORT int sgl_hop_concat_padded_f32(int n_hops, const float *const *h_x, co
     if (vec4) {
         const int grid = stream_grid(n * (d / 4) * n_hops);
         hipLaunchKernelGGL((hop_concat_kernel<4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d);
+    } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && out_cols(d * n_hops, pad_cols, INT32_MAX) <= kConcatRowCap &&
+               (sgl::tuning("concat_lds", 1) == 3 ||
+                (sgl::tuning("concat_lds", 1) == 1 &&      // where the 1024-float tiles of the kernel below would be < 85 % full
+                 100 * (int64_t)out_cols(d * n_hops, pad_cols, INT32_MAX) <
+                     85 * (int64_t)kConcatTile * ((out_cols(d * n_hops, pad_cols, INT32_MAX) + kConcatTile - 1) / kConcatTile)))) {
+        // any d, rows of 256 ... 4096 floats: whole rows assembled in LDS, the block's threads share the work flat
+        const int width_w = out_cols(d * n_hops, pad_cols, INT32_MAX);
+        const int W = (width_w + 3) / 4 * 4;
+        const int R = kConcatLds / W;
+        const int64_t blocks = (n + R - 1) / R;
+        if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_concat_f32: too many rows for one launch (shard the matrix)");
+        hipLaunchKernelGGL(hop_concat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d, width_w, W, R);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && sgl::tuning("concat_lds", 1) != 0 &&
                sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((out_cols(d * n_hops, pad_cols, INT32_MAX) + kConcatTile - 1) / kConcatTile), 256)) {
         // any d, long rows: assembled in LDS, every source vector read once

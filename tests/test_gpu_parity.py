@@ -1277,7 +1277,7 @@ def test_aggregators_with_more_than_sixteen_hops(cuda, d):
     assert np.allclose(sc, np.stack([x.astype(np.float64) @ v for x in host], 1), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("d,H", [(147, 6), (147, 11), (501, 5), (65, 16), (257, 4), (86, 3), (85, 3), (1023, 2), (1025, 3)])
+@pytest.mark.parametrize("d,H", [(147, 6), (147, 11), (501, 5), (65, 16), (257, 4), (86, 3), (85, 3), (1023, 2), (1025, 3), (1025, 4), (511, 16)])
 def test_concat_any_width_lds_tiles(cuda, d, H):
     """any-width concat of long rows (assembled in LDS, 1024-float tiles): rows shorter / longer than a tile, hop
     boundaries that fall inside and exactly on tile boundaries, the last partial vector -- bit-equal to numpy's hstack
@@ -1296,12 +1296,13 @@ def test_concat_any_width_lds_tiles(cuda, d, H):
     assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
     # the pad columns of the output's own pitch are written (as zeros): every line of a row is written whole
     assert dev.own_pad(got) == got.stride(0) - d * H and not bool(dev.padded_parent(got)[:, d * H:].any())
-    _lib.set_tuning("concat_lds", 0)
-    try:
-        funnel = dev.hop_concat(feats)
-        assert torch.equal(funnel, got) and not bool(dev.padded_parent(funnel)[:, d * H:].any())
-    finally:
-        _lib.set_tuning("concat_lds", 1)
+    for mode in (0, 2, 3):                                    # funnel-select, 1024-float tiles, whole rows per block: same bits
+        _lib.set_tuning("concat_lds", mode)
+        try:
+            other = dev.hop_concat(feats)
+            assert torch.equal(other, got) and not bool(dev.padded_parent(other)[:, d * H:].any()), mode
+        finally:
+            _lib.set_tuning("concat_lds", 1)
     # the un-suffixed C entry point (pad_cols = 0) touches nothing beyond the row -- an output may be a slice of a wider matrix
     wide = torch.full((n, d * H + 8), 7.0, device=cuda)
     ptrs, lds = _lib.hop_arrays(feats)

@@ -38,6 +38,8 @@ def main():
         _lib.set_tuning("row_narrow_groups", int(os.environ["AGG_NARROW"]))
     if os.environ.get("AGG_WHOLE"):       # 0: row outputs end at column d (a partly written last line), 1: pad columns written too
         _lib.set_tuning("row_whole_lines", int(os.environ["AGG_WHOLE"]))
+    if os.environ.get("AGG_CONCAT"):      # any-width concat: 1 = auto, 2 = 1024-float tiles, 3 = whole rows per block in LDS, 0 = funnel-select kernel
+        _lib.set_tuning("concat_lds", int(os.environ["AGG_CONCAT"]))
     if os.environ.get("AGG_BLOCKS"):
         _lib.set_tuning("agg_blocks", int(os.environ["AGG_BLOCKS"]))
     device = torch.device("cuda", 0)
