@@ -67,11 +67,14 @@ def take(shape, dtype=torch.float32, pinned=True):
         return torch.empty(0, dtype=dtype).set_(st, 0, tuple(int(s) for s in shape))
 
 
-def trim(keep_sizes=()):
+def trim(keep_sizes=(), only_above=0):
     """release every pooled buffer that is not in use (except buckets whose rounded size is in keep_sizes: what the call that just
-    ended used -- the next call of the same shape finds them warm)"""
+    ended used -- the next call of the same shape finds them warm).  only_above: do nothing while the pool holds no more than
+    this many bytes (a caller alternating between two shapes should not re-pin its buffers on every call)"""
     global _pooled_bytes
     with _lock:
+        if _pooled_bytes <= only_above:
+            return
         for size, lst in list(_buckets.items()):
             if size in keep_sizes:
                 continue

@@ -337,8 +337,9 @@ class GraphOp:
             prev = ypad
         side.synchronize()                                # the results are complete when the call returns (reference contract)
         self._phase_done("hops")                          # (the downloads overlap the hops on this path: one phase)
-        # buffers of other shapes that nobody references any more go back to the system; this call's bucket stays warm
-        hostpool.trim(keep_sizes=(hostpool.bucket_size((n, d)),))
+        # once the pool is more than half full, buffers of other shapes that nobody references go back to the system (this call's
+        # bucket stays warm)
+        hostpool.trim(keep_sizes=(hostpool.bucket_size((n, d)),), only_above=hostpool._CAP_BYTES // 2)
         return out
 
 
