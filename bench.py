@@ -121,6 +121,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     job = _Job(args, engine, rank, world, wl)
     guard = None
     line_box = [None]                         # rank 0's JSON line once the timed region is over (the watchdog prints it if later phases hang)
+    timed_done = [False]                      # every rank: the timed region is behind us
     if world > 1 and emit is print and args.watchdog > 0:
         # a rank that fails before a collective leaves the others waiting in it for ever: end the job with a diagnosis
         import threading
@@ -135,7 +136,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
                     os._exit(0)
                 print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "edge\u00b7featdim/s", "n_gpus": world,
                                   "error": f"watchdog: no progress after {args.watchdog:.0f} s", "phase": _PHASE[0]}), flush=True)
-            os._exit(3 if line_box[0] is None else 0)
+            os._exit(0 if timed_done[0] else 3)       # (ranks other than 0 never hold the line: they go by the phase)
         guard = threading.Timer(args.watchdog, stuck)
         guard.daemon = True
         guard.start()
@@ -176,6 +177,7 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     job.sync_all()
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
+    timed_done[0] = True
 
     # ---- the line exists from here on: whatever follows (self-validation, diagnostics, baselines, the papers100M-shaped section)
     # only ADDS to it, and the watchdog prints it as it stands instead of losing a measured value to a stuck collective ------------
