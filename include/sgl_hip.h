@@ -331,6 +331,14 @@ int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, 
 int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
                             int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
                             int64_t d, void *stream);
+/* Weight gradient of the row-dots (the backward of sgl_hop_rowdot_f32 / sgl_hop_rowdot2_f32 / sgl_hop_gate_f32 w.r.t. the Linear's
+ * weight; torch: one transposed GEMV `X_h.t() @ g[:, h]` per hop):  out[h, :] = sum_n W[n * ldw + h * sw] * X_h[n, :]  for every hop in
+ * ONE pass (sw = 1: a weight per row and hop, sw = 0: one per row shared by all hops).  out: [n_hops, ldo] on device, d_scratch:
+ * sgl_hop_colsum_scratch(n_hops, n, d) floats.  Deterministic two-level reduction, no atomics.  n_hops <= 16, d <= 1024, 16-byte
+ * aligned rows, else SGL_ERR_UNSUPPORTED. */
+int64_t sgl_hop_colsum_scratch(int n_hops, int64_t n, int64_t d);
+int sgl_hop_colsum_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw, int sw, float *d_out,
+                       int64_t ldo, float *d_scratch, int64_t n, int64_t d, void *stream);
 /* Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in one pass over the hop list:
  *   P[n, h - h0] = <X_h[n], vec>  for h in [h0, h1);   A[n] = sum over the hops j with bit j of u_mask set of <X_j[n], U[j, :]>
  * (the reference concatenates [ref || x_h] with ref = feat_list[0] or hstack(feat_list) and applies one Linear: the ref part is

@@ -85,6 +85,9 @@ PROTOTYPES = {
                                  c_int64, c_int64, c_int64, c_void_p]),
     "sgl_hop_rowdot2_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_int, c_int, c_void_p,
                                     c_int64, c_void_p, c_int64, c_int64, c_void_p]),
+    "sgl_hop_colsum_scratch": (c_int64, [c_int, c_int64, c_int64]),
+    "sgl_hop_colsum_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                   c_void_p]),
     "sgl_hop_wsum1d_bwd_scratch": (c_int64, [c_int]),
     "sgl_hop_wsum1d_bwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                        c_int64, c_void_p]),

@@ -1066,6 +1066,90 @@ __global__ __launch_bounds__(64) void hop_dot_final_kernel(const float *__restri
     if (threadIdx.x == 0) dw[h] = acc;
 }
 
+// Column sums of the hops weighted per row:  out[h, :] = sum_n W[n, h] * X_h[n, :]  (sw = 1) or sum_n W[n] * X_h[n, :] (sw = 0).
+// This is the weight gradient of every row-dot -- dv = X_h^T g[:, h] of the gate / jk / ori_ref scores -- which torch evaluates
+// as one transposed GEMV per hop: 0.46 ms EACH for a [50 000, 147] batch slice on its padded pitch (rocBLAS gemvn: 64 GB/s),
+// 5.5 of the 8.4 ms of a GAMLP training step (profiles/r04_train_step.log).  Here: one streaming pass over all hops, 16 bytes per
+// lane, per-thread partial rows in registers, a fixed two-level reduction (row lanes through LDS in lane order, then the blocks in
+// block order): deterministic, no atomics.
+template <int HMAX>
+__global__ __launch_bounds__(256) void hop_colsum_partial_kernel(const Hops hx, const int n_hops, const float *__restrict__ w,
+                                                                 const int64_t ldw, const int sw, float *__restrict__ scratch,
+                                                                 const int64_t n, const int d, const int slots,
+                                                                 const int64_t per_block) {
+    __shared__ f4 red[256];
+    const int t = threadIdx.x;
+    const int rl_count = 256 / slots;               // rows a block takes per iteration
+    const int slot = t % slots, rl = t / slots;
+    const bool lane_on = rl < rl_count;
+    const int64_t r0 = (int64_t)blockIdx.x * per_block, r1 = min(r0 + per_block, n);
+    f4 acc[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) acc[h] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (lane_on) {
+#pragma unroll 1
+        for (int64_t r = r0 + rl; r < r1; r += rl_count) {
+#pragma unroll
+            for (int hb = 0; hb < HMAX; hb += 4) {      // four hop loads in flight at a time: the accumulators are what stays
+                f4 x[4];
+                float wv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (hb + q < n_hops) {
+                        x[q] = load_masked<4, true>(hx.p[hb + q] + r * hx.ld[hb + q], slot * 4, d);
+                        wv[q] = w[r * ldw + (int64_t)(hb + q) * sw];
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (hb + q < n_hops) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[hb + q][e] = __builtin_fmaf(wv[q], x[q][e], acc[hb + q][e]);
+                    }
+            }
+        }
+    }
+    const int dp = slots * 4;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        if (h < n_hops) {
+            red[t] = acc[h];
+            __syncthreads();
+            if (rl == 0) {
+                f4 s = red[slot];
+                for (int q = 1; q < rl_count; ++q) {
+                    const f4 o = red[q * slots + slot];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] += o[e];
+                }
+                *reinterpret_cast<f4 *>(scratch + ((int64_t)blockIdx.x * n_hops + h) * dp + slot * 4) = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// second level: one wavefront per (hop, 16-byte column slot): lane l adds the partials of blocks l, l + 64, ... in that order, a fixed
+// butterfly folds the 64 lanes -- deterministic for a given block count (one thread per column walking all ~1000 partials one
+// after the other took three times as long as the streaming first level)
+__global__ __launch_bounds__(64) void hop_colsum_final_kernel(const float *__restrict__ scratch, const int n_blocks, const int n_hops,
+                                                              const int slots, float *__restrict__ out, const int64_t ldo, const int d) {
+    const int h = blockIdx.x / slots, slot = blockIdx.x - h * slots;
+    const int dp = slots * 4;
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < n_blocks; b += 64) {
+        const f4 o = *reinterpret_cast<const f4 *>(scratch + ((int64_t)b * n_hops + h) * dp + slot * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += o[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = group_sum<64>(s[e]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (slot * 4 + e < d) out[(int64_t)h * ldo + slot * 4 + e] = s[e];
+    }
+}
+
 bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 template <typename H>
@@ -1681,5 +1765,56 @@ SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const in
 #undef SGL_R2_H
 #undef SGL_R2
     SGL_LAUNCH_CHECK("sgl_hop_rowdot2_f32");
+    return SGL_OK;
+}
+
+// ---- weight gradients of the row-dots ----------------------------------------------------------------------------------------
+constexpr int kColsumBlocks = 1024;
+static int64_t colsum_per_block(int64_t n, int slots) {
+    const int64_t rl = 256 / slots;
+    int64_t per = (n + kColsumBlocks - 1) / kColsumBlocks;
+    per = std::max<int64_t>(per, rl * 4);
+    return (per + rl - 1) / rl * rl;
+}
+
+SGL_EXPORT int64_t sgl_hop_colsum_scratch(int n_hops, int64_t n, int64_t d) {
+    if (n_hops < 1 || n < 0 || d < 1 || d > 1024) return 0;
+    const int slots = (int)((d + 3) / 4);
+    const int64_t per = colsum_per_block(n, slots);
+    const int64_t blocks = std::max<int64_t>(1, (n + per - 1) / per);
+    return blocks * n_hops * slots * 4;
+}
+
+SGL_EXPORT int sgl_hop_colsum_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_w, int64_t ldw, int sw,
+                                  float *d_out, int64_t ldo, float *d_scratch, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_colsum_f32: bad sizes");
+    Hops hx;
+    bool vec4 = true;
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    SGL_REQUIRE(d_out && ldo >= d, "sgl_hop_colsum_f32: bad output");
+    SGL_REQUIRE(sw == 0 || sw == 1, "sgl_hop_colsum_f32: sw must be 0 (one weight per row) or 1 (one per row and hop)");
+    hipStream_t st = sgl::as_stream(stream);
+    if (d == 0) return SGL_OK;
+    if (n == 0) {
+        SGL_HIP_CHECK(hipMemset2DAsync(d_out, ldo * sizeof(float), 0, d * sizeof(float), n_hops, st));
+        return SGL_OK;
+    }
+    SGL_REQUIRE(d_w && (sw == 0 || ldw >= n_hops) && ldw >= 1, "sgl_hop_colsum_f32: bad weights");
+    if (!(vec4 && n_hops <= 16 && d <= 1024))
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_colsum_f32: needs <= 16 hops, d <= 1024 and 16-byte aligned rows");
+    SGL_REQUIRE(d_scratch, "sgl_hop_colsum_f32: NULL scratch (sgl_hop_colsum_scratch floats)");
+    const int slots = (int)((d + 3) / 4);
+    const int64_t per = colsum_per_block(n, slots);
+    const int blocks = (int)std::max<int64_t>(1, (n + per - 1) / per);
+#define SGL_CS(HM) hipLaunchKernelGGL((hop_colsum_partial_kernel<HM>), dim3(blocks), dim3(256), 0, st, hx, n_hops, d_w, ldw, sw, d_scratch, n, (int)d, slots, per)
+    if (n_hops <= 4) SGL_CS(4);
+    else if (n_hops <= 8) SGL_CS(8);
+    else if (n_hops <= 12) SGL_CS(12);
+    else SGL_CS(16);
+#undef SGL_CS
+    SGL_LAUNCH_CHECK("sgl_hop_colsum_f32(partial)");
+    hipLaunchKernelGGL(hop_colsum_final_kernel, dim3(n_hops * slots), dim3(64), 0, st, d_scratch, blocks, n_hops, slots, d_out, ldo, (int)d);
+    SGL_LAUNCH_CHECK("sgl_hop_colsum_f32(final)");
     return SGL_OK;
 }

@@ -1238,6 +1238,33 @@ def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
         assert float((fx[h].grad.double() - f64[h].grad).abs().max()) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("n,d,H", [(50_000, 147, 6), (3000, 128, 11), (777, 100, 4), (5, 7, 3), (1, 500, 2), (4099, 1024, 16), (300, 36, 1)])
+def test_hop_colsum_is_the_weight_gradient_of_the_row_dots(cuda, n, d, H):
+    """sgl_hop_colsum_f32: out[h] = sum_n w[n, h] X_h[n, :] (and with one weight per row shared by all hops) -- what torch computes
+    as one transposed GEMV per hop in the backward of the gate / jk / ori_ref scores -- against float64, deterministic, and the
+    fallback for hops the kernel cannot take gives the same answer"""
+    from sgl_amd import device as dev
+    g = torch.Generator(device="cpu").manual_seed(n + d + H)
+    feats = []
+    for _ in range(H):
+        t = dev.alloc_rows(n, d, cuda)
+        t.copy_(torch.randn(n, d, generator=g))
+        feats.append(t)
+    w = torch.randn(n, H, generator=g).to(cuda)
+    ws = torch.randn(n, generator=g).to(cuda)
+    got, got_s = dev.hop_colsum(feats, w), dev.hop_colsum(feats, ws, shared=True)
+    assert got.shape == (H, d) and got_s.shape == (H, d)
+    want = torch.stack([f.double().t() @ w[:, h].double() for h, f in enumerate(feats)])
+    want_s = torch.stack([f.double().t() @ ws.double() for f in feats])
+    mag = torch.stack([f.double().abs().t() @ w[:, h].double().abs() for h, f in enumerate(feats)]).clamp_min(1e-30)
+    mag_s = torch.stack([f.double().abs().t() @ ws.double().abs() for f in feats]).clamp_min(1e-30)
+    assert float(((got.double() - want).abs() / mag).max()) <= 2e-6 and float(((got_s.double() - want_s).abs() / mag_s).max()) <= 2e-6
+    assert torch.equal(dev.hop_colsum(feats, w), got)                                    # no atomics: run-to-run identical
+    dense = [f.contiguous().clone() for f in feats]                                      # [n, d] rows at 4-byte alignment for odd d
+    alt = dev.hop_colsum(dense, w)
+    assert float(((alt.double() - want).abs() / mag).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("d", [100, 13])
 def test_aggregators_with_more_than_sixteen_hops(cuda, d):
     """21 hop matrices (a 20-hop NAFS run): beyond the register-resident kernels' 16-hop limit every aggregator must take
