@@ -331,6 +331,26 @@ int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, 
 int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
                             int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
                             int64_t d, void *stream);
+/* Recursive gate in one pass (IterateLearnableWeightedMessageOp 'recursive', message_op/iterate_learnable_weighted_message_op.py:28-51;
+ * GAMLP-R, models/homo/gamlp_recursive.py:7-13).  The reference walks the hops: step i scores sigmoid(Linear([X_i || acc])), appends
+ * the score to the weights of the steps before, soft-maxes all of them (the earlier ones again) and rebuilds acc = sum_j W[:, j] X_j.
+ * acc is a per-row weighted sum of the hops, so with A[n,h] = <X_h[n], w_x> and C[n,h] = <X_h[n], w_acc>
+ *     Linear([X_i || acc_{i-1}])[n] = A[n,i] + sum_{j<i} W_{i-1}[n,j] C[n,j] + bias
+ * and the recursion runs on the 2 H scalars of a row while its hop rows sit in registers; out[n] = sum_h W[n,h] X_h[n] with the final
+ * weights.  Every hop element is read once (step by step: H (H + 3) / 2 reads of a hop matrix, H accumulator writes).
+ * d_vec: [w_x | w_acc], each zero-padded to round_up(d, 4) floats, 16-byte aligned; bias = NaN: read from d_vec[2 * round_up(d, 4)].
+ * pad_cols: as in the *_padded_f32 entry points above.  d_w_out / d_a_out / d_c_out (optional, [n, n_hops]) receive W, A and C (all the
+ * backward needs besides the hops).  Register-resident rows: n_hops <= 16, d <= 512, 16-byte aligned rows -- otherwise
+ * SGL_ERR_UNSUPPORTED (callers then use two sgl_hop_rowdot_f32 passes, the [n, H] recursion on the host side, sgl_hop_wsum2d_f32). */
+int sgl_hop_recursive_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
+                          int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_a_out, int64_t lda, float *d_c_out,
+                          int64_t ldc, int64_t n, int64_t d, void *stream);
+/* Backward of the [n, n_hops] recursion of sgl_hop_recursive_f32: from A, C, the bias (NaN: *d_bias on the device) and G = dL/dW to
+ * dA, dC [n, n_hops] and dB [n] (per row; sum it for the Linear's bias gradient).  One thread per row; any output may be NULL.
+ * The Linear's weight gradient follows as [sum_h colsum(X_h, dA[:, h]) | sum_h colsum(X_h, dC[:, h])] (sgl_hop_colsum_f32). */
+int sgl_hop_recursive_bwd_f32(int n_hops, const float *d_a, int64_t lda, const float *d_c, int64_t ldc, float bias, const float *d_bias,
+                              const float *d_gw, int64_t ldg, float *d_da, int64_t ldda, float *d_dc, int64_t lddc, float *d_db,
+                              int64_t n, void *stream);
 /* Weight gradient of the row-dots (the backward of sgl_hop_rowdot_f32 / sgl_hop_rowdot2_f32 / sgl_hop_gate_f32 w.r.t. the Linear's
  * weight; torch: one transposed GEMV `X_h.t() @ g[:, h]` per hop):  out[h, :] = sum_n W[n * ldw + h * sw] * X_h[n, :]  for every hop in
  * ONE pass (sw = 1: a weight per row and hop, sw = 0: one per row shared by all hops).  out: [n_hops, ldo] on device, d_scratch:

@@ -99,6 +99,10 @@ PROTOTYPES = {
                                     c_void_p]),
     "sgl_hop_gate_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_hop_recursive_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "sgl_hop_recursive_bwd_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p,
+                                          c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
     "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

@@ -340,6 +340,10 @@ __global__ __launch_bounds__(256) void nafs_weight_kernel(const Hops hx, const i
 // wavefront of occupancy and ~4 % at d = 128, H = 11).  Only where that does not spill (groups of >= 16 lanes).
 #define GATE_MIN_BLOCKS(LPR, HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((CH) == 1 && (HMAX) <= 12 && (LPR) >= 16) ? 7 : ROWREG_MIN_BLOCKS(HMAX, CH)))
 
+// the recursive gate carries a second vector and two scalars per hop: 5 waves per SIMD (<= 96 VGPRs; 6 spill at 12) up to 12 hop vectors without
+// spilling; its array form (more hops than lanes in a group: 8-lane groups only) keeps three scalars per hop and gets 2
+#define RECUR_MIN_BLOCKS(LPR, HMAX, CH) (((HMAX) * (CH) <= 8) ? 8 : (((HMAX) > (LPR)) ? 2 : (((CH) == 1 && (HMAX) <= 12 && (LPR) >= 16) ? 5 : ROWREG_MIN_BLOCKS(HMAX, CH))))
+
 // ---- lanes x chunks of a register-resident row kernel ------------------------------------------------------------------------
 // A row of d floats is ceil(d / 4) 16-byte slots; LPR lanes take CH slots each (slot (c * LPR + l) of the row for lane l, chunk c),
 // 64 / LPR rows per wavefront.  Power-of-two groups leave slots idle when the row is not a power of two wide, and idle slots still
@@ -646,6 +650,225 @@ __global__ __launch_bounds__(256, GATE_MIN_BLOCKS(LPR, HMAX, CH)) void gate_fuse
             }
     }
     store_row<LPR, CH>(out + r * ldo, acc, l, live, d, dw);
+}
+
+__device__ __forceinline__ float fast_exp(const float x) { return __builtin_amdgcn_exp2f(__fmul_rn(x, 1.4426950408889634f)); }
+__device__ __forceinline__ float fast_sigmoid(const float x) { return __builtin_amdgcn_rcpf(__fadd_rn(1.f, fast_exp(-x))); }
+
+// Fused recursive gate (IterateLearnableWeightedMessageOp 'recursive', iterate_learnable_weighted_message_op.py:28-51; GAMLP-R).
+// The reference walks the hops: step i scores Linear([X_i || acc]) -> sigmoid, appends it to the (already soft-maxed) weights of
+// the steps before, soft-maxes all i + 1 of them again and rebuilds acc = sum_j w_j X_j -- H (H + 3) / 2 reads of a hop matrix
+// and H accumulator writes.  The recursion is local to a row and acc is always a weighted sum of that row's hops, so
+//     Linear([X_i || acc_{i-1}]) = a_i + sum_{j < i} w_j c_j + b,      a_h = <X_h, w_x>,  c_h = <X_h, w_acc>
+// and with the hop rows in registers the whole operator is ONE pass: 2 H row-dots, the recursion on the H scalar pairs (lane h of
+// the row's group owns hop h, see "one hop per lane"; the reductions over hops stay inside one 16-lane DPP row), the final
+// weighted sum.  vec = [w_x | w_acc], each zero-padded to whole float4 (dv floats apart).  wout / aout / cout [n, H]: the final
+// weights and the two score matrices, which is all the backward needs besides the hops.
+template <int LPR, int CH, int HMAX>
+__global__ __launch_bounds__(256, RECUR_MIN_BLOCKS(LPR, HMAX, CH)) void recursive_fused_kernel(const Hops hx, const int n_hops, const float *__restrict__ vec, const int dv,
+                                                              const float bias_arg, const float *__restrict__ bias_ptr,
+                                                              float *__restrict__ out, const int64_t ldo,
+                                                              float *__restrict__ wout, const int64_t ldw, float *__restrict__ aout,
+                                                              const int64_t lda, float *__restrict__ cout, const int64_t ldc,
+                                                              const int64_t n, const int d, const int dw) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    const float bias = bias_ptr ? *bias_ptr : bias_arg;
+    f4 x[HMAX][CH], vx[CH], va[CH];
+    bool on[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 4;
+        on[c] = live && col < d;
+        vx[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+        va[c] = (col < d) ? load_masked<4>(vec + dv, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
+    f4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMAX <= LPR) {
+        constexpr int SL = LPR < 16 ? LPR : 16;          // the hop lanes 0 .. H-1 of a group lie in its first DPP row
+        float al = 0.f, cl = 0.f;
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            float sa = 0.f, sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sa = __builtin_fmaf(vx[c][e], x[h][c][e], sa);
+                    sc = __builtin_fmaf(va[c][e], x[h][c][e], sc);
+                }
+            sa = group_sum<LPR>(sa);
+            sc = group_sum<LPR>(sc);
+            al = (l == h) ? sa : al;
+            cl = (l == h) ? sc : cl;
+        }
+        float wl = (l == 0) ? 1.f : 0.f;                 // step 0: the soft-max of one score
+        // One step = ~25 VALU instructions per wavefront: every lane evaluates the sigmoid with ITS a_l (only lane i's is used, so
+        // a_i is never broadcast), the soft-max runs without the max subtraction (its inputs are soft-max weights and a sigmoid,
+        // all in (0, 1)) and exp / reciprocal are the hardware's v_exp_f32 / v_rcp_f32 (1 ulp): with IEEE divisions, expf and the
+        // max the recursion alone was ~55 instructions per step and the kernel VALU-issue-bound at 11 hops.
+#pragma unroll
+        for (int i = 1; i < HMAX; ++i)
+            if (i < n_hops) {
+                const float t = group_sum<SL>((l < i) ? __fmul_rn(wl, cl) : 0.f);          // <acc_{i-1}, w_acc>
+                const float s = fast_sigmoid(__fadd_rn(__fadd_rn(al, t), bias));
+                const float ex = (l < i) ? fast_exp(wl) : ((l == i) ? fast_exp(s) : 0.f);
+                const float sum = group_sum<SL>(ex);     // its own statement: a cross-lane reduction inside an arm of ?: runs only
+                                                         // in the lanes that take the arm, and a butterfly with idle lanes is wrong
+                wl = (l <= i) ? __fmul_rn(ex, __builtin_amdgcn_rcpf(sum)) : 0.f;   // (lanes beyond the first DPP row sum zeros)
+            }
+        if (live && l < n_hops) {
+            if (wout) wout[r * ldw + l] = wl;
+            if (aout) aout[r * lda + l] = al;
+            if (cout) cout[r * ldc + l] = cl;
+        }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                const float w = from_lane<LPR>(wl, h);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w, x[h][c][e], acc[c][e]);
+            }
+    } else {
+        float a[HMAX], cc[HMAX], w[HMAX];
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            float sa = 0.f, sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sa = __builtin_fmaf(vx[c][e], x[h][c][e], sa);
+                    sc = __builtin_fmaf(va[c][e], x[h][c][e], sc);
+                }
+            a[h] = group_sum<LPR>(sa);
+            cc[h] = group_sum<LPR>(sc);
+            w[h] = 0.f;
+        }
+        w[0] = 1.f;
+#pragma unroll
+        for (int i = 1; i < HMAX; ++i)
+            if (i < n_hops) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < i; ++j) t = __fadd_rn(t, __fmul_rn(w[j], cc[j]));
+                const float s = fast_sigmoid(__fadd_rn(__fadd_rn(a[i], t), bias));
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < i; ++j) {
+                    w[j] = fast_exp(w[j]);
+                    sum += w[j];
+                }
+                w[i] = fast_exp(s);
+                sum += w[i];
+                const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                for (int j = 0; j <= i; ++j) w[j] = __fmul_rn(w[j], inv);
+            }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            if (h < n_hops) {
+                if (live && l == 0) {
+                    if (wout) wout[r * ldw + h] = w[h];
+                    if (aout) aout[r * lda + h] = a[h];
+                    if (cout) cout[r * ldc + h] = cc[h];
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(w[h], x[h][c][e], acc[c][e]);
+            }
+    }
+    store_row<LPR, CH>(out + r * ldo, acc, l, live, d, dw);
+}
+
+// Backward of the recursion above on the per-hop scalars: given A, C [n, H], the bias and G = dL/dW (W = the final weights), one
+// thread per row re-runs the H - 1 steps keeping every step's weights, then walks them backwards:
+//   step i:  z = [w^{i-1}_0 .. w^{i-1}_{i-1}, s_i],  s_i = sigmoid(a_i + sum_{j<i} w^{i-1}_j c_j + b),  w^i = softmax(z)
+//   back  :  gz_k = w^i_k (gw_k - sum_m gw_m w^i_m);  p = gz_i s_i (1 - s_i);  da_i = p;  db += p;
+//            dc_j += p w^{i-1}_j,  gw_j <- gz_j + p c_j   (j < i)
+// (torch autograd over the same [n, H] recursion is ~140 launches of [n, H]-sized kernels per training step.)
+template <int HMAX>
+__global__ __launch_bounds__(256) void recursive_scalar_bwd_kernel(const int n_hops, const float *__restrict__ a, const int64_t lda,
+                                                                   const float *__restrict__ c, const int64_t ldc, const float bias_arg,
+                                                                   const float *__restrict__ bias_ptr, const float *__restrict__ g,
+                                                                   const int64_t ldg, float *__restrict__ da, const int64_t ldda,
+                                                                   float *__restrict__ dc, const int64_t lddc, float *__restrict__ db,
+                                                                   const int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float bias = bias_ptr ? *bias_ptr : bias_arg;
+    float av[HMAX], cv[HMAX], gw[HMAX], dcv[HMAX], sv[HMAX];
+    float hist[HMAX][HMAX];                               // hist[i][k] = w^i_k, k <= i
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        const bool in = h < n_hops;
+        av[h] = in ? a[r * lda + h] : 0.f;
+        cv[h] = in ? c[r * ldc + h] : 0.f;
+        gw[h] = in ? g[r * ldg + h] : 0.f;
+        dcv[h] = 0.f;
+        sv[h] = 0.f;
+    }
+    hist[0][0] = 1.f;
+#pragma unroll
+    for (int i = 1; i < HMAX; ++i)
+        if (i < n_hops) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < i; ++j) t = __fadd_rn(t, __fmul_rn(hist[i - 1][j], cv[j]));
+            const float s = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-__fadd_rn(__fadd_rn(av[i], t), bias))));
+            sv[i] = s;
+            float m = s;
+#pragma unroll
+            for (int j = 0; j < i; ++j) m = fmaxf(m, hist[i - 1][j]);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                hist[i][j] = expf(hist[i - 1][j] - m);
+                sum += hist[i][j];
+            }
+            hist[i][i] = expf(s - m);
+            sum += hist[i][i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) hist[i][j] = __fdiv_rn(hist[i][j], sum);
+        }
+    float dbr = 0.f;
+#pragma unroll
+    for (int i = HMAX - 1; i >= 1; --i)
+        if (i < n_hops) {
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) dot += gw[k] * hist[i][k];
+            const float p = hist[i][i] * (gw[i] - dot) * sv[i] * (1.f - sv[i]);
+            if (da) da[r * ldda + i] = p;
+            dbr += p;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const float gz = hist[i][j] * (gw[j] - dot);
+                dcv[j] += p * hist[i - 1][j];
+                gw[j] = gz + p * cv[j];
+            }
+        }
+    if (da) da[r * ldda] = 0.f;                           // step 0 is the soft-max of ONE score: a_0 never reaches the weights
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+        if (dc && h < n_hops) dc[r * lddc + h] = dcv[h];
+    if (db) db[r] = dbr;
 }
 
 // Scores of the 'ori_ref' / 'jk' gates (learnable_weighted_messahe_op.py:73-86) in ONE pass over the hop list:
@@ -1732,6 +1955,71 @@ SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64
                                 float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
                                 int64_t d, void *stream) {
     return sgl_hop_gate_padded_f32(n_hops, h_x, h_ldx, d_vec, bias, d_out, ldo, 0, d_w_out, ldw, d_g_out, ldg, n, d, stream);
+}
+
+// GAMLP-R's recursive gate in one pass (recursive_fused_kernel).  d_vec: [w_x | w_acc], each zero-padded to round_up(d, 4)
+// floats; bias as in sgl_hop_gate_f32 (NaN: the float right after the two padded vectors).  pad_cols as in the *_padded_f32 entries.
+SGL_EXPORT int sgl_hop_recursive_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
+                                     float *d_out, int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_a_out,
+                                     int64_t lda, float *d_c_out, int64_t ldc, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_recursive_f32: bad sizes");
+    {
+        const int prc = check_pad("sgl_hop_recursive_f32", d, pad_cols, ldo);
+        if (prc != SGL_OK) return prc;
+    }
+    Hops hx;
+    bool vec4 = aligned_to(d_vec, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_vec && d_out && ldo >= d, "sgl_hop_recursive_f32: bad arguments");
+    SGL_REQUIRE((!d_w_out || ldw >= n_hops) && (!d_a_out || lda >= n_hops) && (!d_c_out || ldc >= n_hops),
+                "sgl_hop_recursive_f32: bad weight / score buffers");
+    if (!(vec4 && n_hops <= 16 && d <= 512 && ldo % 4 == 0 && aligned_to(d_out, 16)))
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_recursive_f32: needs <= 16 hops, d <= 512 and 16-byte aligned rows (use the step-by-step route)");
+    hipStream_t st = sgl::as_stream(stream);
+    const RowLayout lay = pick_row_layout(d, n_hops);
+    const int64_t blocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_recursive_f32: too many rows for one launch (shard the matrix)");
+    const int dv = (int)((d + 3) / 4 * 4);
+    const float *bias_ptr = (bias != bias) ? d_vec + 2 * dv : nullptr;
+#define SGL_RF(L, C, HM) \
+    hipLaunchKernelGGL((recursive_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, dv, bias, bias_ptr, d_out, ldo, d_w_out, ldw, d_a_out, lda, d_c_out, ldc, n, (int)d, out_cols(d, pad_cols, (L) * (C) * 4))
+#define SGL_RF_H(L, C) SGL_HOPS_UP_TO_16(SGL_RF, L, C)
+#define SGL_RF_H12(L, C) SGL_HOPS_UP_TO_12(SGL_RF, L, C)
+#define SGL_RF_H6(L, C) (void)0          /* 8 x 5 is never chosen for this kernel (pick_row_layout) */
+    SGL_ROWREG_DISPATCH(SGL_RF_H, SGL_RF_H12, SGL_RF_H6, lay);
+#undef SGL_RF_H6
+#undef SGL_RF_H12
+#undef SGL_RF_H
+#undef SGL_RF
+    SGL_LAUNCH_CHECK("sgl_hop_recursive_f32");
+    return SGL_OK;
+}
+
+// backward of the [n, H] recursion of sgl_hop_recursive_f32 (recursive_scalar_bwd_kernel): dA, dC [n, H] and the per-row bias
+// gradient dB [n] (its sum is the Linear's bias gradient; summed by the caller so the result does not depend on a launch shape)
+SGL_EXPORT int sgl_hop_recursive_bwd_f32(int n_hops, const float *d_a, int64_t lda, const float *d_c, int64_t ldc, float bias,
+                                         const float *d_bias, const float *d_gw, int64_t ldg, float *d_da, int64_t ldda,
+                                         float *d_dc, int64_t lddc, float *d_db, int64_t n, void *stream) {
+    SGL_REQUIRE(n >= 0 && n_hops >= 1 && n_hops <= 16, "sgl_hop_recursive_bwd_f32: 1 <= n_hops <= 16");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_a && d_c && d_gw && lda >= n_hops && ldc >= n_hops && ldg >= n_hops, "sgl_hop_recursive_bwd_f32: bad score / gradient matrices");
+    SGL_REQUIRE((!d_da || ldda >= n_hops) && (!d_dc || lddc >= n_hops), "sgl_hop_recursive_bwd_f32: bad output matrices");
+    SGL_REQUIRE(bias == bias || d_bias, "sgl_hop_recursive_bwd_f32: bias = NaN needs the device bias");
+    hipStream_t st = sgl::as_stream(stream);
+    const int64_t blocks = (n + 255) / 256;
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_recursive_bwd_f32: too many rows for one launch");
+    const float *bias_ptr = (bias != bias) ? d_bias : nullptr;
+#define SGL_RB(HM) \
+    hipLaunchKernelGGL((recursive_scalar_bwd_kernel<HM>), dim3((unsigned)blocks), dim3(256), 0, st, n_hops, d_a, lda, d_c, ldc, bias, bias_ptr, d_gw, ldg, d_da, ldda, d_dc, lddc, d_db, n)
+    if (n_hops <= 4) SGL_RB(4);
+    else if (n_hops <= 8) SGL_RB(8);
+    else if (n_hops <= 12) SGL_RB(12);
+    else SGL_RB(16);
+#undef SGL_RB
+    SGL_LAUNCH_CHECK("sgl_hop_recursive_bwd_f32");
+    return SGL_OK;
 }
 
 SGL_EXPORT int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_u, int64_t ldu,

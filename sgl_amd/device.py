@@ -7,6 +7,7 @@ from ctypes import c_int64, c_void_p
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check, current_stream_ptr, lib, ptr
@@ -771,6 +772,23 @@ def _padded_vec(v, d, device, tail=None):
     return vp
 
 
+def _gate_launch(v, b, feats_d, outputs):
+    """sgl_hop_gate_padded_f32 over detached hops; outputs: also write W and G [n, H] (training / return_weights) -> (out, W, G)"""
+    _check_hops(feats_d)
+    n, d = feats_d[0].shape
+    H = len(feats_d)
+    dev_ = feats_d[0].device
+    vp = _padded_vec(v, d, dev_, tail=b)                  # [v | 0-pad | bias]: bias = NaN below = "read it from the device"
+    result = alloc_rows(n, d, dev_)
+    w, g = ((torch.empty((n, H), dtype=torch.float32, device=dev_) for _ in range(2)) if outputs else (None, None))
+    ptrs, lds = _lib.hop_arrays(feats_d)
+    with torch.cuda.device(dev_):
+        check(lib().sgl_hop_gate_padded_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), own_pad(result),
+                                            ptr(w) if outputs else None, H, ptr(g) if outputs else None, H, n, d,
+                                            current_stream_ptr()), "sgl_hop_gate_padded_f32")
+    return result, w, g
+
+
 class _GateFused(torch.autograd.Function):
     """out = sum_h softmax_h(sigmoid(<X_h, v> + b)) X_h in ONE pass over the hops (sgl_hop_gate_f32); the backward re-uses the
     dW row-dot kernel and finishes the [n, H]-sized softmax / sigmoid chain in torch."""
@@ -778,18 +796,7 @@ class _GateFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, b, *feats):
         feats_d = [f.detach() for f in feats]
-        _check_hops(feats_d)
-        n, d = feats_d[0].shape
-        H = len(feats_d)
-        dev_ = feats_d[0].device
-        vp = _padded_vec(v, d, dev_, tail=b)                  # [v | 0-pad | bias]: bias = NaN below = "read it from the device"
-        result = alloc_rows(n, d, dev_)
-        w = torch.empty((n, H), dtype=torch.float32, device=dev_)
-        g = torch.empty((n, H), dtype=torch.float32, device=dev_)
-        ptrs, lds = _lib.hop_arrays(feats_d)
-        with torch.cuda.device(dev_):
-            check(lib().sgl_hop_gate_padded_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), own_pad(result), ptr(w), H,
-                                                ptr(g), H, n, d, current_stream_ptr()), "sgl_hop_gate_padded_f32")
+        result, w, g = _gate_launch(v, b, feats_d, True)
         ctx.save_for_backward(v.detach(), w, g, *feats_d)
         ctx.b_shape = tuple(b.shape)
         ctx.mark_non_differentiable(w)
@@ -826,9 +833,110 @@ def hop_gate(feats, v, b, return_weights=False):
     (sgl_hop_gate_f32) when their rows fit the register-resident kernel (gate_fusable); otherwise the two-pass route -- one
     row-dot pass for the scores, the [n, H] sigmoid / softmax in torch, one weighted-sum pass."""
     if gate_fusable(feats):
-        out, w = _GateFused.apply(v, b, *feats)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (v, b, *feats)):
+            out, w = _GateFused.apply(v, b, *feats)
+        else:                                             # inference: the [n, H] matrices are written only when asked for
+            out, w, _ = _gate_launch(v, b, [f.detach() for f in feats], return_weights)
     else:
         w = torch.softmax(torch.sigmoid(hop_scores(feats, v) + b.reshape(-1)[0]), dim=1)
+        out = hop_wsum2d(feats, w)
+    return (out, w) if return_weights else out
+
+
+def recursive_weights(a, c, b):
+    """The recursion of IterateLearnableWeightedMessageOp (iterate_learnable_weighted_message_op.py:35-41) on per-hop scalars:
+    a[n, h] = <X_h, w_x>, c[n, h] = <X_h, w_acc>, b the Linear's bias -> the final soft-max weights [n, H].  acc is always a
+    per-row weighted sum of the hops, so <acc_{i-1}, w_acc> = sum_{j<i} W[:, j] c[:, j]; plain torch, differentiable."""
+    H = a.shape[1]
+    dot_acc = c[:, 0]                                    # acc starts as X_0
+    weights = None
+    for i in range(H):
+        score = torch.sigmoid(a[:, i] + dot_acc + b).unsqueeze(1)
+        weights = score if weights is None else torch.hstack((weights, score))
+        weights = F.softmax(weights, dim=1)              # the earlier columns are soft-maxed again (reference :39 -- kept)
+        if i + 1 < H:
+            dot_acc = (weights * c[:, :i + 1]).sum(dim=1)
+    return weights
+
+
+def _recursive_launch(weight, b, feats_d, outputs):
+    """sgl_hop_recursive_f32 over detached hops; outputs: also write W, A, C [n, H] (training / return_weights) -> (out, vp, W, A, C)"""
+    _check_hops(feats_d)
+    n, d = feats_d[0].shape
+    H = len(feats_d)
+    dev_ = feats_d[0].device
+    dp = round_up(d, 4)
+    wt = weight.detach().to(device=dev_, dtype=torch.float32).reshape(-1)
+    if wt.numel() != 2 * d:
+        raise ValueError(f"the recursive gate's Linear has {wt.numel()} weights, the hops need 2 * {d}")
+    vp = torch.zeros(2 * dp + 4, dtype=torch.float32, device=dev_)          # [w_x | pad | w_acc | pad | bias]
+    vp[:d] = wt[:d]
+    vp[dp:dp + d] = wt[d:]
+    vp[2 * dp:2 * dp + 1] = b.detach().to(device=dev_, dtype=torch.float32).reshape(-1)[:1]
+    result = alloc_rows(n, d, dev_)
+    w, a, c = ((torch.empty((n, H), dtype=torch.float32, device=dev_) for _ in range(3)) if outputs else (None, None, None))
+    ptrs, lds = _lib.hop_arrays(feats_d)
+    with torch.cuda.device(dev_):
+        # bias = NaN: "read it from the device, after the two padded vectors" (no host synchronisation on a parameter)
+        check(lib().sgl_hop_recursive_f32(H, ptrs, lds, ptr(vp), float("nan"), ptr(result), _ld(result), own_pad(result),
+                                          ptr(w) if outputs else None, H, ptr(a) if outputs else None, H,
+                                          ptr(c) if outputs else None, H, n, d, current_stream_ptr()), "sgl_hop_recursive_f32")
+    return result, vp, w, a, c
+
+
+class _RecursiveFused(torch.autograd.Function):
+    """GAMLP-R's recursive gate in ONE pass over the hops (sgl_hop_recursive_f32): out, final weights W [n, H] and the score
+    matrices A, C.  Backward: dL/dW by the row-dot kernel, the [n, H] recursion backwards in one thread-per-row kernel
+    (sgl_hop_recursive_bwd_f32), the weight gradients by the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, weight, b, *feats):
+        feats_d = [f.detach() for f in feats]
+        result, vp, w, a, c = _recursive_launch(weight, b, feats_d, True)
+        ctx.save_for_backward(vp, w, a, c, *feats_d)
+        ctx.shapes = (tuple(weight.shape), tuple(b.shape))
+        ctx.mark_non_differentiable(w)
+        return result, w
+
+    @staticmethod
+    def backward(ctx, gout, _gw):
+        vp, w, a, c, *feats = ctx.saved_tensors
+        H = len(feats)
+        n, d = feats[0].shape
+        dp = round_up(d, 4)
+        need_x = [ctx.needs_input_grad[2 + h] for h in range(H)]
+        dwt, dxs = _wsum2d_backward(w, feats, gout, True, need_x)                 # dL/dW and the W-part of dL/dX_h
+        dwt = dwt.contiguous()
+        da, dc = torch.empty_like(a), torch.empty_like(c)
+        dbr = torch.empty(n, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib().sgl_hop_recursive_bwd_f32(H, ptr(a), H, ptr(c), H, float("nan"), ptr(vp[2 * dp:]), ptr(dwt), H, ptr(da), H,
+                                                  ptr(dc), H, ptr(dbr), n, current_stream_ptr()), "sgl_hop_recursive_bwd_f32")
+        dweight = dbias = None
+        if ctx.needs_input_grad[0]:
+            dweight = torch.cat([hop_colsum(feats, da).sum(0), hop_colsum(feats, dc).sum(0)]).reshape(ctx.shapes[0])
+        if ctx.needs_input_grad[1]:
+            dbias = dbr.sum().reshape(ctx.shapes[1])
+        v_x, v_acc = vp[:d].view(1, -1), vp[dp:dp + d].view(1, -1)
+        for h in range(H):
+            if need_x[h]:
+                dxs[h] = dxs[h] + da[:, h:h + 1] * v_x + dc[:, h:h + 1] * v_acc
+        return (dweight, dbias, *dxs)
+
+
+def hop_recursive(feats, weight, b, return_weights=False):
+    """IterateLearnableWeightedMessageOp 'recursive' over hops 0 .. H-1 with Linear(2 d -> 1) parameters (weight [1, 2 d] or
+    [2 d]: [w_x | w_acc], bias b).  One pass over the hops when the rows fit the register-resident kernel (gate_fusable);
+    otherwise two row-dot passes for the scores, the [n, H] recursion in torch and one weighted-sum pass."""
+    if gate_fusable(feats):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, b, *feats)):
+            out, w = _RecursiveFused.apply(weight, b, *feats)
+        else:                                             # inference: the [n, H] matrices are written only when asked for
+            out, _, w, _, _ = _recursive_launch(weight, b, [f.detach() for f in feats], return_weights)
+    else:
+        d = feats[0].shape[1]
+        wt = weight.reshape(-1)
+        w = recursive_weights(hop_scores(feats, wt[:d]), hop_scores(feats, wt[d:]), b.reshape(-1)[:1])
         out = hop_wsum2d(feats, w)
     return (out, w) if return_weights else out
 

@@ -1,9 +1,20 @@
 """Recursive gated hop combination (GAMLP-R).  Reference: message_op/iterate_learnable_weighted_message_op.py:8-51.
 
 Per step i the gate sees [X_i || acc] and the running soft-max over the scores so far re-weights ALL hops
-0..i (the reference re-applies soft-max to already soft-maxed columns, :39 -- kept).  The O(n d) work per
-step -- the re-weighted hop sum -- runs in the HIP weighted-sum kernel (with its hand-written backward);
-the gate Linear(2d -> 1) is split as x . W_x + acc . W_acc + b so no [n, 2d] hstack is materialised."""
+0..i (the reference re-applies soft-max to already soft-maxed columns, :39 -- kept).
+
+The recursion is ROW-LOCAL and acc is always a per-row weighted sum of the hops, acc_i[n] = sum_j W_i[n, j] X_j[n], so the
+gate's view of it is a combination of per-hop scalars:
+
+    Linear([X_i || acc_{i-1}])[n] = <X_i[n], w_x> + sum_j W_{i-1}[n, j] <X_j[n], w_acc> + b
+
+With a[n, h] = <X_h[n], w_x> and c[n, h] = <X_h[n], w_acc> the whole loop runs on [n, H] scalars.  On the device the operator is
+ONE pass over the hop matrices (device.hop_recursive -> sgl_hop_recursive_f32: the hop rows in registers, 2 H row-dots, the
+recursion on the scalars, the final weighted sum) where the step-by-step form makes H (H + 3) / 2 reads of a hop matrix and writes
+H intermediate accumulators; rows the register-resident kernel cannot take go through two row-dot passes, the [n, H] recursion
+in torch and one weighted-sum pass.  The backward re-runs the [n, H] recursion under autograd and takes the weight gradients from
+sgl_hop_colsum_f32.  The step-by-step form stays for host tensors and for start != 0 (where the reference's own indexing, kept
+below, is only meaningful by accident)."""
 import torch
 import torch.nn.functional as F
 from torch.nn import Linear
@@ -29,6 +40,11 @@ class IterateLearnableWeightedMessageOp(MessageOp):
         lin = self.__learnable_weight
         d = feat_list[s].shape[1]
         w_x, w_acc = lin.weight.view(-1)[:d], lin.weight.view(-1)[d:]
+        f0 = feat_list[s]
+        if s == 0 and 0 < e <= len(feat_list) and lin.weight.numel() == 2 * d and torch.is_tensor(f0) and f0.is_cuda and f0.dtype == torch.float32 and f0.dim() == 2:
+            from ... import device as dev
+            from ..utils import _rowmajor
+            return dev.hop_recursive([_rowmajor(x) for x in feat_list[:e]], lin.weight, lin.bias)
         acc = feat_list[s]
         weights = None
         for i in range(s, e):

@@ -1238,6 +1238,67 @@ def test_single_pass_gate_matches_two_pass_and_autograd(cuda, n, d, H):
         assert float((fx[h].grad.double() - f64[h].grad).abs().max()) <= 1e-4 * scale
 
 
+def _recursive_step_by_step(feats, weight, bias):
+    """the reference's loop as written (iterate_learnable_weighted_message_op.py:28-51), any dtype, plain torch"""
+    d = feats[0].shape[1]
+    acc, weights = feats[0], None
+    for i in range(len(feats)):
+        score = torch.sigmoid(torch.hstack((feats[i], acc)) @ weight.view(-1, 1) + bias)
+        weights = score if weights is None else torch.hstack((weights, score))
+        weights = torch.softmax(weights, dim=1)
+        acc = sum(weights[:, j:j + 1] * feats[j] for j in range(i + 1))
+    return acc, weights
+
+
+@pytest.mark.parametrize("n,d,H", [(3000, 128, 11), (2500, 100, 4), (700, 147, 6), (64, 16, 16), (90, 20, 12), (1, 500, 2), (900, 260, 5),
+                                   (333, 64, 1), (257, 36, 8), (4000, 600, 3)])
+def test_single_pass_recursive_gate_matches_the_step_by_step_form(cuda, n, d, H):
+    """sgl_hop_recursive_f32 (GAMLP-R's gate with the hop rows in registers: 2 H row-dots, the recursion on per-hop scalars, the
+    weighted sum) against a float64 statement of the reference's step-by-step loop (iterate_learnable_weighted_message_op.py:28-51):
+    values, final weights, gradients w.r.t. the Linear's weight, bias and the hops.  (90, 20, 12): more hops than lanes in a row's
+    group (the array form of the recursion); (4000, 600, 3): rows the register-resident kernel does not take -> two row-dot passes,
+    the [n, H] recursion in torch and one weighted-sum pass behind the same call."""
+    from sgl_amd import device as dev
+    g = torch.Generator(device="cpu").manual_seed(n + d + H)
+    feats = [dev.alloc_rows(n, d, cuda) for _ in range(H)]
+    for h, f in enumerate(feats):
+        f.copy_(torch.randn(n, d, generator=g) * (1.0 - 0.04 * h))
+    weight = (torch.randn(1, 2 * d, generator=g) * (0.5 / d ** 0.5)).to(cuda).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(cuda).requires_grad_(True)
+    gout = torch.randn(n, d, generator=g).to(cuda)
+    assert dev.gate_fusable(feats) == (d <= 512)
+    fx = [f.detach().requires_grad_(True) for f in feats]
+    y, w = dev.hop_recursive(fx, weight, b, return_weights=True)
+    assert y.shape == (n, d) and w.shape == (n, H)
+    w64, b64 = weight.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    f64 = [f.detach().double().requires_grad_(True) for f in feats]
+    y64, wt64 = _recursive_step_by_step(f64, w64, b64)
+    assert float((w.double() - wt64).abs().max()) <= 2e-6
+    assert oracle.parity_ok(y.detach().cpu().numpy(), y64.detach().float().cpu().numpy(), 1e-5, rowwise=False)
+    (y * gout).sum().backward()
+    (y64 * gout.double()).sum().backward()
+    for got, want, tol in ((weight.grad, w64.grad, 2e-4), (b.grad, b64.grad, 2e-3)):
+        scale = float(want.abs().max().clamp_min(1e-12))
+        assert float((got.double() - want).abs().max()) <= tol * max(scale, 1.0), (float((got.double() - want).abs().max()), scale)
+    for h in range(H):
+        scale = float(f64[h].grad.abs().max().clamp_min(1e-12))
+        assert float((fx[h].grad.double() - f64[h].grad).abs().max()) <= 1e-4 * scale, h
+    if d <= 512:
+        # the pad columns of an own output are written as zeros (whole-line stores); the scalar route gives the same weights
+        if n > 1 and y.stride(0) != d:
+            assert bool((dev.padded_parent(y.detach())[:, d:] == 0).all())
+        wt = weight.detach().reshape(-1)
+        w2 = dev.recursive_weights(dev.hop_scores(feats, wt[:d]), dev.hop_scores(feats, wt[d:]), b.detach())
+        assert torch.allclose(w.detach(), w2, rtol=1e-5, atol=2e-6)
+        # the operator routes device hops through it
+        from sgl_amd.operators.message_op import IterateLearnableWeightedMessageOp
+        op = IterateLearnableWeightedMessageOp(0, H, "recursive", d).to(cuda)
+        op.load_state_dict({"_IterateLearnableWeightedMessageOp__learnable_weight.weight": weight.detach(),
+                            "_IterateLearnableWeightedMessageOp__learnable_weight.bias": b.detach()})
+        with torch.no_grad():
+            assert torch.equal(op.aggregate(feats), y.detach())
+
+
 @pytest.mark.parametrize("n,d,H", [(50_000, 147, 6), (3000, 128, 11), (777, 100, 4), (5, 7, 3), (1, 500, 2), (4099, 1024, 16), (300, 36, 1)])
 def test_hop_colsum_is_the_weight_gradient_of_the_row_dots(cuda, n, d, H):
     """sgl_hop_colsum_f32: out[h] = sum_n w[n, h] X_h[n, :] (and with one weight per row shared by all hops) -- what torch computes

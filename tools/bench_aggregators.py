@@ -79,6 +79,10 @@ def main():
         uu = torch.randn(H, d, device=device)
         rep("jk scores (one pass)", timeit(lambda: dev.hop_scores2(feats, v, uu, (1 << H) - 1, 0, H)), H * nb + n * (H + 1) * 4)
         rep("jk scores (hstack+GEMV)", timeit(lambda: (torch.hstack(feats) @ uu.view(-1), dev.hop_scores(feats, v))), H * nb + n * (H + 1) * 4)
+        from sgl_amd.operators.message_op import IterateLearnableWeightedMessageOp
+        it = IterateLearnableWeightedMessageOp(0, H, "recursive", d).to(device)
+        with torch.no_grad():                            # GAMLP-R's recursive gate; algorithmic bytes: every hop once, one output
+            rep("recursive gate (iterate op)", timeit(lambda: it.aggregate(feats)), (H + 1) * nb)
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)

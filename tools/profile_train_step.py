@@ -2,11 +2,11 @@
 """Where a mini-batch training step of a learnable-aggregator SGAP model goes on the device (the device-resident
 training feed; reference loop: sgl/tasks/utils.py:66-76 `train` -> models/base_model.py:58-66 `forward`).
 
-GAMLP ('jk' gate over K + 1 hops) on the products-shaped graph, d + C = 147, batch B: per phase (HIP events) -- row gather of the
+A zoo model (default GAMLP: 'jk' gate over K + 1 hops; --model picks another aggregator) on the products-shaped graph, d + C = 147, batch B: per phase (HIP events) -- row gather of the
 K + 1 hop matrices, the aggregator forward, the MLP forward, loss, backward, optimizer -- and the torch profiler's top device
 kernels / host ops of a step.
 
-    python tools/profile_train_step.py [--workload S1_products] [--batch 50000] [--prop-steps 5] [--steps 20]"""
+    python tools/profile_train_step.py [--workload S1_products] [--batch 50000] [--prop-steps 5] [--steps 20] [--model GAMLPRecursive] [--profile]"""
 import argparse
 import os
 import sys
@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sgl_amd import synthetic  # noqa: E402
 from sgl_amd.io import DeviceAdjacency  # noqa: E402
 from sgl_amd.models.base_model import take_rows  # noqa: E402
-from sgl_amd.models.homo import GAMLP  # noqa: E402
+from sgl_amd.models import homo  # noqa: E402
 
 
 def main():
@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--prop-steps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--classes", type=int, default=47)
+    ap.add_argument("--model", default="GAMLP", choices=["GAMLP", "GAMLPRecursive", "PASCA_V1", "PASCA_V2"],
+                    help="a zoo model with a LEARNABLE aggregator (the others aggregate once, in preprocess)")
     ap.add_argument("--profile", action="store_true")
     a = ap.parse_args()
     device = torch.device("cuda")
@@ -39,7 +41,8 @@ def main():
     g = torch.Generator(device=device).manual_seed(0)
     x = torch.randn((n, d), generator=g, device=device)
     y = torch.randint(0, C, (n,), generator=g, device=device)
-    model = GAMLP(a.prop_steps, d, C, 256, 3).to(device)
+    cls = getattr(homo, a.model)
+    model = cls(a.prop_steps, d, C, 256, 3).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
     model.preprocess(adj, x)
     model.train()
@@ -67,7 +70,7 @@ def main():
         marks[6].record()
         if timers is not None:
             torch.cuda.synchronize()
-            for k, name in enumerate(("gather_rows x H", "aggregate fwd (jk)", "MLP fwd", "loss", "backward", "optimizer")):
+            for k, name in enumerate(("gather_rows x H", "aggregate fwd", "MLP fwd", "loss", "backward", "optimizer")):
                 timers[name] = timers.get(name, 0.0) + marks[k].elapsed_time(marks[k + 1])
 
     for _ in range(3):
@@ -78,7 +81,7 @@ def main():
     for _ in range(a.steps):
         step(timers)
     wall = (time.perf_counter() - t0) / a.steps * 1e3
-    print(f"TRAIN_STEP workload={a.workload} B={a.batch} d={d} H={a.prop_steps + 1}: {wall:.3f} ms per step (wall, phases synchronised)")
+    print(f"TRAIN_STEP model={a.model} workload={a.workload} B={a.batch} d={d} H={a.prop_steps + 1}: {wall:.3f} ms per step (wall, phases synchronised)")
     for k, v in timers.items():
         print(f"TRAIN_STEP   {k:22s} {v / a.steps:8.3f} ms")
     torch.cuda.synchronize()
