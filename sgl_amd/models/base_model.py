@@ -19,8 +19,13 @@ _LEARNABLE = ("proj_concat", "learnable_weighted", "iterate_learnable_weighted")
 
 
 def take_rows(feat, idx, device):
-    """feat[idx].to(device) -- on the GPU when the hop matrix lives there"""
+    """feat[idx].to(device) -- on the GPU when the hop matrix lives there.  A contiguous `range` of rows of a device matrix (a full
+    prediction pass: tricks.label_reuse.predict_all) is a VIEW of it, not a copy: what follows only reads it (the aggregator
+    kernels and the head's GEMM take a row pitch), and a copy would move every hop matrix once more (2 x 1.6 GB per hop at the
+    products shape)."""
     if torch.is_tensor(feat) and feat.is_cuda:
+        if isinstance(idx, range) and idx.step == 1 and 0 <= idx.start <= idx.stop <= feat.shape[0]:
+            return feat[idx.start:idx.stop].to(device)
         return dev.gather_rows(feat, idx).to(device)
     if isinstance(idx, range):
         idx = list(idx)

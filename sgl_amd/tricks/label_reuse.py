@@ -44,10 +44,10 @@ def add_labels(x, labels, idx, num_classes, out=None, device="cuda"):
 def predict_all(model, n, device, batch_size=None):
     """model.model_forward over all n nodes (in batches of `batch_size`, the reference's label_reuse_batch_size) -> [n, C] on device"""
     device = torch.device(device)
+    # contiguous row ranges: the hop rows are views of the hop matrices, nothing is gathered (models/base_model.py take_rows)
     if batch_size is None or batch_size >= n:
-        return model.model_forward(torch.arange(n, device=device), device)
-    return torch.cat([model.model_forward(torch.arange(s, min(s + batch_size, n), device=device), device)
-                      for s in range(0, n, batch_size)])
+        return model.model_forward(range(n), device)
+    return torch.cat([model.model_forward(range(s, min(s + batch_size, n)), device) for s in range(0, n, batch_size)])
 
 
 @torch.no_grad()

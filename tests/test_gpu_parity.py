@@ -1693,6 +1693,29 @@ def test_models_match_reference_goldens(goldens, cuda):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_forward_over_a_contiguous_row_range_reads_the_hops_in_place(goldens, cuda):
+    """model_forward(range(a, b)) -- a full prediction pass in batches -- takes VIEWS of the device hop matrices (no row gather) and
+    gives what the gathered path gives, for a learnable aggregator (hop list) and a fixed one (one aggregated matrix)"""
+    from sgl_amd.models.base_model import take_rows
+    from sgl_amd.models.homo import GAMLPRecursive, SSGC
+    g = goldens.graph("pl2000")
+    n, d, C = 2000, 37, 5
+    x = hash_matrix(n, d, seed=9)
+    for model in (GAMLPRecursive(3, d, C, 16, 2), SSGC(3, d, C)):
+        model = model.to(cuda).eval()
+        model.preprocess(g, x)
+        feats = model._processed_feat_list if model._pre_msg_learnable else [model._processed_feature]
+        assert all(f.is_cuda for f in feats)
+        v = take_rows(feats[0], range(100, 300), cuda)
+        assert v.data_ptr() == feats[0][100:300].data_ptr() and v.shape == (200, feats[0].shape[1])
+        with torch.no_grad():
+            a = model.model_forward(range(100, 300), cuda)
+            b = model.model_forward(torch.arange(100, 300, device=cuda), cuda)
+            c = model.model_forward(range(0, n), cuda)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6) and torch.allclose(c[100:300], b, rtol=1e-5, atol=1e-6)
+        assert take_rows(feats[0], range(0, 10, 2), cuda).data_ptr() != feats[0].data_ptr()      # a strided range is gathered
+
+
 def test_label_reuse_loop_matches_reference_task(goldens, cuda):
     """BASELINE config 3's loop (tasks/node_classification_with_label_use.py:58-137: label use every epoch, label reuse from epoch 1
     on, `preprocess` re-run after every write-back) on the device -- sgl_amd.tricks.add_labels / label_reuse, GAMLP with the
