@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from .. import config
 from .. import device as dev
+from .simple_models import IdenticalMapping
 
 _LEARNABLE = ("proj_concat", "learnable_weighted", "iterate_learnable_weighted")
 
@@ -154,4 +155,7 @@ class BaseSGAPModel(nn.Module):
             if isinstance(feat, np.ndarray):  # no pre-graph-op: the raw feature matrix
                 feat = torch.from_numpy(feat)
             processed_feature = take_rows(feat, idx, device)
+            if isinstance(self._base_model, IdenticalMapping) and torch.is_tensor(feat) and \
+                    processed_feature.untyped_storage().data_ptr() == feat.untyped_storage().data_ptr():
+                processed_feature = processed_feature.clone()     # no head (NAFS): never hand out a view of the stored matrix
         return self._base_model(processed_feature)
