@@ -513,3 +513,52 @@ def test_hop_cache_digest_separates_moves_and_swaps():
         total[1] += hc._mix64(keyed ^ hc._s64(0xD6E8FEB86659FD93)).sum()
     lo, hi = (int(v) & 0xFFFFFFFFFFFFFFFF for v in total.tolist())
     assert whole == (hi << 64) | lo
+
+
+def test_recursive_gate_on_per_hop_scalars_is_the_step_by_step_loop():
+    """device.recursive_weights (the [n, H] recursion the GPU kernels implement, plain torch) against the reference's loop as written
+    (iterate_learnable_weighted_message_op.py:28-51) in float64: final weights, output and gradients of both score matrices"""
+    from sgl_amd import device as dev
+    g = torch.Generator().manual_seed(5)
+    n, d, H = 64, 9, 7
+    feats = [torch.randn(n, d, generator=g, dtype=torch.float64) * (1.0 - 0.05 * h) for h in range(H)]
+    weight = torch.randn(1, 2 * d, generator=g, dtype=torch.float64) * 0.4
+    bias = torch.randn(1, generator=g, dtype=torch.float64)
+    acc, weights = feats[0], None
+    for i in range(H):                                                     # the reference's loop
+        score = torch.sigmoid(torch.hstack((feats[i], acc)) @ weight.view(-1, 1) + bias)
+        weights = score if weights is None else torch.hstack((weights, score))
+        weights = torch.softmax(weights, dim=1)
+        acc = sum(weights[:, j:j + 1] * feats[j] for j in range(i + 1))
+    a = torch.stack([f @ weight[0, :d] for f in feats], dim=1).requires_grad_(True)
+    c = torch.stack([f @ weight[0, d:] for f in feats], dim=1).requires_grad_(True)
+    w = dev.recursive_weights(a, c, bias)
+    assert torch.allclose(w, weights, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(sum(w[:, j:j + 1] * feats[j] for j in range(H)), acc, rtol=1e-12, atol=1e-12)
+    w.sum(dim=0)[1:4].sum().backward()
+    assert float(a.grad[:, 0].abs().max()) == 0.0                          # step 0 is the soft-max of ONE score: a_0 is never seen
+    assert float(c.grad[:, 0].abs().max()) > 0.0 and float(a.grad[:, 1:].abs().max()) > 0.0
+
+
+def test_shared_slope_prelu_is_nn_prelu_with_another_backward():
+    """models/simple_models.py keeps nn.PReLU's parameter, key and forward; its backward (three element-wise passes and a sum) gives
+    torch's gradients, also at x == 0 and with the slope frozen"""
+    from sgl_amd.models.simple_models import MultiLayerPerceptron, _SharedSlopePReLU
+    g = torch.Generator().manual_seed(1)
+    ours, ref = _SharedSlopePReLU(), torch.nn.PReLU()
+    x = torch.randn(50, 13, generator=g)
+    x[0, :3] = 0.0
+    go = torch.randn(50, 13, generator=g)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ours(xa), ref(xb)
+    assert torch.equal(ya, yb)
+    (ya * go).sum().backward()
+    (yb * go).sum().backward()
+    assert torch.equal(xa.grad, xb.grad) and torch.allclose(ours.weight.grad, ref.weight.grad, rtol=1e-6, atol=1e-7)
+    ours.weight.requires_grad_(False)
+    xa2 = x.clone().requires_grad_(True)
+    (ours(xa2) * go).sum().backward()
+    assert torch.equal(xa2.grad, xb.grad)
+    with torch.no_grad():
+        assert torch.equal(ours(x), ref(x))
+    assert "_MultiLayerPerceptron__prelu.weight" in MultiLayerPerceptron(4, 8, 2, 3).state_dict()
