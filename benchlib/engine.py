@@ -1,6 +1,5 @@
 """Everything device-specific in the bench (GpuEngine) and the CPU baseline leg."""
 import os
-import sys
 import time
 
 import numpy as np

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .layout import balanced_bounds, piece_bounds
+from .layout import piece_bounds
 
 
 @dataclass

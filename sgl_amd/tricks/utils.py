@@ -6,7 +6,6 @@
 One fused HIP kernel per layer (sgl_spmm_axpb_clamp_f32: SpMM + scale + residual + clamp in the epilogue, same
 rounding order as the reference's `alpha * torch.spmm(...) + res`); adj, H0 and both ping-pong buffers stay in HBM.
 The reference's torch-COO `spmm` sums each row in storage order like the CSR kernel does."""
-import numpy as np
 import scipy.sparse as sp
 import torch
 import torch.nn.functional as F

@@ -6,7 +6,6 @@ widths / table sizes / gathers in flight.  The SpMM kernel's gather rate is quot
     python tools/mem_ceilings.py [--big]      (--big adds the 57 GB papers100M-sized table)
 """
 import argparse
-import ctypes
 import os
 import sys
 

@@ -8,7 +8,6 @@ Prints one line per configuration: `EXP <name> <key=value ...> ms_per_hop=<t> fr
 import argparse
 import os
 import sys
-import time
 
 import numpy as np
 import torch
