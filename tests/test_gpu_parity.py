@@ -1363,6 +1363,13 @@ def test_aggregators_with_more_than_sixteen_hops(cuda, d):
     v = hash_matrix(1, d, seed=3).reshape(-1)
     sc = dev.hop_scores(feats, torch.from_numpy(v).to(cuda)).cpu().numpy()
     assert np.allclose(sc, np.stack([x.astype(np.float64) @ v for x in host], 1), rtol=1e-4, atol=1e-4)
+    # the recursive gate beyond 16 hops: row-dot passes + the [n, H] recursion + one weighted-sum pass, against the reference loop
+    wt = torch.from_numpy(hash_matrix(1, 2 * d, seed=4) * (0.5 / d ** 0.5)).to(cuda)
+    b = torch.tensor([0.1], device=cuda)
+    y, w = dev.hop_recursive(feats, wt, b, return_weights=True)
+    y64, w64 = _recursive_step_by_step([f.double() for f in feats], wt.double(), b.double())
+    assert float((w.double() - w64).abs().max()) <= 2e-6
+    assert oracle.parity_ok(y.cpu().numpy(), y64.float().cpu().numpy(), 1e-5, rowwise=False)
 
 
 @pytest.mark.parametrize("d,H", [(147, 6), (147, 11), (501, 5), (65, 16), (257, 4), (86, 3), (85, 3), (1023, 2), (1025, 3), (1025, 4), (511, 16)])
