@@ -100,6 +100,7 @@ def main():
                ("learnable gate", M.LearnableWeightedMessageOp(0, K + 1, "gate", d).to(device)),
                ("learnable ori_ref", M.LearnableWeightedMessageOp(0, K + 1, "ori_ref", d).to(device)),
                ("learnable jk", M.LearnableWeightedMessageOp(0, K + 1, "jk", K, d).to(device)),
+               ("iterate recursive", M.IterateLearnableWeightedMessageOp(0, K + 1, "recursive", d).to(device)),
                ("nafs over_smooth", M.OverSmoothDistanceWeightedOp())]
         hb = (K + 1) * (hi - lo) * d * 4
         for oname, op in ops:
