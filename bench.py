@@ -8,7 +8,10 @@ One "step" = one full k-hop propagation (prop_steps SpMM launches, k=3 for the h
 61.86 M undirected edges, d=100; sgl_amd/synthetic.py).  A_hat, X and all hop buffers are resident in HBM when
 the timed region starts.  value = nnz(A_hat) * d * k * steps / time  [edge*featdim/s], whole job.
 
-N>1 (launched by torch.distributed.run, one rank per GPU).  What `value` measures is the contract layout (north_star,
+N>1, one rank per GPU: either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or as a bare
+`python bench.py --gpus N`, in which case this process starts the N ranks itself (benchlib/launch.py; the reference's
+analogue spawns its ranks the same way, tasks/node_classification_dist.py:42-61), relays rank 0's line and exits non-zero with
+a `value: null` line if any rank fails.  What `value` measures is the contract layout (north_star,
 SURVEY 8(e)): A_hat ROW-SHARDED IN STORAGE -- rank 0 generates the raw graph and hands every rank only its nnz-balanced row
 block, each rank normalises its own block (sgl_norm_block_*, one all-reduce of the degree vector) and keeps nothing else --
 plus a per-hop all-gather of the feature block over RCCL, column chunks software-pipelined across hops.  Two things are
@@ -45,7 +48,8 @@ sys.path.insert(0, ROOT)
 from benchlib.common import (HBM_PEAK_BYTES, _PHASE, _QuietStdout, _phase, _replayed_profile, algorithmic_bytes_per_hop,  # noqa: E402,F401
                              baseline_metric, workload_text)
 from benchlib.diagnostics import _diagnostics  # noqa: E402
-from benchlib.engine import GpuEngine, cpu_baseline  # noqa: E402,F401
+from benchlib.engine import GpuEngine, cpu_baseline, engine_from_env  # noqa: E402,F401
+from benchlib.launch import needs_self_launch, self_launch  # noqa: E402
 from benchlib.layouts import _select_layout  # noqa: E402
 from benchlib.papers import papers_section  # noqa: E402,F401
 from benchlib.rows import _Job  # noqa: E402
@@ -99,15 +103,18 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
+def run(args, engine_cls=None, workloads=None, emit=print):
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if engine_cls is None:
+        engine_cls = engine_from_env()
     if world != args.gpus:
+        # main() starts the ranks itself when no launcher did; only a caller of run() with a half-set environment ends up here
         if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+            raise SystemExit("--gpus N>1: call bench.main() (it starts the N ranks) or launch with torch.distributed.run")
         args.gpus = world
     quiet = _QuietStdout()
     if emit is print:
@@ -317,8 +324,13 @@ def run(args, engine_cls=GpuEngine, workloads=None, emit=print):
     return out
 
 
-def main():
-    run(parse_args())
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if needs_self_launch(args):
+        # `python bench.py --gpus N` with no launcher: start the N ranks here (benchlib/launch.py), relay rank 0's line
+        sys.exit(self_launch(args, argv, os.path.abspath(__file__), baseline_metric()))
+    run(args)
 
 
 if __name__ == "__main__":

@@ -340,3 +340,32 @@ class GpuEngine:
     def timer(self):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         return (lambda: ev0.record()), (lambda: ev1.record()), (lambda: ev0.elapsed_time(ev1))
+
+
+class OneGpuGlooEngine(GpuEngine):
+    """REHEARSAL engine: every rank on cuda:0, process group = gloo (which cannot move device memory, so the exchange is the
+    host-staged transport).  The kernels, the row-sharded storage, the need-aware plan, the validation and the JSON line are
+    the real ones; only the wire differs.  Selected by SGL_BENCH_ENGINE=one_gpu_gloo -- it exists so that an N-rank launch of
+    bench.py can be run end to end on a one-GPU box (tests/test_zz_gpu_multiprocess.py, profiles/r05_launch_rehearsal.log)."""
+    backend = "gloo"
+    transports = ("staged",)
+    relay_transport = "relay_staged"
+    probe_links = False                   # the link micro-benchmark moves device tensors through the process group
+    halo_collective = False               # gloo has no all_to_all_single
+
+    def __init__(self, local_rank):
+        super().__init__(0)
+
+    def init_kwargs(self):
+        return {}
+
+
+def engine_from_env():
+    """SGL_BENCH_ENGINE: unset / "gpu" = one rank per GPU over RCCL (the product path); "one_gpu_gloo" = the rehearsal engine"""
+    import os
+    name = os.environ.get("SGL_BENCH_ENGINE", "gpu")
+    if name in ("", "gpu"):
+        return GpuEngine
+    if name == "one_gpu_gloo":
+        return OneGpuGlooEngine
+    raise SystemExit(f"SGL_BENCH_ENGINE={name!r}: expected gpu or one_gpu_gloo")

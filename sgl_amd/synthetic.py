@@ -12,6 +12,7 @@ WORKLOADS = {
     "S0_pubmed": dict(n=19_717, m=44_324, d_max=171, d=500, k=3),
     "S1_products": dict(n=2_449_029, m=61_859_140, d_max=17_481, d=100, k=3),
     "S1_small": dict(n=200_000, m=5_000_000, d_max=5_000, d=100, k=3),
+    "T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3),     # launch rehearsals (N ranks on one GPU), seconds
     "S2_gamlp": dict(n=2_449_029, m=61_859_140, d_max=17_481, d=147, k=5),
     # ogbn-papers100M-shaped: directed hash-generated graph, rows generated per shard on device
     # (`hashed=True`: sgl_synth_*, mirrored on the host below).  mean_deg 30.07 -> nnz ~ 3.34 G over all rows.

@@ -449,3 +449,85 @@ def test_bench_default_falls_back_when_the_need_aware_exchange_cannot_be_built(t
     plan = j["config"]["plan"]
     assert plan["exchange"] == "p2p" and plan["halo_rejected"].startswith("halo") and j["value"] > 0 and plan["layout"] == "rows"
     assert j["config"]["validated"] is True and j["config"]["diagnostics"]["per_hop"]["pack_ms"] == 0
+
+
+# ---- `python bench.py --gpus N` without a launcher (benchlib/launch.py) ------------------------------------------------------------
+_STUB = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[1]
+print("library chatter of rank", rank)                      # only rank 0's JSON line may reach the parent's stdout
+if mode == "ok":
+    if rank == 0:
+        print(json.dumps({"value": 1.0, "n_gpus": world}))
+elif mode == "rank1_dies":
+    if rank == 1:
+        sys.stderr.write("boom on rank 1\n"); sys.exit(7)
+    time.sleep(120)                                          # the survivors wait in a "collective" for ever
+elif mode == "dies_after_line":
+    if rank == 0:
+        print(json.dumps({"value": 2.0, "n_gpus": world}), flush=True)
+    if rank == 1:
+        time.sleep(0.5); sys.exit(5)
+'''
+
+
+def _launch(tmp_path, mode, n=3, grace=1.0):
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+    from benchlib import launch
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB)
+
+    class A:
+        gpus = n
+    buf = io.StringIO()
+    os.environ["SGL_BENCH_ENGINE"] = "one_gpu_gloo"           # (no device-count probe: the stub needs no GPU)
+    try:
+        with contextlib.redirect_stdout(buf):
+            rc = launch.self_launch(A, [mode], str(stub), "m", grace_s=grace)
+    finally:
+        del os.environ["SGL_BENCH_ENGINE"]
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    return rc, lines
+
+
+def test_self_launch_relays_exactly_one_line(tmp_path):
+    rc, lines = _launch(tmp_path, "ok")
+    assert rc == 0 and len(lines) == 1 and json.loads(lines[0]) == {"value": 1.0, "n_gpus": 3}
+
+
+def test_self_launch_ends_the_job_when_a_rank_dies(tmp_path):
+    """rank 1 exits 7 while the others sit in a collective: the parent ends them after the grace period, prints ONE line with
+    value null that names the rank, its code and its stderr, and returns non-zero"""
+    import time
+    t0 = time.monotonic()
+    rc, lines = _launch(tmp_path, "rank1_dies")
+    assert time.monotonic() - t0 < 60
+    j = json.loads(lines[0])
+    assert rc != 0 and len(lines) == 1 and j["value"] is None and j["n_gpus"] == 3
+    assert "rank 1 exited with code 7" in j["error"] and "boom on rank 1" in j["stderr_tail"]
+
+
+def test_self_launch_keeps_a_measured_line_when_a_rank_fails_later(tmp_path):
+    rc, lines = _launch(tmp_path, "dies_after_line", n=2)
+    j = json.loads(lines[0])
+    assert rc == 0 and len(lines) == 1 and j["value"] == 2.0 and j["launcher"]["failed_rank"] == 1
+
+
+def test_bare_bench_command_with_more_ranks_than_gpus_prints_a_null_line():
+    """`python bench.py --gpus 2` where fewer than 2 GPUs are visible (here: none): one JSON line, value null, non-zero rc --
+    not a traceback, and not the SystemExit the bare command used to die with"""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SGL_BENCH_ENGINE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert out.returncode != 0 and len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["value"] is None and j["n_gpus"] == 2 and "GPU(s) visible" in j["error"]

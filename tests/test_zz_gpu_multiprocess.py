@@ -560,3 +560,25 @@ def test_bench_grid_layout_with_four_ranks_on_one_gpu(cuda, tmp_path):
     j = json.loads(json.load(open(tmp_path / "rank0.json"))[0])
     assert j["n_gpus"] == 4 and j["value"] > 0 and j["config"]["plan"]["layout"] == "grid"
     assert "layout_rejected" not in j["config"]["plan"]
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bare_bench_command_starts_its_own_ranks(cuda, ranks):
+    """`python bench.py --gpus N` with NO launcher (the only command shape the driver has ever issued): bench.py starts the N ranks
+    itself (benchlib/launch.py), exactly one JSON line reaches stdout, n_gpus = N, the contract layout ran and validated.  The ranks
+    share cuda:0 through the rehearsal engine (SGL_BENCH_ENGINE=one_gpu_gloo: real kernels, host-staged wire); 8 processes is
+    the shape of the 8-GPU run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SGL_BENCH_ENGINE="one_gpu_gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+                          "--workload", "T_small", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    plan = j["config"]["plan"]
+    assert j["n_gpus"] == ranks and j["steps"] == 2 and j["value"] > 0 and j["config"]["validated"] is True
+    assert plan["layout"] == "rows" and plan["exchange"] in ("halo", "staged") and "launcher" not in j
