@@ -264,6 +264,14 @@ int sgl_norm_block_colsum(int64_t n_cols, int64_t nnz, const int32_t *d_col, con
 int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_val64,
                          const double *d_left_local, const double *d_right_global, int use_alpha, double alpha,
                          float *d_out_val, double *d_out_val64, void *stream);
+/* (1 - alpha) A_hat + alpha I (ppr_graph_op.py:20) from the fp64 A_hat of the same block and r (d_out_val64 of a
+ * sgl_norm_block_scale call with use_alpha = 0): a pure stream, bit-identical to sgl_norm_block_scale(use_alpha = 1).  An alpha
+ * sweep at one r pays the degree factors and the gather of d_right_global once. */
+int sgl_norm_block_mix(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_hat64,
+                       double alpha, float *d_out_val, double *d_out_val64, void *stream);
+/* d_left = deg^(r-1), d_right = deg^(-r), inf -> 0 (utils.py:79-84) with the device's pow(): within 1 ulp(fp64) of the host
+ * libm route described above -- for callers that want 1e-5 parity, not bit-identity, and no host round trip. */
+int sgl_norm_degree_powers(int64_t n, const double *d_deg, double r, double *d_left, double *d_right, void *stream);
 
 /* ---- ingest: COO edge list -> canonical CSR on device (sgl/data/base_data.py:29, dataset/custom_dataset.py:52-54) ---- */
 /* d_row / d_col: int64 [nnz] (the reference keeps them as torch.LongTensor), d_val float32 [nnz].  Duplicate (row,col)

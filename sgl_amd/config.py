@@ -18,6 +18,8 @@ fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / s
               pass (the running aggregate is read and written once per hop) and save K-1 hop buffers:
               "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
               device memory; True / False force it
+cache_prepared  keep the (r, alpha)-independent part of a normalisation (A + I in fp64, degrees: 12 bytes per non-zero) with the
+              device adjacency / row block it was computed from, so that a sweep over r / alpha pays one pass per candidate
 reorder       None -> the rows of A_hat are processed in the caller's node order; "community" -> a plan-time locality ordering
               (sgl_amd/reorder.py -> sgl_reorder_community: label propagation on the device, ~70 ms at products size, cached
               with the adjacency) decides the order in which the rows are STORED and PROCESSED (sgl_csr_permute_rows +
@@ -48,6 +50,7 @@ host_output = _env_bool("SGL_AMD_HOST_OUTPUT", False)
 strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
 strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
 cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
+cache_prepared = _env_bool("SGL_AMD_CACHE_PREPARED", True)
 _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()
 fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)

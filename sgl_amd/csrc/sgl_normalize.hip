@@ -270,37 +270,70 @@ __global__ __launch_bounds__(256) void block_colsum_kernel(const int32_t *__rest
 }
 
 // A_hat[j, i] = (T'[j, i] * L[j]) * R[i]  (+ PPR mix), rounded to fp32 where the reference rounds.
-// A block of 256 threads owns ROWS_PER_BLOCK consecutive rows: their row pointers go to LDS, then the threads stream the
-// block's non-zeros in order (coalesced reads of col / val, coalesced writes) and find each element's row by a binary search
-// in LDS -- one thread per ROW walks its row alone and touches memory 16 bytes at a time (measured 4x slower).
+// A block of 256 threads owns kScaleRows consecutive rows: their row pointers go to LDS (32-bit, relative to the block's first
+// element), then the threads stream the block's non-zeros in order (coalesced reads of col / val, coalesced writes) and find each
+// element's row by a binary search in LDS -- one thread per ROW walks its row alone and touches memory 16 bytes at a time
+// (measured 4x slower).  What bounds the pass is the random 8-byte gather R[col]: four elements per thread are in flight at once
+// (four independent col loads, then four independent gathers), and the streams bypass the caches (non-temporal) so that the R table
+// keeps L2 / the Infinity Cache to itself.
+// kScaled: `val` already holds A_hat in fp64 (the cached Laplacian of an alpha sweep): no L / R factors, only the PPR mix.
+// Algorithmic bytes per non-zero: 4 (col) + 8 (T' or A_hat64) + 8 (R gather; absent when kScaled) + 4 (fp32 out) [+ 8 fp64 out].
 constexpr int kScaleRows = 512;
+constexpr int kScaleUnroll = 4;
 
+template <bool kScaled>
 __global__ __launch_bounds__(256) void block_scale_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                           const double *__restrict__ val, const double *__restrict__ left_local,
                                                           const double *__restrict__ right_global, int64_t n, int64_t row0,
                                                           int use_alpha, double one_minus_alpha, double alpha,
                                                           float *__restrict__ o_val, double *__restrict__ o_val64) {
-    __shared__ int64_t rp[kScaleRows + 1];
+    __shared__ uint32_t rp[kScaleRows + 1];
     const int64_t r_begin = (int64_t)blockIdx.x * kScaleRows;
     const int rows = (int)min((int64_t)kScaleRows, n - r_begin);
-    for (int t = threadIdx.x; t <= rows; t += 256) rp[t] = rowptr[r_begin + t];
+    const int64_t p0 = rowptr[r_begin];
+    for (int t = threadIdx.x; t <= rows; t += 256) rp[t] = (uint32_t)(rowptr[r_begin + t] - p0);
     __syncthreads();
-    const int64_t p0 = rp[0], p1 = rp[rows];
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
-        int lo = 0, hi = rows;                      // last row whose first element is <= p
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (rp[mid] <= p) lo = mid; else hi = mid;
+    const uint32_t cnt = rp[rows];
+    col += p0;
+    val += p0;
+    o_val += p0;
+    if (o_val64) o_val64 += p0;
+    for (uint32_t q0 = threadIdx.x; q0 < cnt; q0 += 256 * kScaleUnroll) {
+        int32_t c[kScaleUnroll];
+        double v[kScaleUnroll], rg[kScaleUnroll], lf[kScaleUnroll];
+        int row[kScaleUnroll];
+#pragma unroll
+        for (int u = 0; u < kScaleUnroll; ++u) {
+            const uint32_t q = q0 + 256u * u;
+            c[u] = q < cnt ? __builtin_nontemporal_load(col + q) : 0;
+            v[u] = q < cnt ? __builtin_nontemporal_load(val + q) : 0.0;
         }
-        const int64_t i = r_begin + lo;
-        const int32_t c = col[p];
-        double v = __dmul_rn(__dmul_rn(val[p], left_local[i]), right_global[c]);
-        if (use_alpha) {
-            v = __dmul_rn(one_minus_alpha, v);
-            if (c == (int32_t)(row0 + i)) v = __dadd_rn(v, alpha);
+#pragma unroll
+        for (int u = 0; u < kScaleUnroll; ++u) {
+            const uint32_t q = q0 + 256u * u;
+            int lo = 0, hi = rows;                      // last row whose first element is <= q
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= q) lo = mid; else hi = mid;
+            }
+            row[u] = lo;
+            if (!kScaled) {
+                rg[u] = q < cnt ? right_global[c[u]] : 0.0;
+                lf[u] = left_local[r_begin + lo];
+            }
         }
-        o_val[p] = (float)v;
-        if (o_val64) o_val64[p] = v;
+#pragma unroll
+        for (int u = 0; u < kScaleUnroll; ++u) {
+            const uint32_t q = q0 + 256u * u;
+            if (q >= cnt) continue;
+            double x = kScaled ? v[u] : __dmul_rn(__dmul_rn(v[u], lf[u]), rg[u]);
+            if (use_alpha) {
+                x = __dmul_rn(one_minus_alpha, x);
+                if (c[u] == (int32_t)(row0 + r_begin + row[u])) x = __dadd_rn(x, alpha);
+            }
+            __builtin_nontemporal_store((float)x, o_val + q);
+            if (o_val64) __builtin_nontemporal_store(x, o_val64 + q);
+        }
     }
 }
 
@@ -550,8 +583,33 @@ SGL_EXPORT int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_ro
     SGL_REQUIRE(n >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_scale: bad sizes");
     if (n == 0) return SGL_OK;
     SGL_REQUIRE(d_rowptr && d_col && d_val64 && d_left_local && d_right_global && d_out_val, "sgl_norm_block_scale: NULL arrays");
-    hipLaunchKernelGGL(block_scale_kernel, dim3((unsigned)((n + kScaleRows - 1) / kScaleRows)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_val64,
+    hipLaunchKernelGGL(block_scale_kernel<false>, dim3((unsigned)((n + kScaleRows - 1) / kScaleRows)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_val64,
                        d_left_local, d_right_global, n, row0, use_alpha, 1.0 - alpha, alpha, d_out_val, d_out_val64);
+    SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+// (1 - alpha) A_hat + alpha I from the fp64 A_hat of the same (graph, r) -- what PprGraphOp._construct_adj adds to the Laplacian
+// (ppr_graph_op.py:20).  An alpha sweep at a fixed r pays the R gather once and this pure stream per alpha; the arithmetic is the
+// tail of sgl_norm_block_scale, so the result is bit-identical to the one-pass form.
+SGL_EXPORT int sgl_norm_block_mix(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_hat64,
+                                  double alpha, float *d_out_val, double *d_out_val64, void *stream) {
+    SGL_REQUIRE(n >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_mix: bad sizes");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_rowptr && d_col && d_hat64 && d_out_val, "sgl_norm_block_mix: NULL arrays");
+    hipLaunchKernelGGL(block_scale_kernel<true>, dim3((unsigned)((n + kScaleRows - 1) / kScaleRows)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_hat64,
+                       (const double *)nullptr, (const double *)nullptr, n, row0, 1, 1.0 - alpha, alpha, d_out_val, d_out_val64);
+    SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+// deg^(r-1), deg^(-r) with inf -> 0 (utils.py:79-84) by the DEVICE's pow(): within 1 ulp(fp64) of the host libm the reference calls,
+// i.e. A_hat within 1 ulp(fp32) in a handful of entries -- the route of every caller that does not ask for bit-identity.
+SGL_EXPORT int sgl_norm_degree_powers(int64_t n, const double *d_deg, double r, double *d_left, double *d_right, void *stream) {
+    SGL_REQUIRE(n >= 0, "sgl_norm_degree_powers: bad size");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_deg && d_left && d_right, "sgl_norm_degree_powers: NULL arrays");
+    hipLaunchKernelGGL(degree_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, sgl::as_stream(stream), d_deg, n, r, d_left, d_right);
     SGL_HIP_CHECK(hipGetLastError());
     return SGL_OK;
 }

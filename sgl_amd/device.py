@@ -3,6 +3,7 @@
 torch is used for device memory, streams and autograd bookkeeping only; every computation
 below is a hand-written HIP kernel in libsgl_hip.so.  There is no CPU fallback."""
 import ctypes
+import os
 from ctypes import c_int64, c_void_p
 
 import numpy as np
@@ -14,7 +15,7 @@ from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
-    "normalize_block", "degree_powers", "PreparedAdjacency",
+    "normalize_block", "degree_powers", "PreparedAdjacency", "PreparedBlock",
     "placed_empty", "MEM_MODES",
     "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate",
     "gather_rows",
@@ -391,26 +392,103 @@ class ChainGraph:
             pass
 
 
-def degree_powers(deg, r):
-    """deg^(r-1), deg^(-r) with inf -> 0, evaluated on the HOST by numpy exactly as the reference does
-    (operators/utils.py:79-84): the same libm, hence bit-identical degree factors.  deg: fp64 tensor (any device);
-    returns two fp64 tensors on deg's device.  On the GPU only the DISTINCT degree values travel (a graph has far fewer
-    distinct degrees than nodes: 2.4 M nodes -> a few thousand values), the factors are gathered back on the device."""
-    def host(d_):
-        d = d_.detach().cpu().numpy().astype(np.float64, copy=False)
+_POW_CACHE = []          # at most one entry: (deg tensor, its version counter, r, host_pow, left, right)
+_POW_THREADS = max(1, min(64, (os.cpu_count() or 2) // 2))
+pow_stats = {"cache_hits": 0, "host_unique": 0, "host_full": 0, "device": 0}
+
+
+def _host_powers(d, r):
+    """numpy's deg^(r-1), deg^(-r) with inf -> 0 (utils.py:79-84) on a 1-D float64 array, written into two new arrays; long
+    vectors are cut into chunks evaluated by a team of threads (the ufunc loop releases the GIL; the values do not depend on the cut)"""
+    left, right = np.empty_like(d), np.empty_like(d)
+
+    def run(a, b):
         with np.errstate(divide="ignore", invalid="ignore"):
-            left = np.power(d, r - 1)
-            left[np.isinf(left)] = 0.
-            right = np.power(d, -r)
-            right[np.isinf(right)] = 0.
-        return torch.from_numpy(left), torch.from_numpy(right)
-    if deg.is_cuda and deg.numel() > 4096:
+            np.power(d[a:b], r - 1, out=left[a:b])
+            left[a:b][np.isinf(left[a:b])] = 0.
+            np.power(d[a:b], -r, out=right[a:b])
+            right[a:b][np.isinf(right[a:b])] = 0.
+    n = d.shape[0]
+    chunk = 1 << 20
+    if n <= 2 * chunk or _POW_THREADS == 1:
+        run(0, n)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(_POW_THREADS) as ex:
+            list(ex.map(lambda a: run(a, min(a + chunk, n)), range(0, n, chunk)))
+    return left, right
+
+
+def _few_distinct(deg, sample=4096):
+    """cheap guess BEFORE sorting the whole vector: do evenly spaced samples repeat each other?  (unit-weight graphs: a few
+    hundred distinct degrees among millions of nodes; real-valued weights: every degree its own)"""
+    n = deg.numel()
+    if n <= 4 * sample:
+        return True
+    s = deg[:: n // sample][:sample]
+    return torch.unique(s).numel() * 2 <= s.numel()
+
+
+def degree_powers(deg, r, host_pow=True):
+    """deg^(r-1), deg^(-r) with inf -> 0 (operators/utils.py:79-84) as two fp64 tensors on deg's device.
+
+    host_pow=True: evaluated on the HOST by numpy exactly as the reference does: the same routine, hence bit-identical
+    degree factors and a bit-identical A_hat.  Only the DISTINCT degree values travel when there are few of them (a unit-weight
+    graph has far fewer distinct degrees than nodes: 2.4 M nodes -> a few thousand values; a strided sample decides, so a
+    vector of all-distinct real-valued degrees is never sorted); otherwise the vector goes through pinned buffers and a team of
+    host threads.  host_pow=False: the device's pow() (sgl_norm_degree_powers), within 1 ulp(fp64) of the host's -- A_hat then
+    differs from the reference's in the last fp32 bit of a handful of entries (tests: <= 1 ulp), far inside the 1e-5 contract.
+    host_pow="auto": the host route when the degrees have few distinct values (it then costs microseconds), the device otherwise.
+    The last result is cached per (degree vector, r, route): an alpha sweep, or re-normalising the same graph, pays once."""
+    r = float(r)
+    for ent in _POW_CACHE:
+        if ent[0] is deg and ent[1] == deg._version and ent[2] == r and ent[3] == host_pow:
+            pow_stats["cache_hits"] += 1
+            return ent[4], ent[5]
+    asked = host_pow
+    few = None
+    if host_pow == "auto":
+        # host route (bit-identical to the reference) whenever it is cheap -- few distinct degrees: every unit-weight graph --
+        # the device's pow() when every node has its own real-valued degree
+        few = (not deg.is_cuda) or deg.numel() <= 4096 or _few_distinct(deg)
+        host_pow = few
+    if deg.is_cuda and not host_pow:
+        left, right = torch.empty_like(deg), torch.empty_like(deg)
+        with torch.cuda.device(deg.device):
+            check(lib().sgl_norm_degree_powers(deg.numel(), ptr(deg), r, ptr(left), ptr(right), current_stream_ptr()),
+                  "sgl_norm_degree_powers")
+        pow_stats["device"] += 1
+    elif deg.is_cuda and deg.numel() > 4096 and (few if few is not None else _few_distinct(deg)):
         uniq, inv = torch.unique(deg, return_inverse=True)
-        if uniq.numel() * 4 <= deg.numel():
-            lu, ru = host(uniq)
-            return lu.to(deg.device)[inv], ru.to(deg.device)[inv]
-    left, right = host(deg)
-    return left.to(deg.device), right.to(deg.device)
+        lu, ru = _host_powers(uniq.cpu().numpy(), r)
+        left, right = torch.from_numpy(lu).to(deg.device)[inv], torch.from_numpy(ru).to(deg.device)[inv]
+        pow_stats["host_unique"] += 1
+    elif deg.is_cuda:
+        from . import hostpool
+        n = deg.numel()
+        bufs = [hostpool.take((n,), torch.float64) if n >= (1 << 20) else None for _ in range(3)]
+        h = bufs[0] if bufs[0] is not None else torch.empty(n, dtype=torch.float64)
+        h.copy_(deg)
+        hl, hr = _host_powers(h.numpy(), r)
+        outs = []
+        for src, buf in ((hl, bufs[1]), (hr, bufs[2])):
+            t = torch.from_numpy(src)
+            if buf is not None:
+                buf.copy_(t)
+                t = buf
+            outs.append(t.to(deg.device, non_blocking=buf is not None))
+        torch.cuda.current_stream(deg.device).synchronize()      # the pinned buffers go back to the pool
+        left, right = outs
+        pow_stats["host_full"] += 1
+    else:
+        hl, hr = _host_powers(deg.detach().numpy().astype(np.float64, copy=False), r)
+        left, right = torch.from_numpy(hl), torch.from_numpy(hr)
+    _POW_CACHE[:] = [(deg, deg._version, r, asked, left, right)]
+    return left, right
+
+
+def clear_power_cache():
+    _POW_CACHE.clear()
 
 
 class PreparedAdjacency:
@@ -439,20 +517,17 @@ class PreparedAdjacency:
             self.symmetric = int(fp.item()) == 0
         self.nnz_out = m
 
-    def normalize(self, r, alpha=None, return_fp64=False):
+    def normalize(self, r, alpha=None, return_fp64=False, host_pow=True):
         """A_hat for this (r, alpha).  Symmetric A: one scaling pass over A + I, A_hat[j,i] = (A'[j,i] L[j]) R[i] -- no
         transposition; otherwise the general pipeline (transpose by stable sort), re-using the degrees computed here.
-        Both are bit-identical to the reference's scipy result."""
+        Both are bit-identical to the reference's scipy result (host_pow=True; see degree_powers).  PPR requests keep the fp64
+        Laplacian of their r: the next alpha of a sweep is one stream over it (sgl_norm_block_mix), bit-identical to the one-pass form."""
         dev = self.rowptr.device
-        left, right = degree_powers(self.deg, r)
         with torch.cuda.device(dev):
             if self.symmetric:
-                o_val = torch.empty(self.nnz_out, dtype=torch.float32, device=dev)
-                o_v64 = torch.empty(self.nnz_out, dtype=torch.float64, device=dev) if return_fp64 else None
-                check(lib().sgl_norm_block_scale(self.n, 0, ptr(self.rowptr), ptr(self.col), ptr(self.t64), ptr(left), ptr(right),
-                                                 int(alpha is not None), float(alpha if alpha is not None else 0.0), ptr(o_val),
-                                                 ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_scale")
-                return (self.rowptr, self.col, o_val, o_v64) if return_fp64 else (self.rowptr, self.col, o_val)
+                vals = _scaled_values(self, self.n, 0, self.rowptr, self.col, self.t64, self.deg, r, alpha, return_fp64, host_pow)
+                return (self.rowptr, self.col) + vals
+            left, right = degree_powers(self.deg, r, host_pow)
             rowptr, col, val = self.src
             m = self.nnz_out
             o_ptr = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
@@ -466,6 +541,46 @@ class PreparedAdjacency:
         return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
 
 
+def _scaled_values(owner, n_loc, row0, rowptr, col, t64, deg, r, alpha, return_fp64, host_pow, keep_hat64=None):
+    """the (r, alpha)-dependent pass over a prepared T' = T + I (rows [row0, row0 + n_loc), global column ids; `deg` = the global
+    degree vector): returns (val32,) or (val32, val64).  `owner` carries the one-entry cache of the fp64 Laplacian values
+    (`_hat64` = ((r, host_pow), tensor)): kept when a PPR matrix is asked for (or keep_hat64=True), so that the other alphas of a
+    sweep at the same r skip the degree factors and the R gather altogether."""
+    dev = rowptr.device
+    m = int(col.numel())
+    key = (float(r), host_pow)
+    keep = (alpha is not None) if keep_hat64 is None else bool(keep_hat64)
+    cached = getattr(owner, "_hat64", None)
+    hat64 = cached[1] if (cached is not None and cached[0] == key) else None
+    o_val = torch.empty(m, dtype=torch.float32, device=dev)
+    o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
+    if hat64 is None:
+        left, right = degree_powers(deg, r, host_pow)
+        left_loc = left if (row0 == 0 and n_loc == left.numel()) else left[row0:row0 + n_loc].contiguous()
+        if alpha is None or not keep:
+            if keep:                                 # Laplacian asked for, values to be kept: the fp64 output IS the cache entry
+                o_v64 = o_v64 if o_v64 is not None else torch.empty(m, dtype=torch.float64, device=dev)
+            check(lib().sgl_norm_block_scale(n_loc, row0, ptr(rowptr), ptr(col), ptr(t64), ptr(left_loc), ptr(right),
+                                             int(alpha is not None), float(alpha if alpha is not None else 0.0), ptr(o_val),
+                                             ptr(o_v64) if o_v64 is not None else None, current_stream_ptr()), "sgl_norm_block_scale")
+            if keep:
+                owner._hat64 = (key, o_v64)
+            return (o_val, o_v64) if return_fp64 else (o_val,)
+        # PPR with the cache empty: the Laplacian in fp64 first (o_val is scratch for its fp32 rounding), then the mix below
+        hat64 = torch.empty(m, dtype=torch.float64, device=dev)
+        check(lib().sgl_norm_block_scale(n_loc, row0, ptr(rowptr), ptr(col), ptr(t64), ptr(left_loc), ptr(right), 0, 0.0,
+                                         ptr(o_val), ptr(hat64), current_stream_ptr()), "sgl_norm_block_scale")
+        owner._hat64 = (key, hat64)
+    if alpha is None:
+        # Laplacian again at a cached r: alpha = 0 would multiply by 1.0 and add 0.0 to the diagonal -- exact, but a plain rounding
+        # pass says what it does
+        o_val.copy_(hat64)
+        return (o_val, hat64.clone()) if return_fp64 else (o_val,)
+    check(lib().sgl_norm_block_mix(n_loc, row0, ptr(rowptr), ptr(col), ptr(hat64), float(alpha), ptr(o_val),
+                                   ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_mix")
+    return (o_val, o_v64) if return_fp64 else (o_val,)
+
+
 def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_pow=True, prepared=None):
     """Device adj_to_symmetric_norm (+ optional PPR mix): canonical CSR of A on device -> CSR of A_hat.
     rowptr int64 [n+1], col int32, val float32 (CUDA).  Returns (rowptr, col, val[, val64]).
@@ -473,9 +588,9 @@ def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_po
     non-zero stays on the GPU; the rounded A_hat is then bit-identical to scipy's.  `prepared`: a PreparedAdjacency of the
     same matrix (re-used across r / alpha); host_pow=False is the all-device pipeline with the GPU's pow()."""
     _lib.require_gpu()
-    if host_pow:
+    if host_pow or prepared is not None:
         prep = prepared if prepared is not None else PreparedAdjacency(rowptr, col, val, n)
-        return prep.normalize(r, alpha, return_fp64=return_fp64)
+        return prep.normalize(r, alpha, return_fp64=return_fp64, host_pow=host_pow)
     nnz = int(col.numel())
     dev = rowptr.device
     nnz_out = c_int64(0)
@@ -493,56 +608,80 @@ def normalize_adj(rowptr, col, val, n, r, alpha=None, return_fp64=False, host_po
     return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
 
 
-def normalize_block(rowptr, col, val, row0, n_cols, r, alpha=None, symmetric=True, group=None, return_fp64=False, deg=None):
+class PreparedBlock:
+    """Everything about ONE RANK'S row block that does not depend on (r, alpha): T' = T + I for rows [row0, row0 + n_local) of
+    T = A^T (symmetric=True: of A itself) as CSR with fp64 values (sgl_norm_block_build), and the GLOBAL degree vector of A + I
+    (`deg`, fp64 [n_cols]).  The only communication is that vector: the blocks' row sums when A is symmetric, an all-reduce of
+    the column sums otherwise; a caller that already holds it passes `deg=` and nothing is communicated.  One preparation then
+    serves every normalize(r, alpha) of the block: the degree factors are cached per r (degree_powers), a PPR sweep keeps the
+    fp64 Laplacian of its r, so (r, alpha) costs one pass over the block -- what a PaSca sweep over graph operators pays per
+    candidate (sgl/search/search_config.py:14-15)."""
+
+    def __init__(self, rowptr, col, val, row0, n_cols, symmetric=True, group=None, deg=None):
+        import torch.distributed as dist
+        _lib.require_gpu()
+        dev = rowptr.device
+        n_loc = int(rowptr.numel()) - 1
+        nnz = int(col.numel())
+        nnz_out = c_int64(0)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.n_local, self.row0, self.n_cols, self.symmetric = n_loc, int(row0), int(n_cols), bool(symmetric)
+        with torch.cuda.device(dev):
+            check(lib().sgl_norm_block_prepare(n_loc, row0, nnz, ptr(rowptr), ptr(col), ctypes.byref(nnz_out),
+                                               current_stream_ptr()), "sgl_norm_block_prepare")
+            m = nnz_out.value
+            self.rowptr = torch.empty(n_loc + 1, dtype=torch.int64, device=dev)
+            self.col = torch.empty(m, dtype=torch.int32, device=dev)
+            self.t64 = torch.empty(m, dtype=torch.float64, device=dev)
+            rowsum = torch.empty(n_loc, dtype=torch.float64, device=dev)
+            check(lib().sgl_norm_block_build(n_loc, row0, nnz, ptr(rowptr), ptr(col), ptr(val), m, ptr(self.rowptr), ptr(self.col),
+                                             ptr(self.t64), ptr(rowsum), current_stream_ptr()), "sgl_norm_block_build")
+            if deg is not None:
+                if deg.numel() != n_cols:
+                    raise ValueError("deg must hold one entry per column")
+                deg = deg.to(dev)
+            elif symmetric:
+                if multi:
+                    deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
+                    deg[row0:row0 + n_loc] = rowsum
+                    dist.all_reduce(deg, group=group)      # blocks are disjoint: the sum IS the concatenation (exact)
+                else:
+                    if n_loc != n_cols or row0 != 0:
+                        raise ValueError("a single process must hold the whole matrix")
+                    deg = rowsum
+            else:
+                deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
+                check(lib().sgl_norm_block_colsum(n_cols, m, ptr(self.col), ptr(self.t64), ptr(deg), current_stream_ptr()),
+                      "sgl_norm_block_colsum")
+                if multi:
+                    dist.all_reduce(deg, group=group)
+        self.deg = deg
+        self.nnz_out = m
+        self._hat64 = None
+
+    def normalize(self, r, alpha=None, return_fp64=False, host_pow=True, keep_hat64=None):
+        """(rowptr, col, val[, val64]) of this block of A_hat (local row pointers, global column ids)"""
+        with torch.cuda.device(self.rowptr.device):
+            vals = _scaled_values(self, self.n_local, self.row0, self.rowptr, self.col, self.t64, self.deg, r, alpha, return_fp64,
+                                  host_pow, keep_hat64)
+        return (self.rowptr, self.col) + vals
+
+    def drop_values(self):
+        """release the cached fp64 Laplacian (8 bytes per non-zero)"""
+        self._hat64 = None
+
+
+def normalize_block(rowptr, col, val, row0, n_cols, r, alpha=None, symmetric=True, group=None, return_fp64=False, deg=None,
+                    host_pow=True, prepared=None):
     """Rows [row0, row0 + n_local) of A_hat from the same rows of T = A^T (symmetric=True: of A itself), each rank of a
     row-sharded job on its own block (sgl_norm_block_*).  The only communication is the degree vector: an all-gather of
     the blocks' row sums when A is symmetric, an all-reduce of the column sums otherwise.  Without an initialised
     process group (or world size 1) the block must be the whole matrix.  Returns (rowptr, col, val[, val64]) of the block
     (local row pointers, global column ids).  `deg` (fp64 [n_cols], any device): the global degree vector of A + I if
-    the caller already has it -- then nothing is communicated at all."""
-    import torch.distributed as dist
-    _lib.require_gpu()
-    dev = rowptr.device
-    n_loc = int(rowptr.numel()) - 1
-    nnz = int(col.numel())
-    nnz_out = c_int64(0)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    with torch.cuda.device(dev):
-        check(lib().sgl_norm_block_prepare(n_loc, row0, nnz, ptr(rowptr), ptr(col), ctypes.byref(nnz_out),
-                                           current_stream_ptr()), "sgl_norm_block_prepare")
-        m = nnz_out.value
-        o_ptr = torch.empty(n_loc + 1, dtype=torch.int64, device=dev)
-        o_col = torch.empty(m, dtype=torch.int32, device=dev)
-        t64 = torch.empty(m, dtype=torch.float64, device=dev)
-        rowsum = torch.empty(n_loc, dtype=torch.float64, device=dev)
-        check(lib().sgl_norm_block_build(n_loc, row0, nnz, ptr(rowptr), ptr(col), ptr(val), m, ptr(o_ptr), ptr(o_col),
-                                         ptr(t64), ptr(rowsum), current_stream_ptr()), "sgl_norm_block_build")
-        if deg is not None:
-            if deg.numel() != n_cols:
-                raise ValueError("deg must hold one entry per column")
-        elif symmetric:
-            if multi:
-                deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
-                deg[row0:row0 + n_loc] = rowsum
-                dist.all_reduce(deg, group=group)      # blocks are disjoint: the sum IS the concatenation (exact)
-            else:
-                if n_loc != n_cols or row0 != 0:
-                    raise ValueError("a single process must hold the whole matrix")
-                deg = rowsum
-        else:
-            deg = torch.zeros(n_cols, dtype=torch.float64, device=dev)
-            check(lib().sgl_norm_block_colsum(n_cols, m, ptr(o_col), ptr(t64), ptr(deg), current_stream_ptr()),
-                  "sgl_norm_block_colsum")
-            if multi:
-                dist.all_reduce(deg, group=group)
-        left, right = degree_powers(deg.to(dev), r)
-        left_loc = left[row0:row0 + n_loc].contiguous()
-        o_val = torch.empty(m, dtype=torch.float32, device=dev)
-        o_v64 = torch.empty(m, dtype=torch.float64, device=dev) if return_fp64 else None
-        check(lib().sgl_norm_block_scale(n_loc, row0, ptr(o_ptr), ptr(o_col), ptr(t64), ptr(left_loc), ptr(right),
-                                         int(alpha is not None), float(alpha if alpha is not None else 0.0), ptr(o_val),
-                                         ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_scale")
-    return (o_ptr, o_col, o_val, o_v64) if return_fp64 else (o_ptr, o_col, o_val)
+    the caller already has it -- then nothing is communicated at all.  `prepared`: a PreparedBlock of the same block (the
+    (r, alpha)-independent part, re-used across a sweep); host_pow: see degree_powers (True = bit-identical to the reference)."""
+    prep = prepared if prepared is not None else PreparedBlock(rowptr, col, val, row0, n_cols, symmetric=symmetric, group=group, deg=deg)
+    return prep.normalize(r, alpha, return_fp64=return_fp64, host_pow=host_pow, keep_hat64=None if prepared is not None else False)
 
 
 # ------------------------------------------------------------------------------------------------

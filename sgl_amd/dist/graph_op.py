@@ -58,6 +58,31 @@ class ShardedGraphOp:
     def _gloo(self):
         return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "gloo"
 
+    def _normalize_block(self, blk):
+        """this rank's rows of A_hat.  The (r, alpha)-independent part (T + I in fp64, the global degree vector: the only
+        communication) is kept ON the RowBlock (sgl_amd.config.cache_prepared), so the next operator over the same block -- the
+        other graph operators of a PaSca sweep, the r values of the NAFS ensemble -- pays one pass over its non-zeros.  The
+        degree powers come from the host's numpy (bit-identical to the reference's A_hat) under strict_order and whenever the
+        degrees have few distinct values (every unit-weight graph: microseconds); real-valued degrees outside strict_order use the
+        device's pow() (A_hat within 1 ulp(fp32); no round trip of an N-vector through the host)."""
+        from .. import config
+        from .. import device as dev
+        from ..operators.base_op import AdjIdentity
+        prep = None
+        if config.cache_prepared:
+            held = getattr(blk, "_prepared", None)
+            world = self._ranks()[1]
+            if held is not None and held[0] == (self.symmetric, world) and held[1].matches(blk):
+                prep = held[2]
+            else:
+                prep = dev.PreparedBlock(blk.rowptr, blk.col, blk.val, blk.lo, blk.n, symmetric=self.symmetric, group=self.group)
+                try:
+                    blk._prepared = ((self.symmetric, world), AdjIdentity(blk), prep)
+                except AttributeError:
+                    pass
+        return dev.normalize_block(blk.rowptr, blk.col, blk.val, blk.lo, blk.n, self.r, self.alpha, symmetric=self.symmetric,
+                                   group=self.group, host_pow=True if self.strict_order else "auto", prepared=prep)
+
     def _propagate_block(self, blk, feature):
         """row-sharded storage: normalise and multiply this rank's rows only"""
         from .. import device as dev
@@ -67,8 +92,7 @@ class ShardedGraphOp:
             raise ValueError("a RowBlock adjacency implies the row-sharded layout")
         key = ("block", world, rank, blk.lo, blk.hi)
         if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(blk):
-            rowptr, col, val = dev.normalize_block(blk.rowptr, blk.col, blk.val, blk.lo, blk.n, self.r, self.alpha,
-                                                   symmetric=self.symmetric, group=self.group)
+            rowptr, col, val = self._normalize_block(blk)
             nblk = RowBlock(blk.lo, blk.hi, blk.n, rowptr, col, val)
             self._cache = [key, None, None, None]
             self._cache_ident = AdjIdentity(blk)
@@ -220,8 +244,7 @@ class ShardedGraphOp:
                 # storage already row-sharded: normalise the block where it lies, then assemble the normalised matrix on every rank
                 # (27 GB of CSR at papers100M size: affordable once, for the plan) to find and apply the relabelling
                 from .sharded_adj import allgather_blocks
-                rp_b, c_b, v_b = dev.normalize_block(adj.rowptr, adj.col, adj.val, adj.lo, n, self.r, self.alpha,
-                                                     symmetric=self.symmetric, group=self.group)
+                rp_b, c_b, v_b = self._normalize_block(adj)
                 rowptr, col, val = allgather_blocks(RowBlock(adj.lo, adj.hi, n, rp_b, c_b, v_b), self.group)
                 self._block_bounds = None
             else:

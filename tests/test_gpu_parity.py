@@ -489,6 +489,72 @@ def test_row_block_normalisation_matches_full(goldens, cuda, gname):
             assert np.array_equal(np.concatenate(vals), fval.cpu().numpy())
 
 
+def test_prepared_block_serves_an_r_alpha_sweep(goldens, cuda):
+    """PreparedBlock: T + I and the degree vector once per row block; every (r, alpha) of a sweep is then ONE pass over the block.
+    A PPR request keeps the fp64 Laplacian of its r, the next alpha is a pure stream over it (sgl_norm_block_mix) -- all of it
+    bit-identical to the reference goldens; the degree powers are evaluated once per r (cache hit counted)."""
+    from sgl_amd.operators.utils import canonical_csr
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(cuda)  # noqa: E731
+    g1 = goldens.npz("g1_norm")
+    for gname in ("pl2000", "dir40"):
+        g = canonical_csr(goldens.graph(gname))
+        n = g.shape[0]
+        symmetric = gname != "dir40"
+        t = g if symmetric else sp.csr_matrix(g.T)
+        t.sort_indices()
+        lo, hi = n // 4, n - 3                               # a proper block: the degrees of the other rows come from `deg`
+        gp, gc, gv = to(g.indptr, np.int64), to(g.indices, np.int32), to(g.data, np.float32)
+        deg = torch.empty(n, dtype=torch.float64, device=cuda)
+        _lib.check(_lib.lib().sgl_norm_degrees(n, 0, _lib.ptr(gp), _lib.ptr(gc), _lib.ptr(gv), _lib.ptr(deg), _lib.current_stream_ptr()))
+        rp = t.indptr[lo:hi + 1].astype(np.int64) - int(t.indptr[lo])
+        cc, vv = t.indices[t.indptr[lo]:t.indptr[hi]], t.data[t.indptr[lo]:t.indptr[hi]]
+        prep = dev.PreparedBlock(to(rp, np.int64), to(cc, np.int32), to(vv, np.float32), lo, n, symmetric=symmetric, deg=deg)
+        full_ptr = g1[gname + "|indptr"]
+        a0, a1 = int(full_ptr[lo]), int(full_ptr[hi])
+        dev.clear_power_cache()
+        hits0 = dev.pow_stats["cache_hits"]
+        for kind, r, a in [("ppr", 0.5, 0.1), ("ppr", 0.5, 0.15), ("lap", 0.5, None), ("ppr", 0.5, 0.3), ("lap", 0.3, None),
+                           ("ppr", 0.3, 0.15), ("ppr", 0.5, 0.2)]:
+            key = f"{gname}|{kind}|{r}" + ("" if a is None else f"|{a}")
+            p_, c_, v32, v64 = prep.normalize(r, a, return_fp64=True)
+            assert np.array_equal(p_.cpu().numpy(), full_ptr[lo:hi + 1] - a0) and np.array_equal(c_.cpu().numpy(), g1[gname + "|indices"][a0:a1])
+            assert np.array_equal(v32.cpu().numpy(), g1[key][a0:a1].astype(np.float32)), key
+            assert np.abs(v64.cpu().numpy() - g1[key][a0:a1]).max() <= 1e-14 * np.abs(g1[key]).max(), key
+            one_pass = dev.normalize_block(to(rp, np.int64), to(cc, np.int32), to(vv, np.float32), lo, n, r, a, symmetric=symmetric,
+                                           deg=deg, return_fp64=True)
+            assert torch.equal(one_pass[2], v32) and torch.equal(one_pass[3], v64), key          # cached and one-pass routes: same bits
+        assert prep._hat64[0][0] == 0.5 and dev.pow_stats["cache_hits"] > hits0
+        prep.drop_values()
+        assert prep._hat64 is None
+    # route selection: unit weights -> few distinct degrees -> the host route even under "auto"; real-valued weights -> device pow
+    g = canonical_csr(goldens.graph("pl2000")).copy()
+    n = g.shape[0]
+    big = sp.block_diag([g] * 12).tocsr()                    # 24 000 nodes: beyond the small-vector shortcut
+    big.data = (1.0 + np.random.default_rng(0).random(big.nnz)).astype(np.float32)
+    big = ((big + big.T) * 0.5).tocsr()                      # real-valued symmetric weights: every node its own degree
+    big.sort_indices()
+    for mat, want in ((sp.block_diag([g] * 12).tocsr(), "host_unique"), (big, "device")):
+        mat.sort_indices()
+        nb = mat.shape[0]
+        prep = dev.PreparedBlock(to(mat.indptr, np.int64), to(mat.indices, np.int32), to(mat.data, np.float32), 0, nb)
+        dev.clear_power_cache()
+        before = dict(dev.pow_stats)
+        _, _, v_auto = prep.normalize(0.5, None, host_pow="auto")
+        assert dev.pow_stats[want] == before[want] + 1, (want, dev.pow_stats, before)
+        _, _, v_host = prep.normalize(0.5, None, host_pow=True)
+        ref = oracle.sym_norm_csr(mat.indptr, mat.indices, mat.data, nb, 0.5, None)[2].astype(np.float32)
+        assert np.array_equal(v_host.cpu().numpy(), ref)                                           # host route: bit-identical
+        assert np.allclose(v_auto.cpu().numpy(), ref, rtol=1.2e-7, atol=0)                          # device pow: <= 1 ulp(fp32)
+    # the host route of an all-distinct vector goes through the thread team in chunks: same values as one numpy call
+    d = np.random.default_rng(1).random(3_000_000) * 50 + 0.5
+    l1, r1 = dev._host_powers(d, 0.3)
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(l1, np.power(d, 0.3 - 1)) and np.array_equal(r1, np.power(d, -0.3))
+    dt = torch.from_numpy(d).to(cuda)
+    lt, rt = dev.degree_powers(dt, 0.3, host_pow=True)
+    assert np.array_equal(lt.cpu().numpy(), l1) and np.array_equal(rt.cpu().numpy(), r1)
+
+
 def test_hashed_directed_blocks_normalise_like_the_whole_matrix(cuda):
     """S4 path in small: hashed (directed, unsorted, possibly duplicated) row blocks -> canonicalize_block ->
     sgl_norm_block_*(symmetric=False) with the degree vector summed over the blocks' column sums == the whole-matrix
