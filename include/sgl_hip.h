@@ -327,6 +327,17 @@ int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, floa
                  float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
 int sgl_nafs_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo, int64_t pad_cols,
                         float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream);
+/* NAFS hop sweep (NodeClusteringNAFS._execute: _k_hop_cluster(hop) for EVERY hop of a range, tasks/node_clustering.py:139,176-178,
+ * 205-241; twin tasks/link_prediction.py:233-284): the over-smoothing-distance aggregate of every PREFIX X_0..X_h of the hop list in
+ * one pass -- running numerator sum e^{c_j} X_j and denominator sum e^{c_j}, c_j = cos(X_0, X_j) as in sgl_nafs_f32; each hop element
+ * is read once.  Bit h of emit_mask set = emit prefix h (h < n_hops) into h_out[rank of the bit among the set bits] (pitch h_ldo[.],
+ * 16-byte aligned, multiple of 4 floats; pad_cols as in the *_padded entry points).  combine says what happens to the values already
+ * there (the multi-r ensemble, node_clustering.py:242-249): 0 = overwrite, 1 = add, 2 = add then divide by `divisor` (the last r of
+ * 'mean'), 3 = element-wise max.  d <= 512.  Agrees with the per-prefix sgl_nafs_f32 to fp32 rounding (softmax without the max
+ * subtraction: |c| <= 1), inside the 1e-5 contract. */
+int sgl_nafs_prefix_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, uint64_t emit_mask, float *const *h_out,
+                        const int64_t *h_ldo, int64_t pad_cols, int combine, float divisor, int64_t n, int64_t d, void *stream);
+
 /* Learnable gate in one pass (LearnableWeightedMessageOp 'gate', message_op/learnable_weighted_messahe_op.py:67-71 followed by
  * two_dim_weighted_add, operators/utils.py:105-116):  G[n,h] = sigmoid(<X_h[n], vec> + bias),  W[n,:] = softmax_h(G[n,:]),
  * out[n] = sum_h W[n,h] X_h[n].  Every hop element is read once.  d_vec: round_up(d, 4) floats, 16-byte aligned, zero beyond d.

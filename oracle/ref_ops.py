@@ -20,7 +20,7 @@ __all__ = [
     "agg_simple_weighted", "learnable_weights", "agg_learnable_weighted",
     "agg_iterate_learnable", "nafs_weights", "agg_over_smooth_distance",
     "sigmoid32", "softmax32", "parity_ok", "parity_report",
-    "label_propagation", "cs_correct", "cs_smooth", "nafs_task_features", "coo_to_csr",
+    "label_propagation", "cs_correct", "cs_smooth", "nafs_task_features", "nafs_task_sweep", "coo_to_csr",
 ]
 
 # ----------------------------------------------------------------------------------------------
@@ -449,6 +449,14 @@ def nafs_task_features(indptr, indices, data, n, x, hops, r_list, method):
     if method == "max":
         return agg_max(per_r, 0, len(per_r))
     return np.hstack(per_r)
+
+
+def nafs_task_sweep(indptr, indices, data, n, x, hops_list, r_list, method):
+    """NodeClusteringNAFS._execute's loop (sgl/tasks/node_clustering.py:139,176-178): _k_hop_cluster(hop) for every hop count of
+    `hops` (an int means range(hops)), each one independently from X_0 exactly as the reference does -- the checker of the
+    one-propagation sweep (sgl_amd.tricks.nafs_ensemble_sweep).  Returns {hop count: features}."""
+    hops_list = range(hops_list) if isinstance(hops_list, int) else hops_list
+    return {int(h): nafs_task_features(indptr, indices, data, n, x, int(h), r_list, method) for h in hops_list}
 
 
 def coo_to_csr(row, col, data, n):

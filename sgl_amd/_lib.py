@@ -99,6 +99,8 @@ PROTOTYPES = {
                              c_void_p]),
     "sgl_nafs_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                     c_void_p]),
+    "sgl_nafs_prefix_f32": (c_int, [c_int, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_int64, c_int, c_float, c_int64, c_int64,
+                                    c_void_p]),
     "sgl_hop_gate_padded_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "sgl_hop_recursive_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p, c_int64,

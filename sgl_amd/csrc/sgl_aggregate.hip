@@ -428,6 +428,94 @@ __device__ __forceinline__ void store_row(float *__restrict__ orow, const f4 (&a
     }
 }
 
+// NAFS hop SWEEP: every prefix of the hop list in ONE pass.  The clustering / link-prediction tasks evaluate hops = 0, 1, ..., K
+// (tasks/node_clustering.py:139,176-178: _k_hop_cluster(hop) for every hop of the range), each from scratch: sum_h h SpMMs and as
+// many aggregations per r.  The cosine score c_j = <X_0, X_j> / (|X_j| + 1e-10) / (|X_0| + 1e-10) of hop j does not depend on how
+// many hops follow, and softmax_j(c)_j = e^{c_j} / sum_{i <= h} e^{c_i}, so with a running numerator sum_{j <= h} e^{c_j} X_j and
+// denominator the feature matrix of EVERY prefix h falls out of one stream over the K + 1 hop matrices (|c| <= 1: no max to
+// subtract).  Each hop element is read once; a row is emitted (numerator / denominator) after the hops whose bit is set in
+// `emit`, into outs[rank of the bit], where it is combined with what the earlier r values of the ensemble left there:
+//   0 store   1 add (Python's sum(): ((0 + f_r0) + f_r1) + ...)   2 add, then true division by `divisor` (the last r of 'mean')
+//   3 max (values only, NaN like torch)                                   (node_clustering.py:242-249)
+// Registers: X_0, the numerator and kPrefixUnroll hop vectors in flight per lane -- independent of the number of hops.
+constexpr int kPrefixUnroll = 4;
+
+template <int LPR, int CH>
+__global__ __launch_bounds__(256) void nafs_prefix_kernel(const Hops hx, const int n_hops, const uint64_t emit, const HopsOut outs,
+                                                          const int combine, const float divisor, const int64_t n, const int d,
+                                                          const int dw) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    f4 x0[CH], acc[CH];
+    bool on[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        on[c] = live && ((c * LPR + l) * 4 < d);
+        x0[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (on[c]) x0[c] = load_masked<4, true>(hx.p[0] + r * hx.ld[0], (c * LPR + l) * 4, d);
+    }
+    float n0 = 1.f, den = 0.f;
+    for (int hb = 0; hb < n_hops; hb += kPrefixUnroll) {
+        f4 x[kPrefixUnroll][CH];
+#pragma unroll
+        for (int u = 0; u < kPrefixUnroll; ++u)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int h = hb + u;
+                x[u][c] = (h == 0) ? x0[c] : (f4){0.f, 0.f, 0.f, 0.f};
+                if (h > 0 && h < n_hops && on[c]) x[u][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+            }
+#pragma unroll
+        for (int u = 0; u < kPrefixUnroll; ++u) {
+            const int h = hb + u;
+            if (h >= n_hops) break;
+            float dot = 0.f, sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot = __builtin_fmaf(x0[c][e], x[u][c][e], dot);
+                    sq = __builtin_fmaf(x[u][c][e], x[u][c][e], sq);
+                }
+            dot = group_sum<LPR>(dot);
+            sq = group_sum<LPR>(sq);
+            const float nh = __fadd_rn(__fsqrt_rn(sq), 1e-10f);
+            if (h == 0) n0 = nh;
+            const float ex = expf(__fdiv_rn(__fdiv_rn(dot, nh), n0));
+            den += ex;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(ex, x[u][c][e], acc[c][e]);
+            if ((emit >> h) & 1ull) {
+                const int k = __popcll(emit & ((1ull << h) - 1ull));
+                float *__restrict__ orow = outs.p[k] + r * outs.ld[k];
+                const float inv = __fdiv_rn(1.f, den);
+                f4 o[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[c][e] = acc[c][e] * inv;
+                    if (combine != 0 && on[c]) {
+                        const f4 old = load_masked<4>(orow, (c * LPR + l) * 4, d);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (combine == 3) o[c][e] = nan_max(old[e], o[c][e]);
+                            else o[c][e] = __fadd_rn(old[e], o[c][e]);
+                            if (combine == 2) o[c][e] = __fdiv_rn(o[c][e], divisor);
+                        }
+                    }
+                }
+                store_row<LPR, CH>(orow, o, l, live, d, dw);
+            }
+        }
+    }
+}
+
 // Fused NAFS: one pass over the H hop rows held in registers -> cosine scores -> softmax -> weighted sum.
 // LPR lanes per row, CH float4 chunks per lane (d <= LPR*4*CH), H <= HMAX.  Same arithmetic as the two-pass path.
 template <int LPR, int CH, int HMAX>
@@ -1851,6 +1939,46 @@ SGL_EXPORT int sgl_nafs_padded_f32(int n_hops, const float *const *h_x, const in
 SGL_EXPORT int sgl_nafs_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, float *d_out, int64_t ldo,
                             float *d_w_out, int64_t ldw, int64_t n, int64_t d, void *stream) {
     return sgl_nafs_padded_f32(n_hops, h_x, h_ldx, d_out, ldo, 0, d_w_out, ldw, n, d, stream);
+}
+
+SGL_EXPORT int sgl_nafs_prefix_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, uint64_t emit_mask,
+                                   float *const *h_out, const int64_t *h_ldo, int64_t pad_cols, int combine, float divisor,
+                                   int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d <= 512, "sgl_nafs_prefix_f32: rows of up to 512 floats (d=%lld)", (long long)d);
+    SGL_REQUIRE(combine >= 0 && combine <= 3, "sgl_nafs_prefix_f32: combine must be 0 (store), 1 (add), 2 (add, divide) or 3 (max)");
+    SGL_REQUIRE(combine != 2 || divisor != 0.f, "sgl_nafs_prefix_f32: zero divisor");
+    Hops hx;
+    bool vec4 = true;
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    SGL_REQUIRE(vec4, "sgl_nafs_prefix_f32: hop rows must be 16-byte aligned with pitches that are multiples of 4 floats");
+    SGL_REQUIRE(emit_mask != 0 && (n_hops == 64 || (emit_mask >> n_hops) == 0), "sgl_nafs_prefix_f32: emit_mask must name hops below n_hops");
+    SGL_REQUIRE(h_out && h_ldo, "sgl_nafs_prefix_f32: NULL output arrays");
+    HopsOut outs;
+    const int n_out = __builtin_popcountll(emit_mask);
+    for (int k = 0; k < SGL_MAX_HOPS; ++k) {
+        outs.p[k] = k < n_out ? h_out[k] : nullptr;
+        outs.ld[k] = k < n_out ? h_ldo[k] : 0;
+        if (k < n_out) {
+            SGL_REQUIRE(outs.p[k] && outs.ld[k] >= d && outs.ld[k] % 4 == 0 && aligned_to(outs.p[k], 16),
+                        "sgl_nafs_prefix_f32: output %d must be 16-byte aligned with a pitch >= d that is a multiple of 4 floats", k);
+            const int prc = check_pad("sgl_nafs_prefix_f32", d, pad_cols, outs.ld[k]);
+            if (prc != SGL_OK) return prc;
+        }
+    }
+    if (n == 0 || d == 0) return SGL_OK;
+    hipStream_t st = sgl::as_stream(stream);
+    const RowLayout lay = pick_row_layout(d, 1);
+    const int64_t nblocks = (n + (256 / lay.lpr) - 1) / (256 / lay.lpr);
+    if (!sgl::launch_fits(nblocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "row-wise kernel: too many rows for one launch (shard the matrix)");
+#define SGL_NP(L, C) \
+    hipLaunchKernelGGL((nafs_prefix_kernel<L, C>), dim3((unsigned)nblocks), dim3(256), 0, st, hx, n_hops, emit_mask, outs, combine, divisor, n, (int)d, out_cols(d, pad_cols, (L) * (C) * 4))
+#define SGL_NP_NONE(L, C) (void)0
+    SGL_ROWREG_DISPATCH(SGL_NP, SGL_NP, SGL_NP_NONE, lay);
+#undef SGL_NP_NONE
+#undef SGL_NP
+    SGL_LAUNCH_CHECK("sgl_nafs_prefix_f32");
+    return SGL_OK;
 }
 
 static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, const int64_t *d_dst,

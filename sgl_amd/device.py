@@ -17,7 +17,7 @@ __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency", "PreparedBlock",
     "placed_empty", "MEM_MODES",
-    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate",
+    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
     "gather_rows",
 ]
 
@@ -1152,6 +1152,39 @@ def nafs_aggregate(feats, return_weights=False):
         check(lib().sgl_nafs_padded_f32(H, ptrs, lds, ptr(out), _ld(out), own_pad(out), ptr(w), H, n, d, current_stream_ptr()),
               "sgl_nafs_padded_f32")
     return (out, w) if return_weights else out
+
+
+NAFS_STORE, NAFS_ADD, NAFS_ADD_DIV, NAFS_MAX = 0, 1, 2, 3
+
+
+def nafs_prefix(feats, emit_hops, outs=None, combine=NAFS_STORE, divisor=1.0):
+    """The over-smoothing-distance aggregate (OverSmoothDistanceWeightedOp / node_clustering.py:218-241) of EVERY requested prefix
+    X_0..X_h of the hop list in one pass over the hop matrices (sgl_nafs_prefix_f32): out[k] = NAFS(feats[:emit_hops[k] + 1]).
+    emit_hops: increasing hop indices < len(feats).  outs: matrices from alloc_rows to write / combine into (the multi-r
+    ensemble: NAFS_ADD, NAFS_ADD_DIV with `divisor`, NAFS_MAX), allocated when None.  Returns the list of outputs."""
+    _check_hops(feats)
+    n, d = feats[0].shape
+    emit_hops = [int(h) for h in emit_hops]
+    if not emit_hops or any(b <= a for a, b in zip(emit_hops, emit_hops[1:])) or emit_hops[0] < 0 or emit_hops[-1] >= len(feats):
+        raise ValueError("emit_hops must be increasing hop indices below len(feats)")
+    feats = feats[:emit_hops[-1] + 1]
+    if outs is None:
+        if combine != NAFS_STORE:
+            raise ValueError("combining needs the matrices to combine with")
+        outs = [alloc_rows(n, d, feats[0].device) for _ in emit_hops]
+    if len(outs) != len(emit_hops) or any(tuple(o.shape) != (n, d) or o.dtype != torch.float32 or o.device != feats[0].device for o in outs):
+        raise ValueError("one [n, d] float32 output per requested prefix")
+    pads = {own_pad(o) for o in outs}
+    pad = pads.pop() if len(pads) == 1 else 0
+    mask = 0
+    for h in emit_hops:
+        mask |= 1 << h
+    ptrs, lds = _lib.hop_arrays(feats)
+    optrs, olds = _lib.hop_arrays(outs)
+    with torch.cuda.device(feats[0].device):
+        check(lib().sgl_nafs_prefix_f32(len(feats), ptrs, lds, mask, optrs, olds, pad, int(combine), float(divisor), n, d,
+                                        current_stream_ptr()), "sgl_nafs_prefix_f32")
+    return outs
 
 
 def scatter_rows(x, src, dst, out):

@@ -13,6 +13,7 @@ Fixture families:
   g3_agg.npz   every MessageOp.aggregate output (+ parameter / input gradients for learnable ops)
   g4_models.npz  SGC / GAMLP / NAFS / ... preprocess + model_forward outputs with saved params
   g5_errors.json the exception contract of propagate / aggregate
+  g11            the NAFS task's hop sweep (hops in {0, 1, 3, 6} x every ensemble method)
   g6 / g7 / g8   consumers of the SpMM (label propagation, C&S, NAFS task), ingest, hop-range quirks
   g10_label_reuse.npz BASELINE config 3: the label use / reuse loop around preprocess, through the reference's task code
   g9_config5.npz BASELINE config 5 at its own hop count: PPR / Laplacian k = 10, every MessageOp over H = 11 hops (d = 16, 128)
@@ -436,6 +437,61 @@ def gen_g6():
 
 
 # ------------------------------------------------------------------------------------------
+# G11: the NAFS task's hop SWEEP (tasks/node_clustering.py:139,176-178: _k_hop_cluster(hop) for every hop of `hops`): what the
+#      reference hands to KMeans for hops in {0, 1, 3, 6}, every ensemble method -- the pin of sgl_nafs_prefix_f32 / nafs_ensemble_sweep
+# ------------------------------------------------------------------------------------------
+def gen_g11():
+    for m in ["matplotlib", "matplotlib.pyplot", "munkres"]:
+        try:
+            importlib.import_module(m)
+        except ImportError:
+            sys.modules[m] = MagicMock()
+    if "sgl.tasks" not in sys.modules:
+        pkg = types.ModuleType("sgl.tasks")
+        pkg.__path__ = [REF + "/sgl/tasks"]
+        sys.modules["sgl.tasks"] = pkg
+    import sgl.tasks.node_clustering as nc
+
+    class Captured(Exception):
+        pass
+
+    class FakeKMeans:
+        def __init__(self, *a, **k):
+            pass
+
+        def fit_predict(self, x):
+            FakeKMeans.seen = np.array(x, copy=True)
+            raise Captured()
+
+    nc.KMeans = FakeKMeans
+    g8 = GRAPHS["pl256"]
+    x8 = hash_positive(256, 12, seed=41)
+    x8[5] = 0.0                                      # an all-zero feature row: cosine 0 for every hop (the + 1e-10 quirk)
+
+    class DS:
+        x = x8
+        adj = g8
+        num_node = 256
+
+    out = {"x": x8, "hops": np.array([0, 1, 3, 6]), "r_list": np.array([0.5, 0.3, 0.0])}
+    for method in ("mean", "max", "concat", "simple"):
+        for hops in (0, 1, 3, 6):
+            task = object.__new__(nc.NodeClusteringNAFS)
+            task._NodeClusteringNAFS__dataset = DS
+            task._NodeClusteringNAFS__r_list = [0.5, 0.3, 0]
+            task._NodeClusteringNAFS__method = method
+            task._NodeClusteringNAFS__n_clusters = 3
+            task._NodeClusteringNAFS__n_init = 1
+            task._NodeClusteringNAFS__seed = 0
+            try:
+                task._k_hop_cluster(hops)
+            except Captured:
+                pass
+            out[f"nafs_sweep|{method}|hops{hops}"] = FakeKMeans.seen.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "g11_nafs_sweep.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
 # G7: ingest -- the reference's Edge (sgl/data/base_data.py:8-30) turning COO arrays into the CSR adjacency
 # ------------------------------------------------------------------------------------------
 def gen_g7():
@@ -696,6 +752,7 @@ def main():
     gen_g8()
     gen_g9()
     gen_g10()
+    gen_g11()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):

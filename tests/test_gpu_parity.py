@@ -1933,6 +1933,67 @@ def test_nafs_task_feature_pipeline_matches_reference(goldens, cuda):
     assert torch.equal(csr.set_values(v2).spmm(xd), device_csr(ptr, col, val2, (n, n), cuda).spmm(xd)) and not torch.equal(y1, csr.spmm(xd))
 
 
+def test_nafs_hop_sweep_in_one_propagation(goldens, cuda):
+    """nafs_ensemble_sweep: the feature matrices of EVERY hop count of the NAFS task's sweep from one propagation per r
+    (sgl_nafs_prefix_f32: running numerator / denominator, every hop element read once) against what the reference hands to
+    KMeans for each hop count separately (G11, 1e-5), every ensemble method; then the kernel itself at the widths of every lane
+    layout against the per-prefix kernel, with the ensemble combinations."""
+    from sgl_amd.tricks import nafs_ensemble_features, nafs_ensemble_sweep
+    g11 = goldens.npz("g11_nafs_sweep")
+    g = goldens.graph("pl256")
+    x, hops, r_list = g11["x"], [int(h) for h in g11["hops"]], [float(r) for r in g11["r_list"]]
+    for method in ("mean", "max", "concat", "simple"):
+        sweep = nafs_ensemble_sweep(g, x, hops, r_list, method)
+        assert sorted(sweep) == hops
+        for h in hops:
+            rep = oracle.parity_report(sweep[h].cpu().numpy(), g11[f"nafs_sweep|{method}|hops{h}"], TOL)
+            assert rep["ok"], (method, h, rep)
+            # and the one-hop-count entry point (one propagation + the register-resident kernel) agrees
+            assert oracle.parity_ok(sweep[h].cpu().numpy(), nafs_ensemble_features(g, x, h, r_list, method).cpu().numpy(), TOL)
+    seen = []
+    res = nafs_ensemble_sweep(g, x, 4, r_list, "mean", consume=lambda h, f: seen.append(h) or float(f.sum()))     # int = range(hops)
+    assert seen == [0, 1, 2, 3] and sorted(res) == seen and all(isinstance(v, float) for v in res.values())
+    with pytest.raises(ValueError):
+        nafs_ensemble_sweep(g, x, [1, 64], r_list, "mean")
+    with pytest.raises(ValueError):
+        nafs_ensemble_sweep(g, x, [1], r_list, "median")
+    # the kernel at every lane layout (8 / 16 / 32 / 64 lanes x 1, 16 x 3, 32 x 2, 64 x 2), more hops than the fused kernel holds
+    n, ptr, col, val = norm_graph(goldens, "pl2000", r=0.5)
+    csr = device_csr(ptr, col, val, (n, n), cuda)
+    for d in (3, 20, 36, 100, 128, 147, 200, 300, 500):
+        feats = [dev.upload_rows(hash_matrix(n, d, seed=d), cuda)]
+        for _ in range(21):
+            feats.append(csr.spmm(feats[-1]))
+        emit = [0, 1, 2, 5, 11, 20, 21]
+        outs = dev.nafs_prefix(feats, emit)
+        ref_feats = [f.cpu().numpy() for f in feats]
+        for h, o in zip(emit, outs):
+            want = oracle.agg_over_smooth_distance(ref_feats[:h + 1])
+            assert oracle.parity_ok(o.cpu().numpy(), want, TOL, rowwise=False), (d, h)
+            if h + 1 <= 16:
+                assert oracle.parity_ok(o.cpu().numpy(), dev.nafs_aggregate(feats[:h + 1]).cpu().numpy(), 1e-6, rowwise=False), (d, h)
+            assert float(dev.padded_parent(o)[:, d:].abs().max()) == 0.0 if dev.padded_parent(o).shape[1] > d else True
+        # ensemble combinations: add, add + divide, max -- against torch on the stored outputs
+        base = [o.clone() for o in outs]
+        acc = [dev.alloc_rows(n, d, cuda) for _ in emit]
+        for a, b in zip(acc, base):
+            a.copy_(b * 0.5 - 1.0)
+        keep = [a.clone() for a in acc]
+        dev.nafs_prefix(feats, emit, outs=acc, combine=dev.NAFS_ADD)
+        assert all(torch.equal(a, k + b) for a, k, b in zip(acc, keep, base))
+        dev.nafs_prefix(feats, emit, outs=acc, combine=dev.NAFS_ADD_DIV, divisor=3.0)
+        assert all(torch.equal(a, ((k + b) + b) / 3.0) for a, k, b in zip(acc, keep, base))
+        for a, k in zip(acc, keep):
+            a.copy_(k)
+        dev.nafs_prefix(feats, emit, outs=acc, combine=dev.NAFS_MAX)
+        assert all(torch.equal(a, torch.maximum(k, b)) for a, k, b in zip(acc, keep, base))
+    with pytest.raises(ValueError):
+        dev.nafs_prefix(feats, [3, 2])
+    with pytest.raises(_lib.SglHipError):
+        wide = [dev.upload_rows(hash_matrix(64, 516, seed=1), cuda)] * 2
+        dev.nafs_prefix(wide, [1])
+
+
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
     """Custom_Homo raw layout -> device COO->CSR build (sgl_coo_to_csr) == the reference's Edge/scipy build (G7),
     and a DeviceAdjacency drives GraphOp.propagate without touching the host"""

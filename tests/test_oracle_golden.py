@@ -164,6 +164,30 @@ def test_g6_nafs_task_pipeline(goldens):
         assert rep["ok"], (method, rep)
 
 
+def test_g11_nafs_hop_sweep(goldens):
+    """the reference's per-hop-count loop for hops in {0, 1, 3, 6}, every ensemble method; and the identity the one-pass device
+    sweep rests on: softmax over a PREFIX of the cosine scores = running e^c numerator / denominator (|c| <= 1, no max needed)"""
+    g11 = goldens.npz("g11_nafs_sweep")
+    g = goldens.graph("pl256")
+    x, hops, r_list = g11["x"], [int(h) for h in g11["hops"]], [float(r) for r in g11["r_list"]]
+    for method in ("mean", "max", "concat", "simple"):
+        sweep = oracle.nafs_task_sweep(g.indptr, g.indices, g.data, 256, x, hops, r_list, method)
+        for h in hops:
+            rep = oracle.parity_report(sweep[h], g11[f"nafs_sweep|{method}|hops{h}"], 1e-5)
+            assert rep["ok"], (method, h, rep)
+    feats = oracle.propagate(oracle.sym_norm_csr(g.indptr, g.indices, g.data, 256, 0.3), x, 6)
+    c = np.stack([np.einsum("nd,nd->n", feats[0].astype(np.float64), f.astype(np.float64)) /
+                  (np.linalg.norm(f.astype(np.float64), axis=1) + 1e-10) / (np.linalg.norm(feats[0].astype(np.float64), axis=1) + 1e-10)
+                  for f in feats], 1)
+    assert np.abs(c).max() <= 1 + 1e-12
+    num, den = np.zeros_like(feats[0], dtype=np.float64), np.zeros(256)
+    for h in range(7):
+        num += np.exp(c[:, h])[:, None] * feats[h]
+        den += np.exp(c[:, h])
+        want = oracle.agg_over_smooth_distance(feats[:h + 1])
+        assert oracle.parity_ok((num / den[:, None]).astype(np.float32), want, 1e-6), h
+
+
 def test_g7_ingest_coo_to_csr(goldens):
     g7 = goldens.npz("g7_ingest")
     n = int(g7["n"])
