@@ -1157,11 +1157,14 @@ def nafs_aggregate(feats, return_weights=False):
 NAFS_STORE, NAFS_ADD, NAFS_ADD_DIV, NAFS_MAX = 0, 1, 2, 3
 
 
-def nafs_prefix(feats, emit_hops, outs=None, combine=NAFS_STORE, divisor=1.0):
+def nafs_prefix(feats, emit_hops, outs=None, combine=NAFS_STORE, divisor=1.0, outs_padded=False):
     """The over-smoothing-distance aggregate (OverSmoothDistanceWeightedOp / node_clustering.py:218-241) of EVERY requested prefix
     X_0..X_h of the hop list in one pass over the hop matrices (sgl_nafs_prefix_f32): out[k] = NAFS(feats[:emit_hops[k] + 1]).
     emit_hops: increasing hop indices < len(feats).  outs: matrices from alloc_rows to write / combine into (the multi-r
-    ensemble: NAFS_ADD, NAFS_ADD_DIV with `divisor`, NAFS_MAX), allocated when None.  Returns the list of outputs."""
+    ensemble: NAFS_ADD, NAFS_ADD_DIV with `divisor`, NAFS_MAX), allocated when None; any 16-byte aligned [n, d] views whose pitch
+    is a multiple of 4 floats -- e.g. column slices of one wide slab (the 'concat' ensemble).  outs_padded=True declares that the
+    tail of every output's pitch is its own padding (matrices from alloc_rows): it is then written as zeros so that every line of a
+    row is written whole.  Returns the list of outputs."""
     _check_hops(feats)
     n, d = feats[0].shape
     emit_hops = [int(h) for h in emit_hops]
@@ -1172,9 +1175,10 @@ def nafs_prefix(feats, emit_hops, outs=None, combine=NAFS_STORE, divisor=1.0):
         if combine != NAFS_STORE:
             raise ValueError("combining needs the matrices to combine with")
         outs = [alloc_rows(n, d, feats[0].device) for _ in emit_hops]
+        outs_padded = True
     if len(outs) != len(emit_hops) or any(tuple(o.shape) != (n, d) or o.dtype != torch.float32 or o.device != feats[0].device for o in outs):
         raise ValueError("one [n, d] float32 output per requested prefix")
-    pads = {own_pad(o) for o in outs}
+    pads = {own_pad(o) for o in outs} if outs_padded else {0}
     pad = pads.pop() if len(pads) == 1 else 0
     mask = 0
     for h in emit_hops:

@@ -146,7 +146,12 @@ def nafs_ensemble_sweep(adj, x, hops_list, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), 
                 if method == "mean" and ri == len(r_list) - 1:
                     ens = [e / float(len(r_list)) for e in ens]
             continue
-        if method == "concat":
+        if method == "concat" and d % 4 == 0:
+            # one [N, R d] slab per hop count; the kernel writes r's columns of every slab directly (16-byte aligned slices)
+            if ens is None:
+                ens = [torch.empty((n, len(r_list) * d), dtype=torch.float32, device=device) for _ in hops_list]
+            dev.nafs_prefix(feats, hops_list, outs=[e[:, ri * d:(ri + 1) * d] for e in ens])
+        elif method == "concat":
             for h, o in zip(hops_list, dev.nafs_prefix(feats, hops_list)):
                 slabs[h].append(o)
         elif ens is None:
@@ -156,11 +161,11 @@ def nafs_ensemble_sweep(adj, x, hops_list, r_list=(0.5, 0.4, 0.3, 0.2, 0.1, 0), 
         else:
             last = ri == len(r_list) - 1
             combine = dev.NAFS_MAX if method == "max" else (dev.NAFS_ADD_DIV if last else dev.NAFS_ADD)
-            dev.nafs_prefix(feats, hops_list, outs=ens, combine=combine, divisor=float(len(r_list)))
+            dev.nafs_prefix(feats, hops_list, outs=ens, combine=combine, divisor=float(len(r_list)), outs_padded=True)
     results = {}
     for k, h in enumerate(hops_list):
-        f = dev.hop_concat(slabs.pop(h)) if method == "concat" else ens[k]
+        f = dev.hop_concat(slabs.pop(h)) if (method == "concat" and ens is None) else ens[k]
         results[h] = consume(h, f) if consume is not None else f
-        if consume is not None and method != "concat":
+        if consume is not None and ens is not None:
             ens[k] = None
     return results

@@ -13,6 +13,7 @@ Fixture families:
   g3_agg.npz   every MessageOp.aggregate output (+ parameter / input gradients for learnable ops)
   g4_models.npz  SGC / GAMLP / NAFS / ... preprocess + model_forward outputs with saved params
   g5_errors.json the exception contract of propagate / aggregate
+  g12_fp64_truth.npz  float64 truth (reference modules in .double()) for the learnable ops of g3 / g9 and the g4 logits
   g11            the NAFS task's hop sweep (hops in {0, 1, 3, 6} x every ensemble method)
   g6 / g7 / g8   consumers of the SpMM (label propagation, C&S, NAFS task), ingest, hop-range quirks
   g10_label_reuse.npz BASELINE config 3: the label use / reuse loop around preprocess, through the reference's task code
@@ -648,7 +649,9 @@ def gen_g9():
 #      run on Linux at all: its add_labels (tasks/utils.py:33-36) returns float64 and csr_sparse_dense_matmul's ctypes signature
 #      accepts float32 only (operators/utils.py:16-26) -> ArgumentError on the first preprocess.  The adaptation casts to float32.
 # ------------------------------------------------------------------------------------------
-def gen_g10():
+def _run_label_reuse(fp64):
+    """the reference's label use / reuse task loop; fp64=True: the same loop in float64 (features as add_labels returns them, the model in
+    .double(), propagate through _construct_adj + scipy's dot instead of the float32-only C kernel) -- the truth for G12"""
     mods = import_models()
     pkg = types.ModuleType("sgl.tasks")
     pkg.__path__ = [REF + "/sgl/tasks"]
@@ -660,7 +663,7 @@ def gen_g10():
             sys.modules[m] = MagicMock()
     import sgl.tasks.node_classification_with_label_use as lu
     orig_add = lu.add_labels
-    lu.add_labels = lambda f, y, idx, C: orig_add(f, y, idx, C).astype(np.float32)
+    lu.add_labels = (lambda f, y, idx, C: orig_add(f, y, idx, C)) if fp64 else (lambda f, y, idx, C: orig_add(f, y, idx, C).astype(np.float32))
     lu.train = lambda *a, **k: (0.0, 0.0)
     lu.evaluate = lambda *a, **k: (0.0, 0.0)
     lu.accuracy = lambda *a, **k: 0.0
@@ -688,6 +691,17 @@ def gen_g10():
     torch.manual_seed(11)
     model = mods["gamlp"].GAMLP(K, d + C, C, 64, 2)
     model.eval()                      # the state label reuse runs in: the previous epoch's evaluate() left the model in eval mode
+    if fp64:
+        model = model.double()
+        gop = model._pre_graph_op
+
+        def propagate64(adj, feature):
+            a64 = gop._construct_adj(adj)
+            hops = [np.asarray(feature, dtype=np.float64)]
+            for _ in range(gop._prop_steps):
+                hops.append(a64.dot(hops[-1]))
+            return [torch.from_numpy(h) for h in hops]
+        gop.propagate = propagate64
     out = {"n": n, "d": d, "C": C, "K": K, "train_idx": np.asarray(DS.train_idx), "val_idx": np.asarray(DS.val_idx),
            "test_idx": np.asarray(DS.test_idx), "labels": labels.numpy()}
     for k, v in state_arrays(model).items():
@@ -698,7 +712,7 @@ def gen_g10():
     real_pre = model.preprocess
 
     def spy(adj, features):
-        assert features.dtype == np.float32 and features.shape == (n, d + C)
+        assert features.dtype == (np.float64 if fp64 else np.float32) and features.shape == (n, d + C)
         i = len(calls)
         out[f"call{i}|label_cols_sub"] = features[sub, d:].copy()
         out[f"call{i}|feature_colsum"] = features.astype(np.float64).sum(0)
@@ -731,7 +745,102 @@ def gen_g10():
         logits = model.model_forward(range(n), torch.device("cpu"))
     out["final|logits_sub"] = logits.numpy()[sub].copy()
     out["final|logits_colsum"] = logits.numpy().astype(np.float64).sum(0)
+    return out
+
+
+def gen_g10():
+    out = _run_label_reuse(False)
     np.savez_compressed(os.path.join(HERE, "g10_label_reuse.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+# G12: float64 TRUTH for every floating-point case whose test tolerance would otherwise be chosen by hand: the learnable MessageOps
+#      of G3 / G9 (outputs, parameter gradients, input gradients) and the model logits of G4.  The reference's own modules, built
+#      with the same seeds (hence the same float32 parameters), cast to .double() and fed the same inputs in float64; the hops of
+#      G4 come from the reference's _construct_adj (float64) and scipy's dot.  The tests then require
+#      err(HIP, truth) <= max(2 * err(reference float32, truth), floor) instead of a flat tolerance.
+# ------------------------------------------------------------------------------------------
+def gen_g12():
+    out = {}
+
+    def record(prefix, op, feats32, gout32, stored):
+        op = op.double()
+        fg = [f.detach().double().clone().requires_grad_(True) for f in feats32]
+        y = op.aggregate(fg)
+        (y * gout32.double()).sum().backward()
+        out[prefix + "|out"] = y.detach().numpy().copy()
+        for k, p_ in op.named_parameters():
+            out[prefix + "|grad|" + k] = p_.grad.numpy().copy()
+        for j in stored:
+            out[prefix + f"|dfeat{j}"] = (fg[j].grad if fg[j].grad is not None else torch.zeros_like(fg[j])).numpy().copy()
+
+    H = AGG_K + 1
+    gout = torch.from_numpy(hash_matrix(AGG_N, AGG_D, seed=777).copy())
+    for kind, args in (("simple", (AGG_K,)), ("simple_allow_neg", (AGG_K,)), ("gate", (AGG_D,)), ("ori_ref", (AGG_D,)), ("jk", (AGG_K, AGG_D))):
+        for (s, e) in ((0, H), (1, H)):
+            torch.manual_seed(1234 + len(kind) + s)
+            record(f"g3|learnable|{kind}|{s}_{e}", LearnableWeightedMessageOp(s, e, kind, *args), agg_feats(), gout, range(H))
+    torch.manual_seed(99)
+    record("g3|iterate|0_5", IterateLearnableWeightedMessageOp(0, H, "recursive", AGG_D), agg_feats(), gout, range(H))
+    H = G9_K + 1
+    for d, n in G9_AGG.items():
+        P = f"g9|agg|d{d}|"
+        gout = torch.from_numpy(hash_matrix(n, d, seed=778).copy())
+        for kind, args in (("simple", (G9_K,)), ("simple_allow_neg", (G9_K,)), ("gate", (d,)), ("ori_ref", (d,)), ("jk", (G9_K, d))):
+            for (s, e) in ((0, H), (1, H)):
+                torch.manual_seed(4321 + len(kind) + s + d)
+                record(P + f"learnable|{kind}|{s}_{e}", LearnableWeightedMessageOp(s, e, kind, *args), g9_feats(d), gout, G9_DFEAT)
+        torch.manual_seed(98 + d)
+        record(P + f"iterate|0_{H}", IterateLearnableWeightedMessageOp(0, H, "recursive", d), g9_feats(d), gout, G9_DFEAT)
+
+    # G4 logits: same seeds as gen_g4, hops in float64 (reference _construct_adj + scipy dot), modules in double
+    mods = import_models()
+    g = GRAPHS["pl2000"]
+    n, d, C, K = g.shape[0], 16, 5, 3
+    x = hash_matrix(n, d, seed=4242).astype(np.float64)
+    idx = np.arange(0, n, 10)
+    specs = {
+        "SGC": (mods["sgc"].SGC, (K, d, C)), "SSGC": (mods["ssgc"].SSGC, (K, d, C)), "SIGN": (mods["sign"].SIGN, (K, d, C, 32, 2)),
+        "GBP": (mods["gbp"].GBP, (K, d, C, 32, 2)), "GAMLP": (mods["gamlp"].GAMLP, (K, d, C, 32, 2)),
+        "GAMLPRecursive": (mods["gamlp_recursive"].GAMLPRecursive, (K, d, C, 32, 2)), "NAFS": (mods["nafs"].NAFS, (K, d, C)),
+        "PASCA_V1": (mods["pasca_v1"].PASCA_V1, (K, d, C, 32, 3)), "PASCA_V2": (mods["pasca_v2"].PASCA_V2, (K, d, C, 32, 3)),
+        "PASCA_V3": (mods["pasca_v3"].PASCA_V3, (K, 2, d, C, 32, 3)),
+    }
+    for name, (cls, args) in specs.items():
+        torch.manual_seed(7)
+        model = cls(*args)
+        model.eval()
+        adj = model._pre_graph_op._construct_adj(g)                     # float64 scipy CSR
+        hops = [x]
+        for _ in range(model._pre_graph_op._prop_steps):
+            hops.append(adj.dot(hops[-1]))
+        model = model.double()
+        model._processed_feat_list = [torch.from_numpy(h) for h in hops]
+        if model._pre_msg_op.aggr_type in ["proj_concat", "learnable_weighted", "iterate_learnable_weighted"]:
+            model._pre_msg_learnable = True
+        else:
+            model._pre_msg_learnable = False
+            model._processed_feature = model._pre_msg_op.aggregate(model._processed_feat_list)
+        with torch.no_grad():
+            y = model.model_forward(idx, torch.device("cpu"))
+        assert y.dtype == torch.float64, (name, y.dtype)
+        out[f"g4|{name}|out"] = y.numpy().copy()
+        if name == "PASCA_V3":                                          # post-propagation of the softmaxed logits, all in float64
+            with torch.no_grad():
+                full = torch.softmax(model.model_forward(range(n), torch.device("cpu")), dim=1).numpy()
+            padj = model._post_graph_op._construct_adj(g)
+            ph = [full]
+            for _ in range(model._post_graph_op._prop_steps):
+                ph.append(padj.dot(ph[-1]))
+            post = model._post_msg_op.aggregate([torch.from_numpy(h) for h in ph])
+            assert post.dtype == torch.float64
+            out[f"g4|{name}|post"] = post.numpy().copy()[idx]
+    # G10's loop in float64: the label columns before every preprocess call, the final hop rows and logits
+    lr = _run_label_reuse(True)
+    for k, v in lr.items():
+        if k.endswith("|label_cols_sub") or k.startswith("final|hop") or k == "final|logits_sub":
+            out["g10|" + k] = np.asarray(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g12_fp64_truth.npz"), **out)
 
 
 def main():
@@ -753,6 +862,7 @@ def main():
     gen_g9()
     gen_g10()
     gen_g11()
+    gen_g12()
     tot = 0
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".npz", ".json")):
