@@ -310,6 +310,11 @@ int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx
 int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops);
 int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,
                            int64_t lddo, float *d_dw, float *d_scratch, int64_t n, int64_t d, void *stream);
+/* Backward of MaxMessageOp / MinMessageOp (torch.stack(hops).max(0)[0], max_message_op.py:12): dX_h = dOut where hop h is the one
+ * torch selects for the element -- the first NaN if there is one, otherwise the first hop attaining the extremum -- and 0 elsewhere.
+ * op = SGL_REDUCE_MAX or SGL_REDUCE_MIN; h_dx[h] may be NULL for hops that need no gradient. */
+int sgl_hop_select_bwd_f32(int op, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_gout, int64_t ldg,
+                           float *const *h_dx, const int64_t *h_lddx, int64_t n, int64_t d, void *stream);
 /* Row outputs and padding: sgl_hop_concat_padded_f32 / sgl_nafs_padded_f32 / sgl_hop_gate_padded_f32 take `pad_cols` = the number of
  * columns after the row (after column n_hops * d resp. d) that are the row's OWN padding inside its pitch ldo.  They are WRITTEN AS
  * ZEROS, so that every 128-byte line of a row is written whole: a partly written line costs a read-modify-write in the ECC-protected

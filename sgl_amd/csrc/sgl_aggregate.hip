@@ -91,6 +91,59 @@ __global__ __launch_bounds__(256) void hop_reduce_kernel(const Hops hx, const in
     }
 }
 
+// Backward of max / min over hops (max_message_op.py:12 / min_message_op.py:12: torch.stack(...).max(0)[0]): the gradient goes to ONE
+// hop per element -- the first NaN if the element has one, otherwise the first hop that attains the extremum (torch's index rule) --
+// and zeros to the others.  One pass: H hop reads + the incoming gradient, one write per requested dX_h.
+template <bool IS_MAX, int VEC>
+__global__ __launch_bounds__(256) void hop_select_bwd_kernel(const Hops hx, const int n_hops, const float *__restrict__ g,
+                                                             const int64_t ldg, const HopsOut dx, const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * VEC;
+        int sel[VEC];
+        float best[VEC];
+        bool isn[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sel[e] = -1;
+            best[e] = 0.f;
+            isn[e] = false;
+        }
+        for (int h = 0; h < n_hops; ++h) {
+            const V xv = __builtin_nontemporal_load(reinterpret_cast<const V *>(hx.p[h] + row * hx.ld[h] + col));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float x;
+                if constexpr (VEC == 1) x = xv; else x = xv[e];
+                if (!isn[e]) {
+                    if (x != x) {
+                        sel[e] = h;
+                        isn[e] = true;
+                    } else if (sel[e] < 0 || (IS_MAX ? x > best[e] : x < best[e])) {
+                        sel[e] = h;
+                        best[e] = x;
+                    }
+                }
+            }
+        }
+        const V gv = __builtin_nontemporal_load(reinterpret_cast<const V *>(g + row * ldg + col));
+        for (int h = 0; h < n_hops; ++h) {
+            if (dx.p[h] == nullptr) continue;
+            V o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if constexpr (VEC == 1) o = (sel[0] == h) ? gv : 0.f;
+                else o[e] = (sel[e] == h) ? gv[e] : 0.f;
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<V *>(dx.p[h] + row * dx.ld[h] + col));
+        }
+    }
+}
+
 // out[n,k] = sum_h W[n,h] X_h[n,k]; FMA: fma chain from 0 (bmm-like); !FMA: rounded product then add (NAFS loop)
 template <int VEC, bool FMA>
 __global__ __launch_bounds__(256) void hop_wsum2d_kernel(const Hops hx, const int n_hops, const float *__restrict__ w,
@@ -1819,6 +1872,39 @@ SGL_EXPORT int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const
     SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(partial)");
     hipLaunchKernelGGL(hop_dot_final_kernel, dim3(n_hops), dim3(64), 0, st, d_scratch, blocks, n_hops, d_dw);
     SGL_LAUNCH_CHECK("sgl_hop_wsum1d_bwd_f32(final)");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_select_bwd_f32(int op, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_gout,
+                                     int64_t ldg, float *const *h_dx, const int64_t *h_lddx, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(op == SGL_REDUCE_MAX || op == SGL_REDUCE_MIN, "sgl_hop_select_bwd_f32: op must be SGL_REDUCE_MAX or SGL_REDUCE_MIN");
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_select_bwd_f32: bad sizes");
+    Hops hx;
+    bool vec4 = (d % 4 == 0) && (ldg % 4 == 0) && aligned_to(d_gout, 16);
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    SGL_REQUIRE(h_dx && h_lddx, "sgl_hop_select_bwd_f32: NULL gradient arrays");
+    HopsOut dx;
+    for (int h = 0; h < SGL_MAX_HOPS; ++h) {
+        dx.p[h] = h < n_hops ? h_dx[h] : nullptr;
+        dx.ld[h] = h < n_hops ? h_lddx[h] : 0;
+        if (dx.p[h]) {
+            SGL_REQUIRE(dx.ld[h] >= d && aligned_to(dx.p[h], 4), "sgl_hop_select_bwd_f32: bad gradient buffer %d", h);
+            if (dx.ld[h] % 4 != 0 || !aligned_to(dx.p[h], 16)) vec4 = false;
+        }
+    }
+    if (n == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_gout && ldg >= d, "sgl_hop_select_bwd_f32: bad incoming gradient");
+    hipStream_t st = sgl::as_stream(stream);
+    const int grid = stream_grid(n * (d / (vec4 ? 4 : 1)));
+    if (op == SGL_REDUCE_MAX) {
+        if (vec4) hipLaunchKernelGGL((hop_select_bwd_kernel<true, 4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_gout, ldg, dx, n, (int)d);
+        else hipLaunchKernelGGL((hop_select_bwd_kernel<true, 1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_gout, ldg, dx, n, (int)d);
+    } else {
+        if (vec4) hipLaunchKernelGGL((hop_select_bwd_kernel<false, 4>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_gout, ldg, dx, n, (int)d);
+        else hipLaunchKernelGGL((hop_select_bwd_kernel<false, 1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_gout, ldg, dx, n, (int)d);
+    }
+    SGL_LAUNCH_CHECK("sgl_hop_select_bwd_f32");
     return SGL_OK;
 }
 

@@ -17,7 +17,7 @@ __all__ = [
     "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency", "PreparedBlock",
     "placed_empty", "MEM_MODES",
-    "hop_reduce", "hop_concat", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
+    "hop_reduce", "hop_concat", "hop_reduce_grad", "hop_concat_grad", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
     "gather_rows",
 ]
 
@@ -743,6 +743,77 @@ def hop_concat(feats):
         check(lib().sgl_hop_concat_padded_f32(H, ptrs, lds, ptr(out), _ld(out), own_pad(out), n, d, current_stream_ptr()),
               "sgl_hop_concat_padded_f32")
     return out
+
+
+class _ReduceGrad(torch.autograd.Function):
+    """sum / mean / max / min over the hop list WITH gradients (sum_message_op.py:10, mean_message_op.py:10, max_message_op.py:12,
+    min_message_op.py:12): forward = the streaming reduction kernel; backward of sum = the incoming gradient broadcast to every hop,
+    of mean = one true division then the broadcast, of max / min = the gradient where torch would select the hop (first NaN, else the
+    first extremum), zeros elsewhere (sgl_hop_select_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, op, divisor, *feats):
+        feats_d = [f.detach() for f in feats]
+        ctx.op, ctx.divisor = op, divisor
+        if op == _lib.SGL_REDUCE_MEAN and divisor is not None and divisor != len(feats_d):
+            # the reference divides by (end - start) whatever the slice held (mean_message_op.py:10)
+            out = hop_reduce(_lib.SGL_REDUCE_SUM, feats_d)
+            out = out / torch.tensor(float(divisor), device=out.device)
+        else:
+            out = hop_reduce(op, feats_d)
+        if op in (_lib.SGL_REDUCE_MAX, _lib.SGL_REDUCE_MIN):
+            ctx.save_for_backward(*feats_d)
+        ctx.n_hops = len(feats_d)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        H = ctx.n_hops
+        need = [ctx.needs_input_grad[2 + h] for h in range(H)]
+        if ctx.op == _lib.SGL_REDUCE_SUM:
+            return (None, None, *[gout if nd else None for nd in need])
+        if ctx.op == _lib.SGL_REDUCE_MEAN:
+            div = float(ctx.divisor if ctx.divisor is not None else H)
+            g = gout / torch.tensor(div, device=gout.device)         # DivBackward: a true division (0-dim device divisor)
+            return (None, None, *[g if nd else None for nd in need])
+        feats = list(ctx.saved_tensors)
+        n, d = feats[0].shape
+        g = gout.detach().to(torch.float32)
+        if g.stride(1) != 1 or (n > 1 and g.stride(0) < d):
+            g = g.contiguous()
+        dxs = [alloc_rows(n, d, g.device) if nd else None for nd in need]
+        ptrs, lds = _lib.hop_arrays(feats)
+        dx_ptrs = (c_void_p * H)(*[(t.data_ptr() if t is not None else None) for t in dxs])
+        dx_lds = (c_int64 * H)(*[(_ld(t) if t is not None else 0) for t in dxs])
+        with torch.cuda.device(g.device):
+            check(lib().sgl_hop_select_bwd_f32(ctx.op, H, ptrs, lds, ptr(g), _ld(g), dx_ptrs, dx_lds, n, d, current_stream_ptr()),
+                  "sgl_hop_select_bwd_f32")
+        return (None, None, *dxs)
+
+
+def hop_reduce_grad(op, feats, divisor=None):
+    """hop_reduce for hop matrices that carry gradients (op: SGL_REDUCE_SUM / MEAN / MAX / MIN)"""
+    return _ReduceGrad.apply(op, divisor, *feats)
+
+
+class _ConcatGrad(torch.autograd.Function):
+    """hstack of the hop list WITH gradients (concat_message_op.py:12; the tail of ProjectedConcatMessageOp._combine,
+    projected_concat_message_op.py:28): forward = sgl_hop_concat_f32, backward = the column slices of the incoming gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        feats_d = [f.detach() for f in feats]
+        ctx.d = feats_d[0].shape[1]
+        return hop_concat(feats_d)
+
+    @staticmethod
+    def backward(ctx, gout):
+        d = ctx.d
+        return tuple(gout[:, h * d:(h + 1) * d] if nd else None for h, nd in enumerate(ctx.needs_input_grad))
+
+
+def hop_concat_grad(feats):
+    return _ConcatGrad.apply(*feats)
 
 
 class _WSum2D(torch.autograd.Function):

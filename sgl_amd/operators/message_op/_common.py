@@ -19,9 +19,10 @@ def back_home(t, home):
 
 
 def wants_grad(feats):
-    """do gradients have to flow through these hop matrices?  The forward-only HIP kernels of the non-learnable aggregators
-    cannot carry them: the callers then evaluate the reference's own differentiable torch expression instead (e.g. when
-    the outputs of a ProjectedConcat / MLP are fed into Concat or Mean; SGAP pre-propagation itself never needs it)."""
+    """do gradients have to flow through these hop matrices?  (e.g. when the outputs of a ProjectedConcat / MLP are fed into Concat
+    or Mean; SGAP pre-propagation itself never needs it.)  The parameter-free aggregators then run the same HIP kernels inside
+    autograd Functions whose backward is the broadcast / slice / selection the reference's torch expression has
+    (device.hop_reduce_grad / hop_concat_grad); only the NAFS op still evaluates its differentiable torch expression."""
     return torch.is_grad_enabled() and any(torch.is_tensor(f) and f.requires_grad for f in feats)
 
 
@@ -53,8 +54,15 @@ def torch_combine(kind, feats, divisor=None):
 REDUCE = {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "max": _lib.SGL_REDUCE_MAX, "min": _lib.SGL_REDUCE_MIN}
 
 
-def reduce_hops(kind, feat_list):
-    if wants_grad(feat_list):
-        return torch_combine(kind, list(feat_list))
+def reduce_hops(kind, feat_list, divisor=None):
     feats, home = device_hops(feat_list)
+    if wants_grad(feat_list):
+        return back_home(dev.hop_reduce_grad(REDUCE[kind], feats, divisor=divisor), home)
     return back_home(dev.hop_reduce(REDUCE[kind], feats), home)
+
+
+def concat_hops(feat_list):
+    feats, home = device_hops(feat_list)
+    if wants_grad(feat_list):
+        return back_home(dev.hop_concat_grad(feats), home)
+    return back_home(dev.hop_concat(feats), home)

@@ -7,9 +7,8 @@ no [H, N, d] stack is ever materialised) and concat is a strided copy kernel; re
 reference's (same left-to-right order, one true division for mean, NaN-propagating max/min)."""
 import torch
 
-from ... import device as dev
 from ..base_op import MessageOp
-from ._common import back_home, device_hops, reduce_hops, torch_combine, wants_grad
+from ._common import concat_hops, reduce_hops, wants_grad
 
 
 class LastMessageOp(MessageOp):
@@ -52,14 +51,11 @@ class ConcatMessageOp(MessageOp):
 
     def _combine(self, feat_list):
         hops = feat_list[self._start:self._end]
-        if wants_grad(hops):
-            return torch_combine("concat", list(hops))
-        if len(hops) > 1:
+        if len(hops) > 1 and not wants_grad(hops):
             view = self._slab_view(hops)
             if view is not None:
                 return view
-        feats, home = device_hops(hops)
-        return back_home(dev.hop_concat(feats), home)
+        return concat_hops(hops)
 
 
 def _reduction(kind, doc):
@@ -71,7 +67,7 @@ def _reduction(kind, doc):
         def _combine(self, feat_list):
             hops = feat_list[self._start:self._end]
             if wants_grad(hops):
-                return torch_combine(kind, list(hops), divisor=(self._end - self._start) if kind == "mean" else None)
+                return reduce_hops(kind, hops, divisor=(self._end - self._start) if kind == "mean" else None)
             if kind == "mean" and len(hops) != self._end - self._start:
                 # the reference divides by (end - start) whatever the slice held (mean_message_op.py:10)
                 total = reduce_hops("sum", hops)

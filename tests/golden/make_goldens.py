@@ -766,8 +766,28 @@ def gen_g12():
     def record(prefix, op, feats32, gout32, stored):
         op = op.double()
         fg = [f.detach().double().clone().requires_grad_(True) for f in feats32]
+        # condition magnitudes of the Linear gradients: weight.grad[k] = sum_rows dS x[:, k] and bias.grad = sum_rows dS are sums of
+        # cancelling terms; recorded next to the truth: the sums of the ABSOLUTE terms (over every call of the module)
+        cond = {}
+        hooks = []
+        for mname, m in op.named_modules():
+            if isinstance(m, torch.nn.Linear):
+                def fwd(mod, inp, outp, mname=mname):
+                    xin = inp[0].detach()
+
+                    def bwd(gr):
+                        cw = gr.abs().t() @ xin.abs()
+                        cb = gr.abs().sum(0)
+                        cond[mname + ".weight"] = cond.get(mname + ".weight", 0) + cw
+                        cond[mname + ".bias"] = cond.get(mname + ".bias", 0) + cb
+                    outp.register_hook(bwd)
+                hooks.append(m.register_forward_hook(fwd))
         y = op.aggregate(fg)
         (y * gout32.double()).sum().backward()
+        for h_ in hooks:
+            h_.remove()
+        for k, v in cond.items():
+            out[prefix + "|gradcond|" + k] = v.numpy().copy()
         out[prefix + "|out"] = y.detach().numpy().copy()
         for k, p_ in op.named_parameters():
             out[prefix + "|grad|" + k] = p_.grad.numpy().copy()
