@@ -207,7 +207,7 @@ def run(args, engine_cls=None, workloads=None, emit=print):
             "config": {"workload": workload_text(args.workload, K),
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
                        "parallelism": info.get("parallelism", "single GPU") if sharded else "single GPU",
-                       "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; rows > 2048 nnz split into pieces",
+                       "summation": "strict (no row splitting: bit-exact reference order)" if args.strict else "reference order per row; long rows split into pieces (> 2048 nnz at this size: the threshold follows the GLOBAL nnz, 32 ... 2048)",
                        "plan": info, "setup_s": round(setup_s, 2), "validated": None, "validation": None, "diagnostics": None},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_BYTES, "traffic": traffic,

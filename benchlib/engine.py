@@ -180,7 +180,8 @@ class GpuEngine:
 
     def block_piece_spmms(self, args, blk, pieces, weights=None):
         from sgl_amd.dist import block_piece_spmms
-        return block_piece_spmms(blk, pieces, weights, strict=args.strict)
+        from sgl_amd.dist.sharded_adj import global_nnz
+        return block_piece_spmms(blk, pieces, weights, strict=args.strict, total_nnz=global_nnz(blk))
 
     def block_halo(self, args, blk, bounds):
         """need-aware exchange of the row-sharded layout (sgl_amd/dist/halo.py): plan, propagator on compact tables and the

@@ -346,8 +346,10 @@ int sgl_nafs_prefix_f32(int n_hops, const float *const *h_x, const int64_t *h_ld
 /* Learnable gate in one pass (LearnableWeightedMessageOp 'gate', message_op/learnable_weighted_messahe_op.py:67-71 followed by
  * two_dim_weighted_add, operators/utils.py:105-116):  G[n,h] = sigmoid(<X_h[n], vec> + bias),  W[n,:] = softmax_h(G[n,:]),
  * out[n] = sum_h W[n,h] X_h[n].  Every hop element is read once.  d_vec: round_up(d, 4) floats, 16-byte aligned, zero beyond d.
- * bias = NaN means "the bias is on the device": it is read from d_vec[round_up(d, 4)] by the kernel (no host synchronisation,
- * the launch can be captured in a hipGraph and replayed while the parameter changes).
+ * sgl_hop_gate_f32: `bias` is the scalar it says (a NaN bias gives NaN scores, and nothing beyond d_vec's round_up(d, 4) floats is
+ * read).  sgl_hop_gate_padded_f32 ONLY: bias = NaN means "the bias is on the device": it is read from d_vec[round_up(d, 4)] by
+ * the kernel -- d_vec then holds round_up(d, 4) + 1 floats -- (no host synchronisation, the launch can be captured in a hipGraph
+ * and replayed while the parameter changes).
  * d_w_out / d_g_out (optional, [n, n_hops]) receive W and G (the backward needs both).  Register-resident rows: n_hops <= 16,
  * d <= 512, 16-byte aligned rows -- otherwise SGL_ERR_UNSUPPORTED (callers then use sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32). */
 int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias, float *d_out,
@@ -392,6 +394,12 @@ int sgl_hop_rowdot2_f32(int n_hops, const float *const *h_x, const int64_t *h_ld
 /* out[i, :] = X[idx[i], :]   (idx: int64 on device; negative indices are NOT wrapped) */
 int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                         float *d_out, int64_t ldo, int64_t d, void *stream);
+/* the same with the destination rows' own padding declared (as in the other *_padded entry points): columns [d, d + pad_cols) of every
+ * output row are written as ZEROS in whole 16-byte vectors, so that every line of a row is written whole; nothing beyond column d of
+ * the source is copied (the source may be a column view of a wider matrix whose tail is somebody's data).  Needs 16-byte aligned
+ * rows, pitches and d + pad_cols multiples of 4. */
+int sgl_gather_rows_padded_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx, float *d_out,
+                               int64_t ldo, int64_t d, int64_t pad_cols, void *stream);
 /* out[dst[i], :] = X[src[i], :] for i < n_idx   (src, dst: int64 on device, dst entries distinct and < n_out_rows; a bad index
  * traps the kernel).  The pack step of the need-aware exchange (sgl_exchange_rows): the (own row, send-buffer row) pairs sorted
  * by own row, so that a row several peers gather is read from HBM once. */

@@ -529,7 +529,8 @@ def parity_report(y, ref, tol=1e-5, scale=None, rowwise=True):
     relative to the RESULT is unbounded when the terms cancel (the reference itself is off by up to 1.3e0
     element-wise-relative against fp64 on cancelling entries).  When given, the row-wise
     criterion divides by max(|ref_row|_2, |scale_row|_2) instead of |ref_row|_2 alone.
-    rowwise=False drops the row criterion (used for gradients, whose rows are sums of cancelling terms)."""
+    rowwise=False drops the row criterion.  BOTH are honoured for one-column outputs only (see below): every wider comparison is
+    held to the unrelaxed three-way test."""
     y = np.asarray(y, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     if y.shape != ref.shape:
@@ -544,6 +545,12 @@ def parity_report(y, ref, tol=1e-5, scale=None, rowwise=True):
     g = float(diff.max() / mx) if mx > 0 else float(diff.max())
     y2, r2 = yf.reshape(len(yf), -1), rf.reshape(len(rf), -1)
     rn = np.sqrt((r2 * r2).sum(1))
+    # The two relaxations only ever apply to ONE-COLUMN outputs, where a "row" is a single element and the row criterion degenerates
+    # into the element-wise relative error that SURVEY 8(c) itself calls meaningless on cancelling entries.  The audit of the whole
+    # GPU suite (profiles/r05_tolerance_audit.md: 712 relaxed comparisons) found that exactly those -- 10, all of width 1 -- need
+    # it; every wider comparison passes the unrelaxed three-way test, which is therefore what it gets, whatever the caller passed.
+    if r2.shape[1] > 1 and os.environ.get("SGL_PARITY_RELAX_ALL") != "1":
+        scale, rowwise = None, True
     if scale is not None:
         s2 = np.asarray(scale, dtype=np.float64).reshape(len(rf), -1)
         rn = np.maximum(rn, np.sqrt((s2 * s2).sum(1)))
@@ -554,7 +561,7 @@ def parity_report(y, ref, tol=1e-5, scale=None, rowwise=True):
     ac = bool(np.allclose(yf, rf, rtol=tol, atol=tol * mx))
     ok = bool(same_nonfinite and g <= tol and (row <= tol or not rowwise) and ac)
     audit = os.environ.get("SGL_PARITY_AUDIT")
-    if audit and ok and (scale is not None or not rowwise):
+    if audit and ok and (scale is not None or not rowwise):       # (run with SGL_PARITY_RELAX_ALL=1 to audit every width again)
         # tolerance audit (profiles/r05_tolerance_audit.md): would this comparison also pass the UNRELAXED SURVEY 8(c) criterion --
         # row norm of the reference alone, row criterion on?  Every call that needs the relaxation is recorded with its test id.
         rn0 = np.sqrt((r2 * r2).sum(1))

@@ -111,6 +111,8 @@ PROTOTYPES = {
                                           c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "sgl_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
+    "sgl_gather_rows_padded_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                           c_void_p]),
     "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                      c_int64, c_void_p]),
     "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

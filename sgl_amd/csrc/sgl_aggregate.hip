@@ -1091,7 +1091,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
                                                           const int64_t n_rows, const int64_t *__restrict__ idx,
                                                           const int64_t *__restrict__ dst, const int64_t n_out,
                                                           const int64_t n_idx, float *__restrict__ out,
-                                                          const int64_t ldo, const int d) {
+                                                          const int64_t ldo, const int d, const int dz) {
+    // d = columns written per row, dz <= d = columns that are DATA: [dz, d) is the destination row's own padding and is written as
+    // zeros -- never copied from the source, whose columns beyond dz may be somebody's data (a column view of a wider matrix)
     using V = typename Vt<VEC>::type;
     constexpr int RPB = 256 / LPR;
     const int l = threadIdx.x % LPR;
@@ -1113,7 +1115,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     for (int c = l * VEC; c < d; c += LPR * VEC) {
         V v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const V *>(x + src[u] * ldx + c);
+        for (int u = 0; u < U; ++u) {
+            if (c < dz) {
+                v[u] = *reinterpret_cast<const V *>(x + src[u] * ldx + c);
+                if constexpr (VEC == 4) {
+                    if (c + 4 > dz) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e >= dz) v[u][e] = 0.f;
+                    }
+                }
+            } else {
+                if constexpr (VEC == 4) v[u] = (V){0.f, 0.f, 0.f, 0.f}; else v[u] = 0.f;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + (int64_t)u * RPB;
@@ -2068,10 +2083,13 @@ SGL_EXPORT int sgl_nafs_prefix_f32(int n_hops, const float *const *h_x, const in
 }
 
 static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, const int64_t *d_dst,
-                     int64_t n_out, int64_t n_idx, float *d_out, int64_t ldo, int64_t d, void *stream) {
-    SGL_REQUIRE(n_idx >= 0 && d >= 0 && d < INT32_MAX && n_rows >= 0 && n_out >= 0, "%s: bad sizes", who);
-    if (n_idx == 0 || d == 0) return SGL_OK;
-    SGL_REQUIRE(d_x && d_idx && d_out && ldx >= d && ldo >= d, "%s: bad arguments", who);
+                     int64_t n_out, int64_t n_idx, float *d_out, int64_t ldo, int64_t dz, int64_t pad, void *stream) {
+    SGL_REQUIRE(n_idx >= 0 && dz >= 0 && pad >= 0 && dz + pad < INT32_MAX && n_rows >= 0 && n_out >= 0, "%s: bad sizes", who);
+    if (n_idx == 0 || dz == 0) return SGL_OK;
+    const int64_t d = dz + pad;                     // columns written: the data, then the destination's own padding as zeros
+    SGL_REQUIRE(d_x && d_idx && d_out && ldx >= dz && ldo >= d, "%s: bad arguments", who);
+    SGL_REQUIRE(pad == 0 || (d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && aligned_to(d_x, 16) && aligned_to(d_out, 16)),
+                "%s: padded rows need 16-byte aligned rows, pitches that are multiples of 4 floats and d + pad_cols a multiple of 4", who);
     const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_x, 16) && aligned_to(d_out, 16);
     hipStream_t st = sgl::as_stream(stream);
     const int lpr = pick_lpr(d, vec4 ? 4 : 1);
@@ -2085,10 +2103,10 @@ static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_r
     do {                                                                                                                         \
         if (u == 4)                                                                                                              \
             hipLaunchKernelGGL((gather_rows_kernel<L, V, 4>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
-                               d_dst, n_out, n_idx, d_out, ldo, (int)d);                                                         \
+                               d_dst, n_out, n_idx, d_out, ldo, (int)d, (int)dz);                                                \
         else                                                                                                                     \
             hipLaunchKernelGGL((gather_rows_kernel<L, V, 1>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
-                               d_dst, n_out, n_idx, d_out, ldo, (int)d);                                                         \
+                               d_dst, n_out, n_idx, d_out, ldo, (int)d, (int)dz);                                                \
     } while (0)
     if (vec4) {
         switch (lpr) {
@@ -2113,7 +2131,14 @@ static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_r
 
 SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                                    float *d_out, int64_t ldo, int64_t d, void *stream) {
-    return copy_rows("sgl_gather_rows_f32", d_x, ldx, n_rows, d_idx, nullptr, n_idx, n_idx, d_out, ldo, d, stream);
+    return copy_rows("sgl_gather_rows_f32", d_x, ldx, n_rows, d_idx, nullptr, n_idx, n_idx, d_out, ldo, d, 0, stream);
+}
+
+// the same with the destination row's own padding declared: columns [d, d + pad_cols) of every output row are written as ZEROS (whole
+// 16-byte vectors, so that every line of the row is written whole); nothing beyond column d of the source is ever read into the result
+SGL_EXPORT int sgl_gather_rows_padded_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
+                                          float *d_out, int64_t ldo, int64_t d, int64_t pad_cols, void *stream) {
+    return copy_rows("sgl_gather_rows_padded_f32", d_x, ldx, n_rows, d_idx, nullptr, n_idx, n_idx, d_out, ldo, d, pad_cols, stream);
 }
 
 // out[dst[i], :] = X[src[i], :], i < n_idx (dst entries distinct; every index is range-checked in the kernel, which traps on a
@@ -2121,15 +2146,15 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
 SGL_EXPORT int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
                                     int64_t n_idx, float *d_out, int64_t ldo, int64_t n_out_rows, int64_t d, void *stream) {
     SGL_REQUIRE(n_idx == 0 || d_dst != nullptr, "sgl_scatter_rows_f32: NULL destination index");
-    return copy_rows("sgl_scatter_rows_f32", d_x, ldx, n_rows, d_src, d_dst, n_out_rows, n_idx, d_out, ldo, d, stream);
+    return copy_rows("sgl_scatter_rows_f32", d_x, ldx, n_rows, d_src, d_dst, n_out_rows, n_idx, d_out, ldo, d, 0, stream);
 }
 
 // ---- learnable gates -------------------------------------------------------------------------------------------------------
 // register-resident row kernels: H <= 16, d <= 512, 16-byte aligned rows.  Anything else -> SGL_ERR_UNSUPPORTED and the caller
 // takes the two-pass route (sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32).
-SGL_EXPORT int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
-                                       float *d_out, int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out,
-                                       int64_t ldg, int64_t n, int64_t d, void *stream) {
+static int hop_gate_impl(bool device_bias_sentinel, int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec,
+                         float bias, float *d_out, int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out,
+                         int64_t ldg, int64_t n, int64_t d, void *stream) {
     SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_gate_f32: bad sizes");
     {
         const int prc = check_pad("sgl_hop_gate_padded_f32", d, pad_cols, ldo);
@@ -2150,7 +2175,9 @@ SGL_EXPORT int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, cons
     if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_gate_f32: too many rows for one launch (shard the matrix)");
     // bias = NaN: the bias is the float that follows the padded vector on the device (d_vec[round_up(d, 4)]) -- a caller whose
     // bias is a device tensor (a torch parameter) needs neither a device-to-host synchronisation nor a new value per launch
-    const float *bias_ptr = (bias != bias) ? d_vec + (d + 3) / 4 * 4 : nullptr;
+    // Only the *_padded entry point reads it that way: a caller of the un-suffixed sgl_hop_gate_f32 whose d_vec holds exactly
+    // round_up(d, 4) floats and whose (diverged) bias is NaN gets NaN outputs, as the scalar semantics say, not a read past its vector.
+    const float *bias_ptr = (device_bias_sentinel && bias != bias) ? d_vec + (d + 3) / 4 * 4 : nullptr;
 #define SGL_GF(L, C, HM) \
     hipLaunchKernelGGL((gate_fused_kernel<L, C, HM>), dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_vec, bias, bias_ptr, d_out, ldo, d_w_out, ldw, d_g_out, ldg, n, (int)d, out_cols(d, pad_cols, (L) * (C) * 4))
 #define SGL_GF_H(L, C) SGL_HOPS_UP_TO_16(SGL_GF, L, C)
@@ -2165,10 +2192,17 @@ SGL_EXPORT int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, cons
     return SGL_OK;
 }
 
+SGL_EXPORT int sgl_hop_gate_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
+                                       float *d_out, int64_t ldo, int64_t pad_cols, float *d_w_out, int64_t ldw, float *d_g_out,
+                                       int64_t ldg, int64_t n, int64_t d, void *stream) {
+    return hop_gate_impl(true, n_hops, h_x, h_ldx, d_vec, bias, d_out, ldo, pad_cols, d_w_out, ldw, d_g_out, ldg, n, d, stream);
+}
+
+// scalar bias, always: a NaN bias means NaN scores (and d_vec needs only round_up(d, 4) floats)
 SGL_EXPORT int sgl_hop_gate_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_vec, float bias,
                                 float *d_out, int64_t ldo, float *d_w_out, int64_t ldw, float *d_g_out, int64_t ldg, int64_t n,
                                 int64_t d, void *stream) {
-    return sgl_hop_gate_padded_f32(n_hops, h_x, h_ldx, d_vec, bias, d_out, ldo, 0, d_w_out, ldw, d_g_out, ldg, n, d, stream);
+    return hop_gate_impl(false, n_hops, h_x, h_ldx, d_vec, bias, d_out, ldo, 0, d_w_out, ldw, d_g_out, ldg, n, d, stream);
 }
 
 // GAMLP-R's recursive gate in one pass (recursive_fused_kernel).  d_vec: [w_x | w_acc], each zero-padded to round_up(d, 4)

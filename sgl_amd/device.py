@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import check, current_stream_ptr, lib, ptr
 
 __all__ = [
-    "DeviceCSR", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
+    "DeviceCSR", "default_long_row_nnz", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency", "PreparedBlock",
     "placed_empty", "MEM_MODES",
     "hop_reduce", "hop_concat", "hop_reduce_grad", "hop_concat_grad", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
@@ -174,6 +174,15 @@ def _check_mat(t, name):
 
 def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def default_long_row_nnz(nnz):
+    """where sgl_csr_create cuts long rows when it is not told (csrc/sgl_spmm.hip: a function of the matrix's nnz only).  A row
+    block of a sharded matrix has fewer non-zeros than the whole and would fall into another bracket: the distributed paths pass
+    default_long_row_nnz(GLOBAL nnz) explicitly, so that the same rows are cut at the same places whatever the world size and the
+    default-order hops of a sharded run stay bit-identical to the single-GPU run."""
+    nnz = int(nnz)
+    return 32 if nnz < (1 << 18) else 128 if nnz < (1 << 20) else 512 if nnz < (1 << 22) else 2048
 
 
 class DeviceCSR:
@@ -1309,16 +1318,21 @@ def gather_rows(x, idx, out=None):
             raise ValueError("gather_rows: `out` must be [len(idx), d]")
     if idx.numel() == 0:
         return out
-    # copy whole 16-byte lanes for any d: the source row's padding is readable and the destination's padding is ours
+    # 16-byte lanes for any d: the vector that straddles column d is READ from the source (its pitch is a multiple of 4 floats, and the
+    # storage must hold it for the last row too) but only the d data columns reach the result; the columns of the destination's
+    # padding that get written are written as zeros (sgl_gather_rows_padded_f32) -- never the source's tail, which may be real
+    # data when x is a column view of a wider matrix.  Our own output: its whole pitch is padding we own, so every line of a row is
+    # written whole (a row of 147 floats on a 160-float pitch would otherwise end in a partly written line: a read-modify-write in
+    # HBM); a caller's output: up to the next multiple of 4, as before.
     dp = round_up(d, 4)
-    d_copy = dp if (d != dp and n_rows > 1 and idx.numel() > 1 and x.stride(0) % 4 == 0 and x.stride(0) >= dp
-                    and out.stride(0) >= dp and out.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0) else d
-    # our own output on the source's pitch: copy whole pitches, pad columns included -- every line of the output is then written
-    # whole (a row of 147 floats on a 160-float pitch would otherwise end in a partly written line: a read-modify-write in HBM)
-    if (own_out and n_rows > 1 and idx.numel() > 1 and out.stride(0) == x.stride(0) and d < x.stride(0) < d + 32
-            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
-        d_copy = x.stride(0)
+    ldx, ldo = x.stride(0) if n_rows > 1 else max(x.stride(0), d), out.stride(0) if idx.numel() > 1 else max(out.stride(0), d)
+    room = x.untyped_storage().nbytes() // 4 - x.storage_offset() >= (n_rows - 1) * ldx + dp
+    vec_ok = (n_rows > 1 and idx.numel() > 1 and ldx % 4 == 0 and ldx >= dp and ldo % 4 == 0 and ldo >= dp and room
+              and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+    pad = 0
+    if vec_ok:
+        pad = (ldo - d) if (own_out and ldo - d < 32) else (dp - d)
     with torch.cuda.device(x.device):
-        check(lib().sgl_gather_rows_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d_copy,
-                                        current_stream_ptr()), "sgl_gather_rows_f32")
+        check(lib().sgl_gather_rows_padded_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d, pad,
+                                               current_stream_ptr()), "sgl_gather_rows_padded_f32")
     return out

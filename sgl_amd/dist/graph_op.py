@@ -107,7 +107,9 @@ class ShardedGraphOp:
                 self._cache[2] = gather_piece_bounds([blk.lo, blk.hi], self.group)
             return self._propagate_halo(x, self._cache[2], rank, world)
         if self._cache[1] is None:                           # full-replica transports: SpMM handles on global column ids
-            fns, handles, mine = block_piece_spmms(self.a_hat_block, self.pieces, strict=self.strict_order, reorder=self.reorder)
+            from .sharded_adj import global_nnz
+            fns, handles, mine = block_piece_spmms(self.a_hat_block, self.pieces, strict=self.strict_order, reorder=self.reorder,
+                                                   total_nnz=global_nnz(self.a_hat_block, self.group))
             self._cache[1:] = [fns, gather_piece_bounds(mine, self.group), handles]
         _, fns, pb, handles = self._cache
         if x.shape[0] == blk.n_local and x.shape[0] != n:

@@ -398,10 +398,12 @@ def block_halo(block, bounds, group=None, strict=False, reorder=None):
     reorder: None / "community" / "auto" -- the rank's rows are STORED and PROCESSED in a locality order found on the block's own
     diagonal part (sgl_amd.reorder.local_rowmap; no communication) behind a row map: outputs, ids and every row's terms keep
     their order, the hops are bit-identical (plan.reorder_info says what was decided)."""
-    from ..device import DeviceCSR, permute_rows
+    from ..device import DeviceCSR, default_long_row_nnz, permute_rows
     from ..reorder import local_rowmap
+    from .sharded_adj import global_nnz
     plan = HaloPlan(block.lo, block.hi, block.n, block.col, bounds, group)
     plan.reorder_info = {"reorder": reorder}
+    total = global_nnz(block, group)          # long rows are cut where the WHOLE matrix would cut them (same bits at any world size)
     if block.n_local == 0:
         return plan, HaloPropagator(plan, lambda x, out: None), None
     rowptr, ccol, val = block.rowptr, plan.relabel(block.col), block.val
@@ -410,7 +412,7 @@ def block_halo(block, bounds, group=None, strict=False, reorder=None):
         rowmap, plan.reorder_info = local_rowmap(rowptr, ccol, 0, plan.n_own, reorder)   # own nodes = compact columns [0, n_own)
         if rowmap is not None:
             rowptr, ccol, val = permute_rows(rowptr, ccol, val, rowmap)
-    handle = DeviceCSR(rowptr, ccol, val, (block.n_local, plan.n_compact), strict=strict)
+    handle = DeviceCSR(rowptr, ccol, val, (block.n_local, plan.n_compact), strict=strict, long_row_nnz=default_long_row_nnz(total))
     if rowmap is not None:
         handle.set_rowmap(rowmap)
     return plan, HaloPropagator(plan, lambda x, out: handle.spmm(x, out=out)), handle

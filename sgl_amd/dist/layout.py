@@ -45,7 +45,7 @@ def device_piece_spmms(rowptr, col, val, n_cols, my_bounds, rowptr_host=None, st
     """One DeviceCSR (rectangular: rows of the piece x all columns) per local row piece, as `f(x_full, out)`
     callables for ShardedPropagator.  rowptr/col/val: the FULL normalised adjacency on this rank's device (only
     views of the local rows are kept alive); my_bounds: this rank's row of all_piece_bounds()."""
-    from ..device import DeviceCSR
+    from ..device import DeviceCSR, default_long_row_nnz
     if rowptr_host is None:
         rowptr_host = rowptr.cpu().numpy()
     fns, handles = [], []
@@ -53,7 +53,8 @@ def device_piece_spmms(rowptr, col, val, n_cols, my_bounds, rowptr_host=None, st
         r0, r1 = int(my_bounds[p]), int(my_bounds[p + 1])
         nb, ne = int(rowptr_host[r0]), int(rowptr_host[r1])
         rp_local = (rowptr[r0:r1 + 1] - rowptr[r0]).contiguous()
-        h = DeviceCSR(rp_local, col[nb:ne].contiguous(), val[nb:ne].contiguous(), (r1 - r0, n_cols), strict=strict)
+        h = DeviceCSR(rp_local, col[nb:ne].contiguous(), val[nb:ne].contiguous(), (r1 - r0, n_cols), strict=strict,
+                      long_row_nnz=default_long_row_nnz(int(rowptr_host[-1])))      # cut long rows where the WHOLE matrix would
         handles.append(h)
         fns.append(lambda x, out, h=h: h.spmm(x, out=out))
     return fns, handles

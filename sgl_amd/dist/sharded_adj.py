@@ -151,12 +151,24 @@ def local_piece_bounds(block, pieces, weights=None):
     return piece_bounds(rp_host, 0, block.n_local, pieces, weights) + block.lo, rp_host
 
 
-def block_piece_spmms(block, pieces, weights=None, strict=False, reorder=None):
+def global_nnz(block, group=None):
+    """non-zeros of the whole matrix = the sum of the ranks' blocks (one all-reduce of one integer; collective)"""
+    t = torch.tensor([block.nnz], dtype=torch.int64, device=block.device)
+    rank, world = _world(group)
+    if world > 1:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
+def block_piece_spmms(block, pieces, weights=None, strict=False, reorder=None, total_nnz=None):
     """One DeviceCSR (rows of the piece x all n columns) per local row piece, built from the rank's OWN rows only.
     Returns (callables f(x_full, out), handles, absolute piece boundaries [pieces+1]).
     reorder (None / "community" / "auto"): every piece's rows are stored and processed in a locality order found on the piece's
-    own diagonal part, behind a row map (sgl_amd.reorder.local_rowmap): bit-identical results."""
-    from ..device import DeviceCSR, permute_rows
+    own diagonal part, behind a row map (sgl_amd.reorder.local_rowmap): bit-identical results.
+    total_nnz: non-zeros of the WHOLE matrix (global_nnz(block)): long rows are then cut where the unsharded matrix would cut them."""
+    from ..device import DeviceCSR, default_long_row_nnz, permute_rows
     pb, rp_host = local_piece_bounds(block, pieces, weights)
     fns, handles = [], []
     for p in range(pieces):
@@ -169,7 +181,8 @@ def block_piece_spmms(block, pieces, weights=None, strict=False, reorder=None):
             rowmap, _ = local_rowmap(rp_local, cc, int(pb[p]), int(pb[p + 1]), reorder)
             if rowmap is not None:
                 rp_local, cc, vv = permute_rows(rp_local, cc.contiguous(), vv.contiguous(), rowmap)
-        h = DeviceCSR(rp_local, cc, vv, (r1 - r0, block.n), strict=strict)
+        h = DeviceCSR(rp_local, cc, vv, (r1 - r0, block.n), strict=strict,
+                      long_row_nnz=default_long_row_nnz(total_nnz) if total_nnz is not None else 0)
         if rowmap is not None:
             h.set_rowmap(rowmap)
         handles.append(h)

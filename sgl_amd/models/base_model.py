@@ -51,14 +51,15 @@ class BaseSGAPModel(nn.Module):
     # `_processed_feat_list` is part of the de-facto interface (the reference's distributed tasks and search code read it:
     # sgl/tasks/node_classification_dist.py:69, sgl/search/auto_search_dist.py:80).  When preprocess() folded the aggregation into
     # the SpMM epilogue no hop list was kept; it is then produced ON DEMAND, the first time somebody asks for it.
-    # An incidental read (an `is None` check, an attribute walk) must not trigger K SpMMs over matrices that were folded precisely
-    # because the K+1 hop matrices would not fit: the lazy path only runs when they take at most half of the free device memory;
-    # otherwise the attribute reads None and materialize_hops(force=True) is the explicit way to get the list.
+    # A read must not silently trigger K SpMMs over matrices that were folded precisely because the K+1 hop matrices would not fit:
+    # the lazy path only runs when they take at most half of the free device memory.  Otherwise the read RAISES, deterministically
+    # and with the way out in the message (materialize_hops(force=True)) -- never None: the reference-compatible readers would fail
+    # later with an opaque TypeError, and the same model would read as a list or as None depending on the allocator's state.
     @property
     def _processed_feat_list(self):
         hops = self.__dict__.get("_hop_list")
-        if hops is None and self.__dict__.get("_hop_source") is not None and self._hops_fit():
-            hops = self.materialize_hops()
+        if hops is None and self.__dict__.get("_hop_source") is not None:
+            hops = self.materialize_hops()          # raises RuntimeError when the hop matrices would not fit
         return hops
 
     def materialize_hops(self, force=False):
@@ -69,8 +70,10 @@ class BaseSGAPModel(nn.Module):
         src = self.__dict__.get("_hop_source")
         if hops is None and src is not None:
             if not force and not self._hops_fit():
-                raise RuntimeError("materialize_hops: the K+1 hop matrices of the folded pre-propagation would take more than half "
-                                   "of the free device memory; pass force=True to propagate them anyway")
+                raise RuntimeError("the K+1 hop matrices of the folded pre-propagation (_processed_feat_list) would take more than half "
+                                   "of the free device memory (or the device could not report it): call "
+                                   "model.materialize_hops(force=True) to propagate them anyway, or set sgl_amd.config.fuse_aggregate "
+                                   "= False before preprocess() to keep the hop list")
             hops = self._pre_graph_op.propagate(*src)
             self.__dict__["_hop_list"], self.__dict__["_hop_source"] = hops, None
         return hops
@@ -82,8 +85,10 @@ class BaseSGAPModel(nn.Module):
             need = (self._pre_graph_op._prop_steps + 1) * n * dev.row_pitch(d) * 4
             free, _ = torch.cuda.mem_get_info(torch.device(self._pre_graph_op._opt("device")))
             return need <= free // 2
-        except (RuntimeError, AssertionError, ValueError, TypeError, AttributeError):
-            return True                                   # nothing to ask (small CPU-side jobs): keep the round-3 behaviour
+        except (ValueError, TypeError, AttributeError):
+            return True                                   # no shape to ask about (nothing folded on a device): nothing to refuse
+        except (RuntimeError, AssertionError):
+            return False                                  # the device cannot say how much memory is free: refuse, explicitly
 
     # the inputs of a folded preprocess() (adjacency, features) are kept only to serve the lazy hop list: they are not part of the
     # model and do not travel with torch.save(model) / copy.deepcopy(model) (the reference's search code pickles whole models)
