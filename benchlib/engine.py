@@ -158,7 +158,7 @@ class GpuEngine:
         n = wl["n"]
         tab = torch.from_numpy(self.hashed_table(wl)).to(self.device)
         deg = torch.empty(n, dtype=torch.int64, device=self.device)
-        _lib.check(_lib.lib().sgl_synth_degrees(ctypes.c_uint64(args.seed), 0, n, _lib.ptr(tab), _lib.ptr(deg),
+        _lib.check_probe(_lib.probe_lib().sgl_synth_degrees(ctypes.c_uint64(args.seed), 0, n, _lib.ptr(tab), _lib.ptr(deg),
                                                 _lib.current_stream_ptr()), "sgl_synth_degrees")
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
         torch.cumsum(deg, 0, out=rowptr[1:])
@@ -212,7 +212,7 @@ class GpuEngine:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
             def go():
-                _lib.check(_lib.lib().sgl_probe_gather_f32(_lib.ptr(x), ld, _lib.ptr(idx), idx.numel(), rf, 16, _lib.ptr(sink),
+                _lib.check_probe(_lib.probe_lib().sgl_probe_gather_f32(_lib.ptr(x), ld, _lib.ptr(idx), idx.numel(), rf, 16, _lib.ptr(sink),
                                                            _lib.current_stream_ptr()), "sgl_probe_gather_f32")
             go()
             torch.cuda.synchronize()

@@ -115,15 +115,23 @@ PROTOTYPES = {
                                            c_void_p]),
     "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                      c_int64, c_void_p]),
+    "sgl_content_hash": (c_int, [c_void_p, c_int64, POINTER(c_uint64)]),
+}
+
+
+# libsgl_probe.so (include/sgl_probe.h): measurement and test support -- memory probes, placed allocations, synthetic workloads
+PROBE_LIB_PATH = os.environ.get("SGL_PROBE_LIB") or os.path.join(_HERE, "csrc", "libsgl_probe.so")
+PROBE_PROTOTYPES = {
+    "sgl_probe_last_error": (c_char_p, []),
     "sgl_synth_degrees": (c_int, [c_uint64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_fill": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_synth_features": (c_int, [c_uint64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
-    "sgl_content_hash": (c_int, [c_void_p, c_int64, POINTER(c_uint64)]),
     "sgl_mem_alloc": (c_int, [POINTER(c_void_p), c_int64, c_int, c_int64]),
     "sgl_mem_free": (c_int, [c_void_p]),
     "sgl_probe_stream_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sgl_probe_gather_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
 }
+_probe = None
 
 
 class SglHipError(RuntimeError):
@@ -145,6 +153,26 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def probe_lib():
+    """libsgl_probe.so: what benchmarks and tests need next to the product library (never the propagation path itself)"""
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise SglHipError(f"{PROBE_LIB_PATH} is missing: build it with `python -m sgl_amd.csrc.build` (needs hipcc)")
+        handle = ctypes.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in PROBE_PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _probe = handle
+    return _probe
+
+
+def check_probe(rc, what=""):
+    if rc != 0:
+        raise SglHipError(f"{what or 'libsgl_probe'} failed (code {rc}): {probe_lib().sgl_probe_last_error().decode('utf-8', 'replace')}")
 
 
 def last_error():

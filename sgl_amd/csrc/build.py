@@ -1,4 +1,4 @@
-"""Build libsgl_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+"""Build libsgl_hip.so (the C-ABI HIP library) and libsgl_probe.so (measurement / test support) in-tree with hipcc for gfx950.
 
     python -m sgl_amd.csrc.build [--force] [--verbose]
 
@@ -14,8 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libsgl_hip.so")
-SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_probe.hip", "sgl_synth.hip", "sgl_exchange.hip", "sgl_reorder.hip", "sgl_mem.hip"]
-HEADERS = ["sgl_common.h", os.path.join(ROOT, "include", "sgl_hip.h")]
+SOURCES = ["sgl_core.cpp", "sgl_spmm.hip", "sgl_aggregate.hip", "sgl_normalize.hip", "sgl_ingest.hip", "sgl_shims.hip", "sgl_exchange.hip", "sgl_reorder.hip"]
+# measurement / test support, a library of its own (include/sgl_probe.h): memory probes, placed allocations, synthetic workloads
+PROBE_LIB = os.path.join(HERE, "libsgl_probe.so")
+PROBE_SOURCES = ["sgl_probe_core.cpp", "sgl_probe.hip", "sgl_synth.hip", "sgl_mem.hip"]
+HEADERS = ["sgl_common.h", os.path.join(ROOT, "include", "sgl_hip.h"), os.path.join(ROOT, "include", "sgl_probe.h")]
 ARCH = "gfx950"
 FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
@@ -41,7 +44,7 @@ def stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    """both libraries: libsgl_hip.so (the product) and libsgl_probe.so (measurement / test support); returns the product's path"""
     hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -60,15 +63,19 @@ def build(force=False, verbose=False):
                 print(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    if force or stale(LIB, objs):
-        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    groups = ((LIB, SOURCES), (PROBE_LIB, PROBE_SOURCES))
+    every = [os.path.join(HERE, s_) for _, names in groups for s_ in names]
+    with ThreadPoolExecutor(max_workers=min(len(every), os.cpu_count() or 4)) as ex:
+        objs = dict(zip(every, ex.map(compile_one, every)))
+    for lib, names in groups:
+        mine = [objs[os.path.join(HERE, s_)] for s_ in names]
+        if force or stale(lib, mine):
+            cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + mine + ["-ldl", "-pthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

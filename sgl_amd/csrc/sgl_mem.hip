@@ -15,6 +15,8 @@
 
 #include "sgl_common.h"
 
+#include "../../include/sgl_probe.h"
+
 namespace {
 
 struct Block {

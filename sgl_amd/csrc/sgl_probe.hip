@@ -8,6 +8,8 @@
 
 #include "sgl_common.h"
 
+#include "../../include/sgl_probe.h"
+
 namespace {
 
 using F4 = float __attribute__((ext_vector_type(4)));

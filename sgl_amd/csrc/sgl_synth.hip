@@ -13,6 +13,8 @@
 //   x(row, k)      = ((h(seed, 3, row, k) >> 40) - 2^23) * 2^-23            in [-1, 1),   exact in fp32
 #include "sgl_common.h"
 
+#include "../../include/sgl_probe.h"
+
 namespace {
 
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

@@ -97,7 +97,7 @@ class _PlacedBlock:
         self.n = int(n_floats)
         p = c_void_p()
         with torch.cuda.device(self.device):
-            check(lib().sgl_mem_alloc(ctypes.byref(p), self.n * 4, MEM_MODES[mode], int(chunk_bytes)), f"sgl_mem_alloc({mode})")
+            _lib.check_probe(_lib.probe_lib().sgl_mem_alloc(ctypes.byref(p), self.n * 4, MEM_MODES[mode], int(chunk_bytes)), f"sgl_mem_alloc({mode})")
         self.ptr = p.value
         self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "<f4", "data": (self.ptr, False), "version": 2}
 
@@ -106,7 +106,7 @@ class _PlacedBlock:
         if p:
             try:
                 with torch.cuda.device(self.device):
-                    lib().sgl_mem_free(c_void_p(p))
+                    _lib.probe_lib().sgl_mem_free(c_void_p(p))
             except Exception:
                 pass
 

@@ -226,14 +226,14 @@ def hashed_block_torch(seed, row0, n_rows, n_cols, table, device="cuda"):
     deg = torch.empty(n_rows, dtype=torch.int64, device=device)
     st = _lib.current_stream_ptr()
     with torch.cuda.device(tab.device):
-        _lib.check(_lib.lib().sgl_synth_degrees(ctypes.c_uint64(seed), row0, n_rows, _lib.ptr(tab), _lib.ptr(deg), st), "sgl_synth_degrees")
+        _lib.check_probe(_lib.probe_lib().sgl_synth_degrees(ctypes.c_uint64(seed), row0, n_rows, _lib.ptr(tab), _lib.ptr(deg), st), "sgl_synth_degrees")
         rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
         torch.cumsum(deg, 0, out=rowptr[1:])
         del deg
         nnz = int(rowptr[-1])
         col = torch.empty(nnz, dtype=torch.int32, device=device)
         val = torch.empty(nnz, dtype=torch.float32, device=device)
-        _lib.check(_lib.lib().sgl_synth_fill(ctypes.c_uint64(seed), row0, n_rows, n_cols, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val),
+        _lib.check_probe(_lib.probe_lib().sgl_synth_fill(ctypes.c_uint64(seed), row0, n_rows, n_cols, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val),
                                              st), "sgl_synth_fill")
     return rowptr, col, val
 
@@ -248,6 +248,6 @@ def hashed_features_torch(seed, row0, n_rows, d, device="cuda", out=None):
         out = dev.alloc_rows(n_rows, d, device, zero_pad=False)
     parent = dev.padded_parent(out)
     with torch.cuda.device(parent.device):
-        _lib.check(_lib.lib().sgl_synth_features(ctypes.c_uint64(seed), row0, n_rows, d, parent.stride(0) if n_rows > 1 else parent.shape[1],
+        _lib.check_probe(_lib.probe_lib().sgl_synth_features(ctypes.c_uint64(seed), row0, n_rows, d, parent.stride(0) if n_rows > 1 else parent.shape[1],
                                                  _lib.ptr(parent), _lib.current_stream_ptr()), "sgl_synth_features")
     return out

@@ -15,8 +15,8 @@ from sgl_amd import _lib
 from sgl_amd.dist import balanced_bounds, piece_bounds
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "sgl_hip.h")).read()
+def header_functions(header="sgl_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+)?(?:int64_t|int|void|const char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
@@ -31,6 +31,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.PROTOTYPES) == names, (sorted(set(names) ^ set(_lib.PROTOTYPES)))
     assert _lib.lib().sgl_version() >= 100
     assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
+    # measurement / test support lives in its own library behind its own header: nothing of it in the product ABI
+    probe = header_functions("sgl_probe.h")
+    assert probe and not set(probe) & set(names) and all(n.startswith(("sgl_probe_", "sgl_synth_", "sgl_mem_")) for n in probe), probe
+    assert not [n for n in names if n.startswith(("sgl_probe_", "sgl_synth_", "sgl_mem_"))]
+    ph = ctypes.CDLL(_lib.PROBE_LIB_PATH)
+    for n in probe:
+        assert hasattr(ph, n), f"{n} declared in include/sgl_probe.h but not exported by libsgl_probe.so"
+    assert sorted(_lib.PROBE_PROTOTYPES) == probe
+    assert not any(hasattr(handle, n) for n in probe), "the product library still exports measurement symbols"
+    assert _lib.probe_lib().sgl_probe_last_error() == b""
 
 
 def test_device_count_never_aborts():

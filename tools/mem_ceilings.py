@@ -14,7 +14,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from sgl_amd._lib import check, current_stream_ptr, lib, ptr  # noqa: E402
+from sgl_amd import _lib  # noqa: E402
+from sgl_amd._lib import check, current_stream_ptr, lib, ptr  # noqa: E402,F401
 
 
 def time_ms(fn, reps=5, warm=2):
@@ -44,7 +45,7 @@ def main():
     n_fl = 2 * (1 << 30)   # 8 GiB
     big = torch.empty(n_fl, device=dev)
     big.normal_(generator=g)
-    ms = time_ms(lambda: check(lib().sgl_probe_stream_f32(ptr(big), n_fl, ptr(sink), current_stream_ptr())))
+    ms = time_ms(lambda: _lib.check_probe(_lib.probe_lib().sgl_probe_stream_f32(ptr(big), n_fl, ptr(sink), current_stream_ptr())))
     print(f"CEIL stream_read bytes={n_fl * 4 / 1e9:.1f}GB ms={ms:.3f} TBps={n_fl * 4 / (ms * 1e-3) / 1e12:.2f}", flush=True)
     del big
 
@@ -73,7 +74,7 @@ def main():
                                  (100, 100, "400B rows at pitch 100, 4 lines"), (96, 96, "384B rows at pitch 96, 3 lines")):
                 tv = table.view(-1)[: rows * ld].view(rows, ld)
                 for fl in (8, 16, 32):
-                    ms = time_ms(lambda: check(lib().sgl_probe_gather_f32(ptr(tv), ld, ptr(idx), n_idx, rf, fl, ptr(sink),
+                    ms = time_ms(lambda: _lib.check_probe(_lib.probe_lib().sgl_probe_gather_f32(ptr(tv), ld, ptr(idx), n_idx, rf, fl, ptr(sink),
                                                                           current_stream_ptr())))
                     lines = (rf * 4 + 127) // 128 if (ld * 4) % 128 == 0 else 4
                     print(f"CEIL gather table={tname} dist={dist} [{what}] in_flight={fl} ms={ms:.3f} "

@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sgl_amd import device as dev  # noqa: E402
-from sgl_amd._lib import check, current_stream_ptr, lib, ptr  # noqa: E402
+from sgl_amd import _lib  # noqa: E402
+from sgl_amd._lib import check, current_stream_ptr, lib, ptr  # noqa: E402,F401
 
 ROWS = {1: 2_449_029, 57: 111_059_956}     # the two benchmark tables; any other size (GB, may be fractional) is size * 2^30 / 512 rows
 CHUNK = {"vmm": 0, "vmm1g": 1 << 30, "vmm2m": 2 << 20, "vmm64m": 64 << 20}
@@ -65,7 +66,7 @@ def main():
                     flat[s:s + step].uniform_(-1, 1, generator=g)
 
                 def run():
-                    check(lib().sgl_probe_gather_f32(ptr(t), 128, ptr(idx), n_idx, 128, 16, ptr(sink), current_stream_ptr()))
+                    _lib.check_probe(_lib.probe_lib().sgl_probe_gather_f32(ptr(t), 128, ptr(idx), n_idx, 128, 16, ptr(sink), current_stream_ptr()))
                 run()
                 torch.cuda.synchronize()
                 if a.pmc:

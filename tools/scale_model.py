@@ -214,7 +214,7 @@ def papers(device):
     tab_h = synthetic.degree_table(wl["mean_deg"], wl["d_max"])
     tab = torch.from_numpy(tab_h).to(device)
     deg = torch.empty(n, dtype=torch.int64, device=device)
-    _lib.check(_lib.lib().sgl_synth_degrees(ctypes.c_uint64(seed), 0, n, _lib.ptr(tab), _lib.ptr(deg), _lib.current_stream_ptr()))
+    _lib.check_probe(_lib.probe_lib().sgl_synth_degrees(ctypes.c_uint64(seed), 0, n, _lib.ptr(tab), _lib.ptr(deg), _lib.current_stream_ptr()))
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
     torch.cumsum(deg, 0, out=rowptr[1:])
     del deg
