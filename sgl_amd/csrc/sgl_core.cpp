@@ -1,8 +1,10 @@
 // Host-only part of libsgl_hip.so: error text, tuning knobs, and the SpMM execution-plan builder.
 // No device code here, so these entry points work (and are unit-tested) on a machine without a GPU.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "sgl_common.h"
 
@@ -82,16 +84,10 @@ static void heavy_items_first(Plan &plan, const int64_t *rowptr, int32_t item_nn
     }
 }
 
-// Greedy partition of the rows into work items (see include/sgl_hip.h, "execution plan").
-int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz) {
-    if (n_rows < 0 || (n_rows > 0 && rowptr == nullptr)) return fail(SGL_ERR_INVALID, "build_plan: bad arguments");
-    if (n_rows >= (int64_t)INT32_MAX) return fail(SGL_ERR_UNSUPPORTED, "build_plan: n_rows >= 2^31 (shard the matrix)");
-    if (item_nnz <= 0) item_nnz = kDefaultItemNnz;
+// Greedy partition of the rows [r0, r1) into work items (see include/sgl_hip.h, "execution plan"); a fresh item starts at r0.
+static int build_segment(Plan &plan, const int64_t *rowptr, int64_t r0, int64_t r1, int32_t item_nnz, int32_t long_row_nnz) {
     const bool split = long_row_nnz > 0;
-    plan = Plan();
-    plan.n_rows = n_rows;
-    plan.long_first.push_back(0);
-    int64_t cur_begin = 0, cur_nnz = 0;
+    int64_t cur_begin = r0, cur_nnz = 0;
     auto close_item = [&](int64_t end) {
         if (end > cur_begin) {
             plan.items.push_back((int32_t)cur_begin);
@@ -102,7 +98,7 @@ int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_n
         cur_begin = end;
         cur_nnz = 0;
     };
-    for (int64_t r = 0; r < n_rows; ++r) {
+    for (int64_t r = r0; r < r1; ++r) {
         const int64_t b = rowptr[r], e = rowptr[r + 1];
         if (e < b) return fail(SGL_ERR_INVALID, "build_plan: row pointers decrease at row %lld", (long long)r);
         const int64_t deg = e - b;
@@ -129,7 +125,67 @@ int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_n
         cur_nnz += deg;
         if (cur_nnz >= item_nnz || (r + 1 - cur_begin) >= kMaxItemRows) close_item(r + 1);
     }
-    close_item(n_rows);
+    close_item(r1);
+    return SGL_OK;
+}
+
+// Rows are cut into segments of kPlanSegmentRows; every segment is partitioned on its own (a fresh item starts at its first row:
+// at most one short item per 2^20 rows) by a team of host threads and the pieces are laid end to end.  The plan depends on the
+// segment size only, never on the number of threads; matrices of up to two segments -- everything but the 10^7 ... 10^8-row
+// blocks of the papers100M-sized jobs, where the serial loop was hundreds of milliseconds of setup -- are one segment: the plan
+// they always had.  Items are whole rows and long rows are cut per row: results do not depend on any of this.
+constexpr int64_t kPlanSegmentRows = (int64_t)1 << 20;
+
+int build_plan(Plan &plan, const int64_t *rowptr, int64_t n_rows, int32_t item_nnz, int32_t long_row_nnz) {
+    if (n_rows < 0 || (n_rows > 0 && rowptr == nullptr)) return fail(SGL_ERR_INVALID, "build_plan: bad arguments");
+    if (n_rows >= (int64_t)INT32_MAX) return fail(SGL_ERR_UNSUPPORTED, "build_plan: n_rows >= 2^31 (shard the matrix)");
+    if (item_nnz <= 0) item_nnz = kDefaultItemNnz;
+    plan = Plan();
+    plan.n_rows = n_rows;
+    plan.long_first.push_back(0);
+    if (n_rows <= 2 * kPlanSegmentRows) {
+        const int rc = build_segment(plan, rowptr, 0, n_rows, item_nnz, long_row_nnz);
+        if (rc != SGL_OK) return rc;
+    } else {
+        const int64_t n_seg = (n_rows + kPlanSegmentRows - 1) / kPlanSegmentRows;
+        std::vector<Plan> segs((size_t)n_seg);
+        std::vector<int> rcs((size_t)n_seg, SGL_OK);
+        std::vector<std::string> errs((size_t)n_seg);
+        const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), (int64_t)16, n_seg}));
+        std::atomic<int64_t> next{0};
+        auto work = [&]() {
+            for (int64_t sidx = next.fetch_add(1); sidx < n_seg; sidx = next.fetch_add(1)) {
+                const int64_t r0 = sidx * kPlanSegmentRows, r1 = std::min(n_rows, r0 + kPlanSegmentRows);
+                rcs[(size_t)sidx] = build_segment(segs[(size_t)sidx], rowptr, r0, r1, item_nnz, long_row_nnz);
+                if (rcs[(size_t)sidx] != SGL_OK) errs[(size_t)sidx] = get_error();      // the error text is per thread
+            }
+        };
+        std::vector<std::thread> team;
+        for (int t = 1; t < n_thr; ++t) team.emplace_back(work);
+        work();
+        for (auto &t : team) t.join();
+        size_t n_items = 0, n_pieces = 0, n_long = 0;
+        for (int64_t sidx = 0; sidx < n_seg; ++sidx) {
+            if (rcs[(size_t)sidx] != SGL_OK) return fail(rcs[(size_t)sidx], "%s", errs[(size_t)sidx].c_str());
+            n_items += segs[(size_t)sidx].items.size();
+            n_pieces += segs[(size_t)sidx].pieces.size();
+            n_long += segs[(size_t)sidx].long_row.size();
+        }
+        plan.items.reserve(n_items);
+        plan.pieces.reserve(n_pieces);
+        plan.long_row.reserve(n_long);
+        plan.long_first.reserve(n_long + 1);
+        for (auto &sg : segs) {
+            const int32_t piece0 = (int32_t)plan.pieces.size();
+            plan.items.insert(plan.items.end(), sg.items.begin(), sg.items.end());
+            plan.pieces.insert(plan.pieces.end(), sg.pieces.begin(), sg.pieces.end());
+            plan.long_row.insert(plan.long_row.end(), sg.long_row.begin(), sg.long_row.end());
+            for (int32_t lf : sg.long_first) plan.long_first.push_back(piece0 + lf);   // (a segment's list has no leading 0)
+            plan.max_item_rows = std::max(plan.max_item_rows, sg.max_item_rows);
+            plan.max_item_nnz = std::max(plan.max_item_nnz, sg.max_item_nnz);
+            sg = Plan();
+        }
+    }
     if (tuning("spmm_heavy_first", 1) != 0) heavy_items_first(plan, rowptr, item_nnz);
     return SGL_OK;
 }

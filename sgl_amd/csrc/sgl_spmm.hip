@@ -501,6 +501,57 @@ __global__ __launch_bounds__(256) void rowmap_check_kernel(const int32_t *__rest
     if (atomicOr(&seen[m >> 5], bit) & bit) atomicOr(bad, 2);
 }
 
+// The row pointers come to the host for the plan (sgl::build_plan).  Small ones in one copy; the 10^7 ... 10^8 rows of a
+// papers100M-sized block (up to 888 MB) through two page-locked 32 MB staging buffers, the copy of chunk c + 1 in flight while
+// chunk c is unpacked -- a pageable destination of that size is staged by the runtime at a fraction of the link rate -- and the
+// host waits on the chunks' EVENTS, not on the stream: work the caller queued behind this call on other streams is not held up.
+static int fetch_rowptr(std::vector<int64_t> &h, const int64_t *d, hipStream_t st) {
+    const size_t n = h.size();
+    constexpr size_t kChunk = (size_t)4 << 20;                        // elements: 32 MB
+    if (n <= 2 * kChunk) {
+        SGL_HIP_CHECK(hipMemcpyAsync(h.data(), d, n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        SGL_HIP_CHECK(hipStreamSynchronize(st));
+        return SGL_OK;
+    }
+    int64_t *stage[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = SGL_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) {
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+    };
+    for (int i = 0; i < 2 && rc == SGL_OK; ++i) {
+        if (hipHostMalloc((void **)&stage[i], kChunk * sizeof(int64_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+            rc = sgl::fail(SGL_ERR_ALLOC, "sgl_csr_create: no page-locked staging buffer for the row pointers");
+    }
+    const size_t n_chunks = (n + kChunk - 1) / kChunk;
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t off = c * kChunk, len = std::min(kChunk, n - off);
+        hipError_t e = hipMemcpyAsync(stage[c & 1], d + off, len * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+        return e != hipSuccess ? e : hipEventRecord(ev[c & 1], st);
+    };
+    if (rc == SGL_OK && issue(0) != hipSuccess) rc = sgl::fail(SGL_ERR_INVALID, "sgl_csr_create: copying the row pointers failed");
+    for (size_t c = 0; c < n_chunks && rc == SGL_OK; ++c) {
+        if (hipEventSynchronize(ev[c & 1]) != hipSuccess) {
+            rc = sgl::fail(SGL_ERR_INVALID, "sgl_csr_create: copying the row pointers failed");
+            break;
+        }
+        const size_t off = c * kChunk, len = std::min(kChunk, n - off);
+        // chunk c sits in stage[c & 1]; chunk c + 1 goes to the other buffer, whose contents (chunk c - 1) were unpacked in the last round
+        if (c + 1 < n_chunks && issue(c + 1) != hipSuccess) {
+            rc = sgl::fail(SGL_ERR_INVALID, "sgl_csr_create: copying the row pointers failed");
+            break;
+        }
+        memcpy(h.data() + off, stage[c & 1], len * sizeof(int64_t));
+    }
+    if (rc != SGL_OK) (void)hipStreamSynchronize(st);                   // nothing may still write into the buffers we free
+    cleanup();
+    return rc;
+}
+
 SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
                               const int32_t *d_col, const float *d_val, uint32_t flags, int32_t item_nnz,
                               int32_t long_row_nnz, void *stream) {
@@ -512,8 +563,10 @@ SGL_EXPORT int sgl_csr_create(sgl_csr_t **out, int64_t n_rows, int64_t n_cols, i
     SGL_REQUIRE(nnz == 0 || (d_col && d_val), "sgl_csr_create: NULL col/val with nnz > 0");
     hipStream_t st = sgl::as_stream(stream);
     std::vector<int64_t> h_rowptr((size_t)n_rows + 1);
-    SGL_HIP_CHECK(hipMemcpyAsync(h_rowptr.data(), d_rowptr, h_rowptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SGL_HIP_CHECK(hipStreamSynchronize(st));
+    {
+        const int rc_fetch = fetch_rowptr(h_rowptr, d_rowptr, st);
+        if (rc_fetch != SGL_OK) return rc_fetch;
+    }
     SGL_REQUIRE(h_rowptr[0] == 0 && h_rowptr[n_rows] == nnz, "sgl_csr_create: rowptr[0]=%lld rowptr[n]=%lld but nnz=%lld",
                 (long long)h_rowptr[0], (long long)h_rowptr[n_rows], (long long)nnz);
     if (item_nnz <= 0) {

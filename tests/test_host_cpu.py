@@ -107,6 +107,40 @@ def test_plan_partitions_every_row_exactly_once(seed, item_nnz, long_nnz):
     assert counts[0] == len(items) and counts[5] == n
 
 
+def test_plan_of_a_large_matrix_is_built_in_segments():
+    """more than 2^21 rows: the rows are cut into 2^20-row segments partitioned by a team of host threads and laid end to end
+    (sgl_core.cpp: build_plan).  Same guarantees -- every row exactly once, long rows cut per row -- and the plan does not depend
+    on the number of threads: two builds are identical, and equal to the single-segment plans of the segments' row ranges"""
+    rng = np.random.default_rng(7)
+    n = (1 << 21) + (1 << 20) + 12345
+    deg = np.minimum(rng.lognormal(1.0, 1.2, n).astype(np.int64), 4000)
+    deg[[5, (1 << 20) - 1, 1 << 20, n - 1]] = 3000                       # long rows at the segment boundaries and at both ends
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    _lib.set_tuning("spmm_heavy_first", 0)
+    try:
+        items, pb, pl, pr, lr, lf, counts = build_plan(rowptr, 256, 2048)
+        again = build_plan(rowptr, 256, 2048)
+        parts = [build_plan(rowptr[a:b + 1] - 0, 256, 2048) for a, b in ((0, 1 << 20), (1 << 20, 1 << 21), (1 << 21, 3 << 20), (3 << 20, n))]
+    finally:
+        _lib.set_tuning("spmm_heavy_first", 1)
+    assert np.array_equal(items, again[0]) and np.array_equal(pb, again[1]) and np.array_equal(lf, again[5])
+    covered = np.zeros(n, np.int32)
+    np.add.at(covered, lr, 1)
+    diff = np.zeros(n + 1, np.int64)
+    np.add.at(diff, items[:, 0], 1)
+    np.add.at(diff, items[:, 1], -1)
+    covered += np.cumsum(diff[:-1]).astype(np.int32)
+    assert (covered == 1).all() and (items[:, 1] - items[:, 0] <= 63).all() and (np.diff(items[:, 0]) > 0).all()
+    assert np.array_equal(lr, np.flatnonzero(deg > 2048)) and lf[0] == 0 and lf[-1] == len(pb)
+    assert np.array_equal(pb[lf[:-1]], rowptr[lr]) and np.array_equal(pb[lf[1:] - 1] + pl[lf[1:] - 1], rowptr[lr + 1])
+    # no item spans a segment boundary, and each segment's share is the plan the segment has on its own
+    for k, (a, part) in enumerate(zip((0, 1 << 20, 1 << 21, 3 << 20), parts)):
+        b = min(a + (1 << 20), n)
+        mine = items[(items[:, 0] >= a) & (items[:, 0] < b)]
+        assert (mine[:, 1] <= b).all() and np.array_equal(mine - a, part[0])
+    assert counts[0] == len(items) and counts[1] == len(pb) and counts[5] == n
+
+
 def test_plan_issues_heavy_items_first_inside_every_xcd_range():
     """an item that ends in a heavy row holds several times item_nnz non-zeros; issued late it is the tail of the launch
     (profiles/r03_probe_small_launch.log).  Inside every XCD's range of the item list the items with >= 2 x item_nnz non-zeros
