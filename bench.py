@@ -94,6 +94,8 @@ def parse_args(argv=None):
                     help="skip the ogbn-papers100M-shaped secondary measurement of an S1_products run")
     ap.add_argument("--papers-budget", type=float, default=float(os.environ.get("SGL_BENCH_PAPERS_BUDGET", "150")),
                     help="watchdog (s) of the papers100M-shaped section: on overrun the JSON line is printed without it")
+    ap.add_argument("--papers-k", type=int, default=3,
+                    help="prop_steps of the papers100M-shaped section (3 by default; 10 = BASELINE config 5's hop count: raise --papers-budget)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dup2", action="store_true",
                     help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "
@@ -101,6 +103,15 @@ def parse_args(argv=None):
     ap.add_argument("--force-sharded", action="store_true",
                     help="debug: run the row-piece (multi-GPU) code path even with one GPU")
     return ap.parse_args(argv)
+
+
+def _step_stats(step_ms):
+    if not step_ms:
+        return None
+    a = np.sort(np.asarray(step_ms, dtype=np.float64))
+    return {"n": int(a.size), "median": float(np.median(a)), "min": float(a[0]), "max": float(a[-1]),
+            "p10": float(np.percentile(a, 10)), "p90": float(np.percentile(a, 90)),
+            "spread_pct": float((a[-1] - a[0]) / np.median(a) * 100.0)}
 
 
 def run(args, engine_cls=None, workloads=None, emit=print):
@@ -176,15 +187,19 @@ def run(args, engine_cls=None, workloads=None, emit=print):
         step()
     job.sync_all()
     t_start, t_stop, t_elapsed_ms = engine.timer()
+    marks = engine.step_marks(args.steps) if hasattr(engine, "step_marks") else None
     t0 = time.perf_counter()
     t_start()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        if marks is not None:
+            marks.mark(i)                     # one event record per step on the launch stream: the spread of the K steps (below)
     t_stop()
     job.sync_all()
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     gpu_ms = t_elapsed_ms()
     timed_done[0] = True
+    step_ms = marks.durations_ms(t_start.event if hasattr(t_start, "event") else None) if marks is not None else None
 
     # ---- the line exists from here on: whatever follows (self-validation, diagnostics, baselines, the papers100M-shaped section)
     # only ADDS to it, and the watchdog prints it as it stands instead of losing a measured value to a stuck collective ------------
@@ -202,7 +217,11 @@ def run(args, engine_cls=None, workloads=None, emit=print):
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "edge\u00b7featdim/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            # the K timed steps one by one (HIP events on rank 0's launch stream, inside the one timed region `value` comes from):
+            # median and spread -- what one run can say about its own noise; box-to-box spread is a separate matter
+            "ms_per_step_stats": _step_stats(step_ms),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text(args.workload, K),
                        "n_nodes": n, "nnz_a_hat": nnz, "feat_dim": d, "prop_steps": K,
@@ -218,7 +237,9 @@ def run(args, engine_cls=None, workloads=None, emit=print):
                          "kernel": "spmm_kernel", "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": hop_s * 1e3,
                          "kernel_ms_profile": prof.get("kernel_avg_ms_rocprof") if prof else None,
-                         "traffic_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None,
+                         # NOT an HBM utilisation: the counters sit on the fabric side of L2 and count every request, also those the
+                         # Infinity Cache serves -- requests per second against the HBM peak (can exceed what HBM itself delivers)
+                         "fabric_request_frac": (traffic / hop_s / HBM_PEAK_BYTES) if traffic else None,
                          # the bare-gather ceiling of THIS access pattern measured in this run (probe kernel: the same
                          # column ids, row width and pitch; no CSR stream, arithmetic or stores) and the kernel's gather rate
                          "gather_ceiling_Ggathers_per_s": None,

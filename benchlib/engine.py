@@ -31,9 +31,24 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
     fn = (lambda: oracle.reference_spmm(rp, c, v, xh, n_rows=rows)) if kind == "reference" else \
          (lambda: oracle.oracle_spmm(rp, c, v, xh, n_rows=rows))
     fn()  # warm-up
+    t0 = time.perf_counter()
+    fn()
+    t_probe = time.perf_counter() - t0
+    whole = ""
+    nnz_all = int(rowptr[-1])
+    if rows < n and not compacted and t_probe * nnz_all / max(nnz_s, 1) * 4 <= budget_s:
+        # ONE WHOLE HOP fits the budget (warm-up + three repetitions): the figure is then no extrapolation from the first rows --
+        # the static schedule hands every thread one contiguous block of rows, whose cost the first 16 % need not represent
+        rows, rp = n, rowptr.cpu().numpy()
+        nnz_s = nnz_all
+        c, v = col.cpu().numpy(), val.cpu().numpy()
+        fn = (lambda: oracle.reference_spmm(rp, c, v, xh, n_rows=rows)) if kind == "reference" else \
+             (lambda: oracle.oracle_spmm(rp, c, v, xh, n_rows=rows))
+        fn()  # warm-up of the full-size output
+        whole = "ONE WHOLE HOP: "
     times = []
     t_all = time.perf_counter()
-    for _ in range(5):
+    for _ in range(3 if whole else 5):
         t0 = time.perf_counter()
         fn()
         times.append(time.perf_counter() - t0)
@@ -62,7 +77,8 @@ def cpu_baseline(rowptr, col, val, x, d, budget_s=20.0):
         pass
     cores = min(threads, physical) if physical else threads
     out = {"value": nnz_s * d / t, "unit": "edge\u00b7featdim/s", "cores": cores, "threads": threads, "kind": kind,
-           "sample": f"first {rows} rows of A_hat ({nnz_s} nnz) x d={d}{compacted}, one hop, median of {len(times)} reps, "
+           "sample": f"{whole}{'all' if whole else 'first'} {rows} rows of A_hat ({nnz_s} nnz) x d={d}{compacted}, one hop, median of {len(times)} reps "
+                     f"({min(times) * 1e3:.0f} ... {max(times) * 1e3:.0f} ms), "
                      f"OpenMP static schedule, {threads} threads on {cores} physical cores of {cpu_model}",
            "ms_per_hop_sample": t * 1e3}
     # the build's OWN restatement of the same loop (oracle/spmm_ref.c: bit-equal to the reference binary, tests/test_oracle_golden.py)
@@ -340,7 +356,30 @@ class GpuEngine:
 
     def timer(self):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        return (lambda: ev0.record()), (lambda: ev1.record()), (lambda: ev0.elapsed_time(ev1))
+
+        def start():
+            ev0.record()
+        start.event = ev0
+        return start, (lambda: ev1.record()), (lambda: ev0.elapsed_time(ev1))
+
+    def step_marks(self, n_steps):
+        """one event per timed step on the stream the kernels are launched on (torch's current stream = what current_stream_ptr()
+        hands the library): the per-step durations inside the timed region"""
+        class Marks:
+            def __init__(self):
+                self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps)]
+
+            def mark(self, i):
+                self.ev[i].record()
+
+            def durations_ms(self, start_event):
+                out, prev = [], start_event
+                for e in self.ev:
+                    if prev is not None:
+                        out.append(prev.elapsed_time(e))
+                    prev = e
+                return out
+        return Marks()
 
 
 class OneGpuGlooEngine(GpuEngine):

@@ -22,7 +22,8 @@ def papers_section(args, engine, rank, world, exchange, wl=None):
     import torch.distributed as dist
     from sgl_amd import synthetic
     from sgl_amd.dist import ShardedPropagator, exchange_checksums, gather_piece_bounds
-    wl = dict(synthetic.WORKLOADS["S3_papers"], k=3) if wl is None else wl      # (tests pass a small hashed workload)
+    # k = 3 by default (bounded: the section shares the bench's time budget); --papers-k 10 = BASELINE config 5's own hop count
+    wl = dict(synthetic.WORKLOADS["S3_papers"], k=int(getattr(args, "papers_k", 3) or 3)) if wl is None else wl      # (tests pass a small hashed workload)
     n, d, K = wl["n"], wl["d"], wl["k"]
     t0 = time.perf_counter()
     bounds, nnz = engine.hashed_bounds(args, wl, world)
