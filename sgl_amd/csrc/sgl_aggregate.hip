@@ -1231,7 +1231,7 @@ constexpr int kConcatLds = 8192;                    // floats of LDS per block (
 constexpr int kConcatRowCap = 4096;                 // widest row this kernel takes (then 2 rows per block)
 __global__ __launch_bounds__(256) void hop_concat_rows_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
                                                               const int64_t ldo, const int64_t n, const int d, const int width_w,
-                                                              const int W, const int R) {
+                                                              const int W, const int R, const int pitch_v) {
     __shared__ float tile[kConcatLds];
     const int width = d * n_hops;
     const int64_t row0 = (int64_t)blockIdx.x * R;
@@ -1242,9 +1242,13 @@ __global__ __launch_bounds__(256) void hop_concat_rows_kernel(const Hops hx, con
         const int r = i / (W - width);
         tile[r * W + width + (i - r * (W - width))] = 0.f;
     }
-    // phase 1: (row r, hop h, vector j) -> consecutive threads take consecutive vectors of one source row (coalesced)
-    const int per_row = n_hops * nv;
-    const int total = rows * per_row;
+    // phase 1.  pitch_v > 0 (every hop has the same pitch of pitch_v vectors, at most a line more than the row): (hop h, row r,
+    // vector j of the PITCH) -- the block's rows are contiguous in every hop matrix, so consecutive threads read consecutive
+    // addresses ACROSS rows and every wavefront load is one contiguous kilobyte of one hop (the access pattern of the element-wise
+    // kernels); the pitch's pad vectors are skipped.  Otherwise (row r, hop h, vector j): consecutive threads take consecutive
+    // vectors of one source row.
+    const int per_row = pitch_v > 0 ? pitch_v : n_hops * nv;
+    const int total = pitch_v > 0 ? n_hops * rows * pitch_v : rows * per_row;
     constexpr int U = 4;                            // independent loads in flight per thread
     for (int base = t; base < total; base += 256 * U) {
         f4 x[U];
@@ -1256,13 +1260,23 @@ __global__ __launch_bounds__(256) void hop_concat_rows_kernel(const Hops hx, con
             o[u] = -1;
             k[u] = 0;
             if (i < total) {
-                const int r = i / per_row;
-                const int rem = i - r * per_row;
-                const int h = rem / nv;
-                const int j = rem - h * nv;
-                x[u] = *reinterpret_cast<const f4 *>(hx.p[h] + (row0 + r) * hx.ld[h] + 4 * j);   // inside the row's 4-float pitch
-                o[u] = r * W + h * d + 4 * j;
-                k[u] = d - 4 * j;                   // floats of this vector that belong to the row (>= 1)
+                int r, h, j;
+                if (pitch_v > 0) {
+                    h = i / (rows * pitch_v);
+                    const int rem = i - h * (rows * pitch_v);
+                    r = rem / pitch_v;
+                    j = rem - r * pitch_v;
+                } else {
+                    r = i / per_row;
+                    const int rem = i - r * per_row;
+                    h = rem / nv;
+                    j = rem - h * nv;
+                }
+                if (j < nv) {
+                    x[u] = *reinterpret_cast<const f4 *>(hx.p[h] + (row0 + r) * hx.ld[h] + 4 * j);   // inside the row's 4-float pitch
+                    o[u] = r * W + h * d + 4 * j;
+                    k[u] = d - 4 * j;               // floats of this vector that belong to the row (>= 1)
+                }
             }
         }
 #pragma unroll
@@ -1952,7 +1966,14 @@ SGL_EXPORT int sgl_hop_concat_padded_f32(int n_hops, const float *const *h_x, co
         const int R = kConcatLds / W;
         const int64_t blocks = (n + R - 1) / R;
         if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_hop_concat_f32: too many rows for one launch (shard the matrix)");
-        hipLaunchKernelGGL(hop_concat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d, width_w, W, R);
+        // every hop on the same pitch, at most one line longer than the row: read whole pitches, contiguously across the block's rows
+        int pitch_v = 0;
+        if (sgl::tuning("concat_flat_read", 1) != 0 && n > 1) {
+            pitch_v = (int)(hx.ld[0] / 4);
+            for (int h = 0; h < n_hops; ++h)
+                if (hx.ld[h] != hx.ld[0] || hx.ld[h] % 4 != 0 || hx.ld[h] >= d + 32) pitch_v = 0;
+        }
+        hipLaunchKernelGGL(hop_concat_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, hx, n_hops, d_out, ldo, n, (int)d, width_w, W, R, pitch_v);
     } else if (out16 && d >= 4 && vec4_rows(hx, n_hops) && d * n_hops >= 256 && sgl::tuning("concat_lds", 1) != 0 &&
                sgl::launch_fits((n + kConcatRows - 1) / kConcatRows * ((out_cols(d * n_hops, pad_cols, INT32_MAX) + kConcatTile - 1) / kConcatTile), 256)) {
         // any d, long rows: assembled in LDS, every source vector read once

@@ -60,6 +60,10 @@ def main():
         w1 = torch.rand(H, device=device)
         rep("wsum1d", timeit(lambda: dev.hop_reduce(_lib.SGL_REDUCE_WSUM, feats, w1)), (H + 1) * nb)
         rep("concat", timeit(lambda: dev.hop_concat(feats)), 2 * H * nb)
+        if d % 4:
+            _lib.set_tuning("concat_flat_read", 0)
+            rep("concat (row-by-row reads)", timeit(lambda: dev.hop_concat(feats)), 2 * H * nb)
+            _lib.set_tuning("concat_flat_read", 1)
         w2 = torch.softmax(torch.randn(n, H, device=device), 1)
         rep("wsum2d fwd", timeit(lambda: dev.hop_wsum2d(feats, w2)), (H + 1) * nb + n * H * 4)
         w2g = w2.clone().requires_grad_(True)
@@ -86,6 +90,14 @@ def main():
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
+        # what a launch of THIS size can reach at all: the same bytes as one contiguous copy, and a sorted (nearly sequential) gather
+        cont = feats[0][:200_000]
+        dst = dev.alloc_rows(200_000, d, device)
+        rep("  ceiling: contiguous copy 200k", timeit(lambda: dev.padded_parent(dst).copy_(dev.padded_parent(cont))), 2 * 200_000 * d * 4)
+        idx_sorted = torch.sort(idx).values
+        rep("  gather_rows 200k (sorted ids)", timeit(lambda: dev.gather_rows(feats[0], idx_sorted)), 2 * 200_000 * d * 4)
+        idx2m = torch.randint(0, n, (2_000_000,), device=device)
+        rep("gather_rows 2M", timeit(lambda: dev.gather_rows(feats[0], idx2m)), 2 * 2_000_000 * d * 4)
         # torch reference points for the same math (not part of the product): stack+sum, index_select
         rep("[torch] sum of hops", timeit(lambda: sum(feats)), (H + 1) * nb)
         rep("[torch] x[idx]", timeit(lambda: feats[0][idx]), 2 * 200_000 * d * 4)
