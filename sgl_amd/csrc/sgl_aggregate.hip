@@ -2113,21 +2113,46 @@ static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_r
                 "%s: padded rows need 16-byte aligned rows, pitches that are multiples of 4 floats and d + pad_cols a multiple of 4", who);
     const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(d_x, 16) && aligned_to(d_out, 16);
     hipStream_t st = sgl::as_stream(stream);
-    const int lpr = pick_lpr(d, vec4 ? 4 : 1);
-    // U rows per thread once there are enough rows to fill the chip several times over; small batches keep one row per thread
+    // Lanes per row: the group size that leaves the fewest lane slots idle (a row of 40 vectors -- d = 147 on its 160-float pitch --
+    // on 64 lanes idles 24 of them in every instruction; on 8 lanes x 5 iterations none, and a wavefront then has 8 rows = 8
+    // independent sets of lines in flight); ties go to the wider group (fewer iterations per row).
+    int lpr = 64;
+    {
+        const int64_t nv = (d + (vec4 ? 3 : 0)) / (vec4 ? 4 : 1);
+        int64_t best = -1;
+        for (int cand : {64, 32, 16, 8}) {
+            const int64_t waste = (nv + cand - 1) / cand * cand - nv;
+            if (best < 0 || waste < best) {
+                best = waste;
+                lpr = cand;
+            }
+        }
+        if (sgl::tuning("gather_lpr", 0) > 0) lpr = (int)sgl::tuning("gather_lpr", 0);
+    }
+    // Rows per thread: a copy is three dependent memory round trips (index, row, store); a launch that needs several ROUNDS of
+    // resident workgroups pays them once per round, which is what a small batch is made of (200 000 rows: 46 us against 26 us
+    // for a contiguous copy of the same bytes, profiles/r05_aggregators.log).  U rows per thread -- all index loads, then all row
+    // loads, then all stores -- so that the grid is about one or two rounds of the chip (<= 4 096 workgroups), up to 8 (70 VGPRs, 7 waves per SIMD).
     const int rpb = 256 / lpr;
-    const int u = n_idx >= (int64_t)rpb * 4 * 256 * 8 ? 4 : 1;
+    int u = 1;
+    while (u < 8 && (n_idx + (int64_t)rpb * u - 1) / ((int64_t)rpb * u) > 4096) u *= 2;   // (16 rows: 135 VGPRs, 3 waves per SIMD)
+    if (sgl::tuning("gather_rows_per_thread", 0) > 0) u = (int)sgl::tuning("gather_rows_per_thread", 0);
+    if (u != 1 && u != 2 && u != 4 && u != 8 && u != 16) u = 4;
     const int64_t blocks = (n_idx + (int64_t)rpb * u - 1) / ((int64_t)rpb * u);
     if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: too many indices for one launch", who);
     SGL_REQUIRE(blocks < INT32_MAX, "%s: too many rows", who);
+#define SGL_GRU(L, V, UU)                                                                                                         \
+    hipLaunchKernelGGL((gather_rows_kernel<L, V, UU>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, d_dst, n_out, \
+                       n_idx, d_out, ldo, (int)d, (int)dz)
 #define SGL_GR(L, V)                                                                                                             \
     do {                                                                                                                         \
-        if (u == 4)                                                                                                              \
-            hipLaunchKernelGGL((gather_rows_kernel<L, V, 4>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
-                               d_dst, n_out, n_idx, d_out, ldo, (int)d, (int)dz);                                                \
-        else                                                                                                                     \
-            hipLaunchKernelGGL((gather_rows_kernel<L, V, 1>), dim3((unsigned)blocks), dim3(256), 0, st, d_x, ldx, n_rows, d_idx, \
-                               d_dst, n_out, n_idx, d_out, ldo, (int)d, (int)dz);                                                \
+        switch (u) {                                                                                                             \
+            case 16: SGL_GRU(L, V, 16); break;                                                                                   \
+            case 8: SGL_GRU(L, V, 8); break;                                                                                     \
+            case 4: SGL_GRU(L, V, 4); break;                                                                                     \
+            case 2: SGL_GRU(L, V, 2); break;                                                                                     \
+            default: SGL_GRU(L, V, 1); break;                                                                                    \
+        }                                                                                                                        \
     } while (0)
     if (vec4) {
         switch (lpr) {
@@ -2145,6 +2170,7 @@ static int copy_rows(const char *who, const float *d_x, int64_t ldx, int64_t n_r
         }
     }
 #undef SGL_GR
+#undef SGL_GRU
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sgl::fail((int)e, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
     return SGL_OK;

@@ -53,7 +53,7 @@ def main():
         nb = n * d * 4
 
         def rep(name, ms, bytes_):
-            print(f"AGG d={d} H={H} {name:28s} ms={ms:8.3f} GB/s={bytes_ / (ms * 1e-3) / 1e9:8.1f} frac_of_8TB/s={bytes_ / (ms * 1e-3) / 8e12:.3f}", flush=True)
+            print(f"AGG d={d} H={H} {name:44s} ms={ms:8.3f} GB/s={bytes_ / (ms * 1e-3) / 1e9:8.1f} frac_of_8TB/s={bytes_ / (ms * 1e-3) / 8e12:.3f}", flush=True)
 
         for name, op in (("sum", _lib.SGL_REDUCE_SUM), ("mean", _lib.SGL_REDUCE_MEAN), ("max", _lib.SGL_REDUCE_MAX)):
             rep(name, timeit(lambda: dev.hop_reduce(op, feats)), (H + 1) * nb)
@@ -94,6 +94,12 @@ def main():
         cont = feats[0][:200_000]
         dst = dev.alloc_rows(200_000, d, device)
         rep("  ceiling: contiguous copy 200k", timeit(lambda: dev.padded_parent(dst).copy_(dev.padded_parent(cont))), 2 * 200_000 * d * 4)
+        for lpr_, u_ in ((0, 1), (0, 4), (0, 16), (64, 0), (32, 0), (16, 0), (8, 0)):      # the knobs behind the default choice
+            _lib.set_tuning("gather_lpr", lpr_)
+            _lib.set_tuning("gather_rows_per_thread", u_)
+            rep(f"  gather_rows 200k lpr={lpr_ or 'auto'} rows/thread={u_ or 'auto'}", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
+        _lib.set_tuning("gather_lpr", 0)
+        _lib.set_tuning("gather_rows_per_thread", 0)
         idx_sorted = torch.sort(idx).values
         rep("  gather_rows 200k (sorted ids)", timeit(lambda: dev.gather_rows(feats[0], idx_sorted)), 2 * 200_000 * d * 4)
         idx2m = torch.randint(0, n, (2_000_000,), device=device)
