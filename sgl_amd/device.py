@@ -1311,7 +1311,11 @@ def gather_rows(x, idx, out=None):
     idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
     own_out = out is None
     if out is None:
-        out = alloc_rows(idx.numel(), d, x.device)
+        # (the pad columns of our own output are written by the kernel below whenever the vector path applies: no separate zero fill)
+        fast = (n_rows > 1 and idx.numel() > 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and 0 < row_pitch(d) - d < 32
+                and x.stride(0) >= round_up(d, 4)
+                and x.untyped_storage().nbytes() // 4 - x.storage_offset() >= (n_rows - 1) * x.stride(0) + round_up(d, 4))
+        out = alloc_rows(idx.numel(), d, x.device, zero_pad=not fast)
     else:
         _check_mat(out, "out")
         if out.shape != (idx.numel(), d):

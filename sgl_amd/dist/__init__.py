@@ -30,9 +30,11 @@ from .propagator import ShardedPropagator
 from .sharded_adj import (RowBlock, allgather_blocks, allgather_rows, balanced_bounds_device, block_piece_spmms, canonicalize_block,
                           exchange_checksums, gather_piece_bounds, local_piece_bounds, scatter_row_blocks)
 from .halo import HaloPlan, HaloPropagator, halo_checksums
+from .redistribute import exchange_var, fetch_rows, redistribute_rows, sharded_community_order
 from .graph_op import ShardedGraphOp
 
 __all__ = ["balanced_bounds", "piece_bounds", "all_piece_bounds", "tapered_weights", "device_piece_spmms", "column_chunks",
            "column_slices", "GridLayout", "ShardedPropagator", "ShardedGraphOp", "RowBlock", "scatter_row_blocks",
            "block_piece_spmms", "gather_piece_bounds", "local_piece_bounds", "allgather_blocks", "allgather_rows",
-           "balanced_bounds_device", "exchange_checksums", "canonicalize_block", "HaloPlan", "HaloPropagator", "halo_checksums"]
+           "balanced_bounds_device", "exchange_checksums", "canonicalize_block", "HaloPlan", "HaloPropagator", "halo_checksums",
+           "exchange_var", "fetch_rows", "redistribute_rows", "sharded_community_order"]

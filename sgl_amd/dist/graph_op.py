@@ -243,26 +243,43 @@ class ShardedGraphOp:
         if self._cache is None or self._cache[0] != key or not self._cache_ident.matches(adj):
             ident = AdjIdentity(adj)
             if isinstance(adj, RowBlock):
-                # storage already row-sharded: normalise the block where it lies, then assemble the normalised matrix on every rank
-                # (27 GB of CSR at papers100M size: affordable once, for the plan) to find and apply the relabelling
-                from .sharded_adj import allgather_blocks
+                # storage already row-sharded: normalise the block where it lies; the relabelling is found and applied on the ranks' own
+                # rows (sgl_amd/dist/redistribute.py): labels by distributed label propagation (what is replicated is one integer per
+                # node), then every row moves to the rank that owns its new id.  No rank ever holds the whole matrix.
+                from ..reorder import AUTO_MIN_GAIN, AUTO_MIN_LOCALITY
+                from .redistribute import _gather_ints, redistribute_rows, sharded_community_order, sharded_edge_locality
                 rp_b, c_b, v_b = self._normalize_block(adj)
-                rowptr, col, val = allgather_blocks(RowBlock(adj.lo, adj.hi, n, rp_b, c_b, v_b), self.group)
-                self._block_bounds = None
+                nblk = RowBlock(adj.lo, adj.hi, n, rp_b, c_b, v_b)
+                old = _gather_ints([adj.lo, adj.hi], self.group)
+                old_bounds = [int(v) for v in old[:, 0]] + [int(old[-1, 1])]
+                order, text = sharded_community_order(nblk, old_bounds, self.group)
+                info = {"partition": self.partition, "communities": text, "applied": True, "found_on": "row blocks (no rank holds the matrix)"}
+                if self.partition == "auto":
+                    before, after = sharded_edge_locality(nblk, None, self.group), sharded_edge_locality(nblk, order, self.group)
+                    use = after >= AUTO_MIN_LOCALITY and after >= before + AUTO_MIN_GAIN
+                    info.update({"edge_locality_before": round(before, 4), "edge_locality_after": round(after, 4), "applied": bool(use)})
+                    if not use:
+                        order = None
+                if order is None:
+                    order = torch.arange(n, dtype=torch.int64, device=nblk.device)
+                blk, bounds = redistribute_rows(nblk, order, self.group)
+                perm = torch.argsort(order)                                 # perm[k] = original id of the node relabelled k
+                self._old_bounds = old_bounds
+                del nblk
             else:
                 dadj = adj if isinstance(adj, DeviceAdjacency) else DeviceAdjacency.from_scipy(adj, device=device)
                 rowptr, col, val = dev.normalize_adj(dadj.rowptr, dadj.col, dadj.val, n, self.r, self.alpha)
-            order, info = plan_order(rowptr, col, n, self.partition)       # identical on every rank: same kernels, same input
-            if order is not None:
-                rowptr, col, val = permute_csr(rowptr, col, val, order)
-                perm = torch.argsort(order)                                 # perm[k] = original id of the node relabelled k
-            else:
-                perm = torch.arange(n, dtype=torch.int64, device=rowptr.device)
-            bounds = balanced_bounds(rowptr.cpu().numpy(), world)
-            lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-            a0, a1 = int(rowptr[lo]), int(rowptr[hi])
-            blk = RowBlock(lo, hi, n, (rowptr[lo:hi + 1] - rowptr[lo]).contiguous(), col[a0:a1].contiguous(), val[a0:a1].contiguous())
-            del rowptr, col, val
+                order, info = plan_order(rowptr, col, n, self.partition)   # identical on every rank: same kernels, same input
+                if order is not None:
+                    rowptr, col, val = permute_csr(rowptr, col, val, order)
+                    perm = torch.argsort(order)                             # perm[k] = original id of the node relabelled k
+                else:
+                    perm = torch.arange(n, dtype=torch.int64, device=rowptr.device)
+                bounds = balanced_bounds(rowptr.cpu().numpy(), world)
+                lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+                a0, a1 = int(rowptr[lo]), int(rowptr[hi])
+                blk = RowBlock(lo, hi, n, (rowptr[lo:hi + 1] - rowptr[lo]).contiguous(), col[a0:a1].contiguous(), val[a0:a1].contiguous())
+                del rowptr, col, val
             plan, prop, handle = block_halo(blk, [int(b) for b in bounds], group=self.group, strict=False, reorder=self.reorder)
             self._cache = (key, plan, prop, handle, perm, info)
             self._cache_ident = ident
@@ -275,13 +292,16 @@ class ShardedGraphOp:
         x = feature if torch.is_tensor(feature) else torch.from_numpy(np.ascontiguousarray(feature, dtype=np.float32))
         x = x.to(device=device, dtype=torch.float32)
         if isinstance(adj, RowBlock) and x.shape[0] == adj.n_local and x.shape[0] != n:
-            # this rank's feature rows only (old ids): the rows a relabelled block needs are scattered over all ranks
-            sizes = [None] * world
-            if world > 1:
-                dist.all_gather_object(sizes, (adj.lo, adj.hi), group=self.group)
-            else:
-                sizes = [(adj.lo, adj.hi)]
-            x = allgather_rows(x.contiguous(), [s_[0] for s_ in sizes] + [sizes[-1][1]], n, group=self.group)
+            # this rank's feature rows only (old ids): the rows the relabelled block's compact table holds are scattered over all
+            # ranks -- each is asked of its owner, exactly those rows travel (never the 57 GB matrix of a papers100M-sized job)
+            from .redistribute import fetch_rows
+            self.c0, self.c1 = 0, x.shape[1]
+            table = fetch_rows(x.contiguous(), self._old_bounds, perm[plan.global_ids], self.group)
+            chunks = column_chunks(x.shape[1], self.col_chunks if world > 1 else 1)
+            if len(chunks) == 1:
+                return prop.propagate(table, self.prop_steps)
+            hops = prop.propagate_chunked([table[:, a:b].contiguous() for a, b in chunks], self.prop_steps)
+            return [torch.cat(h, dim=1) for h in hops]
         if x.shape[0] != n:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
         self.c0, self.c1 = 0, x.shape[1]

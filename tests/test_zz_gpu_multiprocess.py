@@ -299,8 +299,21 @@ def _partition_worker(rank, world, port, out_dir):
                       ((raw.indptr, np.int64), (raw.indices, np.int32), (raw.data, np.float32))) if rank == 0 else None
         blk = scatter_row_blocks(whole, bnd, n, dv)
         opb = ShardedGraphOp(3, r=0.5, partition="community", col_chunks=2)
-        hb = opb.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+        # ... and WITHOUT any rank assembling the matrix or the feature matrix: the relabelling is found by label propagation over the
+        # row blocks, the rows move to their new owners, the feature rows are fetched from theirs (sgl_amd/dist/redistribute.py)
+        import sgl_amd.dist.graph_op as gop_
+        import sgl_amd.dist.sharded_adj as sadj_
+
+        def _forbidden(*a_, **k_):
+            raise AssertionError("a rank assembled the whole matrix / feature matrix")
+        saved = (gop_.allgather_rows, sadj_.allgather_blocks)
+        gop_.allgather_rows = sadj_.allgather_blocks = _forbidden
+        try:
+            hb = opb.propagate(blk, torch.from_numpy(x[blk.lo:blk.hi].copy()).to(dv))
+        finally:
+            gop_.allgather_rows, sadj_.allgather_blocks = saved
         ok = ok and torch.equal(opb.node_ids, ids) and all(torch.equal(a_, b_) for a_, b_ in zip(hb, hops))
+        ok = ok and opb.partition_info["found_on"].startswith("row blocks") and opb.a_hat_block.nnz < raw.nnz + n
         flags.append(bool(ok))
         # "auto" keeps the ids when there is nothing to gain (the same graph in its natural order)
         adj0c = adj0.tocsr()

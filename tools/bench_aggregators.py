@@ -90,6 +90,13 @@ def main():
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
+        # the kernel alone: ten launches queued back to back into a preallocated output (the host's ~20 us per call -- allocation,
+        # index checks, ctypes -- hide behind the GPU as they do in a training loop; a single timed call includes them)
+        gout_ = dev.alloc_rows(200_000, d, device)
+        rep("  gather_rows 200k (10 queued, per launch)", timeit(lambda: [dev.gather_rows(feats[0], idx, out=gout_) for _ in range(10)]) / 10,
+            2 * 200_000 * d * 4)
+        rep("  contiguous copy 200k (10 queued, per launch)",
+            timeit(lambda: [dev.padded_parent(gout_).copy_(dev.padded_parent(feats[0][:200_000])) for _ in range(10)]) / 10, 2 * 200_000 * d * 4)
         # what a launch of THIS size can reach at all: the same bytes as one contiguous copy, and a sorted (nearly sequential) gather
         cont = feats[0][:200_000]
         dst = dev.alloc_rows(200_000, d, device)
