@@ -65,6 +65,13 @@ def main():
     torch.cuda.synchronize()
     t_nafs = time.perf_counter() - t0
     t_again = t_prop + t_nafs
+    # the adaptive-k-hop SWEEP of the NAFS tasks (every hop count 0 .. k evaluated, tasks/node_clustering.py:176-178) from the SAME
+    # propagation: every prefix of the hop list in one pass over this rank's shards, no communication
+    t0 = time.perf_counter()
+    sweep = op.over_smooth_sweep(hops, a.hops + 1)
+    torch.cuda.synchronize()
+    t_sweep = time.perf_counter() - t0
+    assert sorted(sweep) == list(range(a.hops + 1)) and torch.allclose(sweep[a.hops], smoothed, rtol=1e-5, atol=1e-6)
 
     nnz = torch.tensor([op.a_hat_block.nnz], dtype=torch.int64, device=device)
     check = smoothed.double().sum().reshape(1)
@@ -79,6 +86,8 @@ def main():
         print(f"  load own rows {t_load:.2f} s, first propagate (normalise block + plan + {a.hops} hops) {t_first:.2f} s, "
               f"cached propagate {t_prop * 1e3:.1f} ms + over-smoothing weights {t_nafs * 1e3:.1f} ms "
               f"= {int(nnz) * a.feat * a.hops / t_again / 1e12:.3f}e12 edge*feat/s; checksum {float(check):.6e}")
+        print(f"  hop sweep: the smoothed features of all {a.hops + 1} hop counts from the same propagation in {t_sweep * 1e3:.1f} ms "
+              f"(the reference re-propagates per hop count: {a.hops * (a.hops + 1) // 2} hops instead of {a.hops})")
         assert np.isfinite(float(check))
     if world > 1:
         dist.destroy_process_group()

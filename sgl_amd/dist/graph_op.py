@@ -363,6 +363,19 @@ class ShardedGraphOp:
         """all-gather a local [hi-lo, d] shard into the full [N, d] matrix (row-sharded layout)"""
         return self.gather_full(local)
 
+    def over_smooth_sweep(self, hops, hops_list):
+        """The NAFS aggregate of EVERY requested prefix X_0..X_h of this rank's hop shards in one pass (the adaptive-k-hop sweep of the
+        NAFS tasks, tasks/node_clustering.py:139,176-178, on row-sharded storage: BASELINE config 4): {h: [n_local, d]}.  The
+        over-smoothing weights are per node and a row-sharded rank owns whole rows, so this is sgl_nafs_prefix_f32 on the local
+        shards with no communication at all; column-sliced layouts fall back to one over_smooth_aggregate per prefix."""
+        from .. import device as dev
+        hops_list = sorted({int(h) for h in (range(hops_list) if isinstance(hops_list, int) else hops_list)})
+        prop = self._prop
+        feats = [h.contiguous() for h in hops]
+        if (prop.layout is None or prop.layout.col_groups == 1) and feats[0].shape[1] <= 512:
+            return dict(zip(hops_list, dev.nafs_prefix(feats, hops_list)))
+        return {h: self.over_smooth_aggregate(hops[:h + 1]) for h in hops_list}
+
     def over_smooth_aggregate(self, hops):
         """OverSmoothDistanceWeightedOp (NAFS, message_op/over_smooth_distance_op.py:6-33) on this rank's blocks, for any
         layout.  The weights need whole rows (cosine of X_0[n] and X_h[n]); a rank that owns only a column slice

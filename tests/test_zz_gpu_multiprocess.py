@@ -152,6 +152,12 @@ def _two_rank_worker(rank, world, port, out_dir):
         nafs_c = opc.gather_full(opc.over_smooth_aggregate(hc))
         ok = ok and orc.parity_ok(nafs_c.cpu().numpy(), orc.agg_over_smooth_distance(ref), 1e-5, rowwise=False)
         ok = ok and torch.equal(op.over_smooth_aggregate(hops), nafs)      # row-sharded: the fused kernel itself
+        # the adaptive-k-hop sweep on the shards: every prefix from one pass, no communication; column slices: one aggregate per prefix
+        sw = op.over_smooth_sweep(hops, [1, 3])
+        ok = ok and sorted(sw) == [1, 3] and orc.parity_ok(sw[3].cpu().numpy(), nafs.cpu().numpy(), 1e-5)
+        ok = ok and orc.parity_ok(op.gather_rows(sw[1].contiguous()).cpu().numpy(), orc.agg_over_smooth_distance(ref[:2]), 1e-5)
+        swc = opc.over_smooth_sweep(hc, [1, 3])
+        ok = ok and orc.parity_ok(opc.gather_full(swc[1]).cpu().numpy(), orc.agg_over_smooth_distance(ref[:2]), 1e-5)
         # ROW-SHARDED STORAGE (the contract layout): rank 0 holds the raw graph and hands out row blocks; every rank
         # normalises ITS block (degrees all-reduced), never sees the rest of A or A_hat, and passes only its feature rows
         from sgl_amd.dist import RowBlock, balanced_bounds, exchange_checksums, scatter_row_blocks
