@@ -178,63 +178,103 @@ __global__ __launch_bounds__(256) void block_build_kernel(const int64_t *__restr
                                                           int64_t n, int64_t row0, int64_t *__restrict__ o_rowptr,
                                                           int32_t *__restrict__ o_col, double *__restrict__ o_val,
                                                           double *__restrict__ rowsum, unsigned long long *sym_hash) {
-    __shared__ int64_t rp[kBuildRows + 1], sh[kBuildRows + 1];
+    // row pointers and diagonal shifts of the block's rows, RELATIVE to its first row, in LDS (32-bit: a block of 256 rows of a
+    // matrix with < 2^32 non-zeros per row block)
+    __shared__ uint32_t rp[kBuildRows + 1], sh[kBuildRows + 1];
     const int64_t r_begin = (int64_t)blockIdx.x * kBuildRows;
     const int rows = (int)min((int64_t)kBuildRows, n - r_begin);
+    const int64_t p0 = rowptr[r_begin], s0 = shift[r_begin];
     for (int t = threadIdx.x; t <= rows; t += 256) {
-        rp[t] = rowptr[r_begin + t];
-        sh[t] = shift[r_begin + t];
+        rp[t] = (uint32_t)(rowptr[r_begin + t] - p0);
+        sh[t] = (uint32_t)(shift[r_begin + t] - s0);
     }
     __syncthreads();
     // symmetry fingerprint (whole matrices only): every off-diagonal entry (i, j, v) adds +h(min, max, v) if i < j and
     // -h(...) if i > j, in wrapping 64-bit arithmetic: the sum over a matrix with A[i,j] == A[j,i] bit for bit is 0, and
     // it is non-zero for any other matrix except with probability 2^-64
     uint64_t fp = 0;
-    const int64_t p0 = rp[0], p1 = rp[rows];
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
-        int lo = 0, hi = rows;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (rp[mid] <= p) lo = mid; else hi = mid;
+    const uint32_t cnt = rp[rows];
+    const int32_t *colb = col + p0;
+    const float *valb = val + p0;
+    int32_t *ocol = o_col + p0 + s0;
+    double *oval = o_val + p0 + s0;
+    constexpr int U = 4;                                         // independent element loads in flight per thread
+    for (uint32_t q0 = threadIdx.x; q0 < cnt; q0 += 256 * U) {
+        int32_t c[U];
+        float vf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 256u * u;
+            c[u] = q < cnt ? __builtin_nontemporal_load(colb + q) : 0;
+            vf[u] = q < cnt ? __builtin_nontemporal_load(valb + q) : 0.f;
         }
-        const int32_t me = (int32_t)(row0 + r_begin + lo);
-        const int32_t c = col[p];
-        const float vf = val[p];
-        double v = (double)vf;
-        const bool miss = sh[lo + 1] != sh[lo];                 // this row gets a diagonal entry inserted
-        const int64_t o = p + sh[lo] + ((miss && c > me) ? 1 : 0);
-        if (c == me) v += 1.0;                                   // a_ii + 1
-        o_col[o] = c;
-        o_val[o] = v;
-        if (sym_hash && c != me) {
-            const uint64_t lo_ = (uint64_t)(c < me ? c : me), hi_ = (uint64_t)(c < me ? me : c);
-            const uint64_t h = sym_mix(sym_mix(lo_ * 0x100000001B3ull + hi_) ^ (uint64_t)__float_as_uint(vf));
-            fp += (me < c) ? h : (0ull - h);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 256u * u;
+            if (q >= cnt) continue;
+            int lo = 0, hi = rows;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= q) lo = mid; else hi = mid;
+            }
+            const int32_t me = (int32_t)(row0 + r_begin + lo);
+            double v = (double)vf[u];
+            const bool miss = sh[lo + 1] != sh[lo];             // this row gets a diagonal entry inserted
+            const uint32_t o = q + sh[lo] + ((miss && c[u] > me) ? 1u : 0u);
+            if (c[u] == me) v += 1.0;                            // a_ii + 1
+            ocol[o] = c[u];
+            oval[o] = v;
+            if (sym_hash && c[u] != me) {
+                const uint64_t lo_ = (uint64_t)(c[u] < me ? c[u] : me), hi_ = (uint64_t)(c[u] < me ? me : c[u]);
+                const uint64_t h = sym_mix(sym_mix(lo_ * 0x100000001B3ull + hi_) ^ (uint64_t)__float_as_uint(vf[u]));
+                fp += (me < c[u]) ? h : (0ull - h);
+            }
         }
     }
     if (sym_hash && fp) atomicAdd(sym_hash, (unsigned long long)fp);
     const int t = threadIdx.x;
     if (t < rows) {
         const int32_t me = (int32_t)(row0 + r_begin + t);
-        const int64_t ob = rp[t] + sh[t];
-        o_rowptr[r_begin + t] = ob;
+        o_rowptr[r_begin + t] = p0 + s0 + rp[t] + sh[t];
         if (sh[t + 1] != sh[t]) {                                // insert the diagonal before the first larger column
-            int64_t lo = rp[t], hi = rp[t + 1];
+            uint32_t lo = rp[t], hi = rp[t + 1];
             while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (col[mid] < me) lo = mid + 1; else hi = mid;
+                const uint32_t mid = (lo + hi) >> 1;
+                if (colb[mid] < me) lo = mid + 1; else hi = mid;
             }
-            o_col[lo + sh[t]] = me;
-            o_val[lo + sh[t]] = 1.0;
+            ocol[lo + sh[t]] = me;
+            oval[lo + sh[t]] = 1.0;
         }
     }
-    if (r_begin + rows == n && t == 0) o_rowptr[n] = rp[rows] + sh[rows];
+    if (r_begin + rows == n && t == 0) o_rowptr[n] = p0 + s0 + rp[rows] + sh[rows];
     __syncthreads();                                             // the block's rows of T' are complete (same CU wrote them)
+    // Row sums, SEQUENTIAL in column order (the fp64 sum scipy forms).  A thread walking its row alone pays one dependent L2 round
+    // trip per element: fine for the usual few dozen, but the launch then lasts as long as its LONGEST row -- 17 481 elements x
+    // ~0.2 us = 3.4 ms at the products shape, the whole kernel (profiles/r05_all_kernels_stats.csv).  Rows beyond 64 elements are
+    // therefore summed by a whole wavefront: 64 consecutive values in one coalesced load, then the same sequential chain of
+    // additions fed from registers (v_readlane) instead of from memory -- the same operations in the same order.
+    constexpr uint32_t kCoopRow = 64;
     if (t < rows) {
-        const int64_t ob = rp[t] + sh[t], oe = rp[t + 1] + sh[t + 1];
+        const uint32_t ob = rp[t] + sh[t], oe = rp[t + 1] + sh[t + 1];
+        if (oe - ob <= kCoopRow) {
+            double s = 0.0;
+            for (uint32_t q = ob; q < oe; ++q) s += __builtin_nontemporal_load(oval + q);
+            rowsum[r_begin + t] = s;
+        }
+    }
+    const int lane = t & 63;
+    for (int r = t >> 6; r < rows; r += 4) {                     // uniform per wavefront
+        const uint32_t ob = rp[r] + sh[r], oe = rp[r + 1] + sh[r + 1];
+        if (oe - ob <= kCoopRow) continue;
         double s = 0.0;
-        for (int64_t q = ob; q < oe; ++q) s += __builtin_nontemporal_load(o_val + q);
-        rowsum[r_begin + t] = s;
+        for (uint32_t q = ob; q < oe; q += 64) {
+            const double x = (q + lane < oe) ? oval[q + lane] : 0.0;
+            const int m = (int)min(64u, oe - q);
+            const int xl = __double2loint(x), xh = __double2hiint(x);
+            for (int j = 0; j < m; ++j)
+                s += __hiloint2double(__builtin_amdgcn_readlane(xh, j), __builtin_amdgcn_readlane(xl, j));
+        }
+        if (lane == 0) rowsum[r_begin + r] = s;
     }
 }
 

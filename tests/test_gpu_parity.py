@@ -453,6 +453,35 @@ def test_prepared_adjacency_symmetric_fast_path(goldens, cuda):
     assert np.array_equal(v32.cpu().numpy(), ref[2].astype(np.float32))
 
 
+def test_long_weighted_rows_are_summed_in_scipy_order(cuda):
+    """the fp64 degrees of A + I are SEQUENTIAL sums in column order (what scipy's row sum forms); rows beyond 64 elements are summed
+    by a whole wavefront fed from registers -- same operations, same order: bit-identical degrees for real-valued weights, and the
+    normalised matrix bit-identical to the oracle's"""
+    rng = np.random.default_rng(3)
+    n = 3000
+    rows = np.concatenate([np.full(700, 5), np.full(65, 9), np.full(64, 10), np.full(2999, 11), rng.integers(0, n, 6000)])
+    cols = np.concatenate([rng.choice(n, 700, replace=False), rng.choice(n, 65, replace=False), rng.choice(n, 64, replace=False),
+                           np.delete(np.arange(n), 11), rng.integers(0, n, 6000)])
+    a = sp.coo_matrix((rng.random(rows.size).astype(np.float32) + 0.01, (rows, cols)), shape=(n, n)).tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    to = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(cuda)  # noqa: E731
+    prep = dev.PreparedAdjacency(to(a.indptr, np.int64), to(a.indices, np.int32), to(a.data, np.float32), n)
+    ap = (a.astype(np.float64) + sp.eye(n, format="csr")).tocsr()
+    ap.sort_indices()
+    want = np.zeros(n)
+    for i in range(n):                                           # the sequential sum, element by element
+        s_ = 0.0
+        for v_ in ap.data[ap.indptr[i]:ap.indptr[i + 1]]:
+            s_ += v_
+        want[i] = s_
+    assert np.array_equal(prep.deg.cpu().numpy(), want)
+    assert int(np.diff(ap.indptr).max()) == n and (np.diff(ap.indptr) > 64).sum() >= 3
+    ref = oracle.sym_norm_csr(a.indptr, a.indices, a.data, n, 0.5, None)
+    _, _, v32 = prep.normalize(0.5)
+    assert np.array_equal(v32.cpu().numpy(), ref[2].astype(np.float32))
+
+
 @pytest.mark.parametrize("gname", ["sym64", "dir40", "pl2000"])
 def test_row_block_normalisation_matches_full(goldens, cuda, gname):
     """sgl_norm_block_*: every rank of a row-sharded job normalises only ITS rows; the blocks laid end to end are
