@@ -412,7 +412,8 @@ def test_python_examples_run_end_to_end(cuda):
     for script, extra, expect in (("sgc_synthetic.py", ["--nodes", "4000", "--feat", "64", "--epochs", "5"], "test acc"),
                                   ("gamlp_label_reuse_synthetic.py", ["--workload", "S1_small", "--epochs", "2", "--label-iters", "1",
                                                                       "--prop-steps", "3"], "label use + reuse per epoch"),
-                                  ("nafs_row_sharded.py", ["--nodes", "200000", "--hops", "3", "--feat", "64"], "NAFS row-sharded x1")):
+                                  ("nafs_row_sharded.py", ["--nodes", "200000", "--hops", "3", "--feat", "64"], "NAFS row-sharded x1"),
+                                  ("nafs_hop_sweep.py", ["--nodes", "6000", "--hops", "5"], "best hop count")):
         r = subprocess.run([_sys.executable, os.path.join(root, "examples", script), *extra], capture_output=True, text=True, timeout=600,
                            env=env)
         assert r.returncode == 0 and expect in r.stdout, (script, r.stdout[-800:], r.stderr[-1500:])
