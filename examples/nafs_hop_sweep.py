@@ -35,7 +35,7 @@ def planted_graph(n, classes, deg, p_in, d, seed):
         b[m] = same[c][: m.sum()]
     adj = sp.coo_matrix((np.ones(a.size, np.float32), (a, b)), shape=(n, n)).tocsr()
     adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
-    x = rng.standard_normal((n, d)).astype(np.float32) + 0.35 * np.eye(classes, d, dtype=np.float32)[y]     # weak class signal
+    x = rng.standard_normal((n, d)).astype(np.float32) + 1.0 * np.eye(classes, d, dtype=np.float32)[y]      # weak class signal
     return adj, x, y
 
 
@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--hops", type=int, default=8)
     ap.add_argument("--classes", type=int, default=5)
     a = ap.parse_args()
-    adj, x, y = planted_graph(a.nodes, a.classes, 10, 0.7, 32, seed=0)
+    adj, x, y = planted_graph(a.nodes, a.classes, 10, 0.8, 32, seed=0)
     scores = {}
 
     def consume(hop, feats):                                   # called in hop order once the ensemble over r is complete
