@@ -300,3 +300,28 @@ def test_g10_label_use_features_and_their_propagation(goldens):
         assert np.array_equal(f.astype(np.float64).sum(0), g10[f"call{call}|feature_colsum"])
         hops = oracle.propagate(norm, f, K)
         assert np.array_equal(np.array([h.astype(np.float64).sum() for h in hops]), g10[f"call{call}|hop_sums"]), call
+
+
+def test_truth_report_rule():
+    """the derived tolerance: at most `factor` times the reference's own float32 distance from the float64 truth, with a floor of
+    16 float32 roundings of the largest entry, and -- for sums of cancelling terms -- of the sum of their absolute values"""
+    truth = np.array([1.0, -2.0, 1e-3])
+    ref = truth + np.array([1e-6, 0.0, 0.0])                 # the reference is 1e-6 / 2 = 5e-7 (relative to max|truth|) off
+    assert oracle.truth_report(truth + np.array([0.0, 1.9e-6, 0.0]), ref, truth)["ok"]                    # within 2 x
+    floor_abs = oracle.TRUTH_FLOOR * 2.0
+    assert oracle.truth_report(truth + np.array([0.0, 0.0, 0.9 * floor_abs]), truth, truth)["ok"]         # exact reference: the floor
+    bad = oracle.truth_report(truth + np.array([0.0, 0.0, 3e-6]), ref, truth)
+    assert not bad["ok"] and bad["err_got"] > bad["bound"] and abs(bad["err_ref"] - 5e-7) < 1e-12
+    # a cancelled scalar: tiny value, large sum of absolute terms -> the condition-aware bound applies to that element only
+    t2, c2 = np.array([1e-4, 5.0]), np.array([40.0, 5.0])
+    assert not oracle.truth_report(t2 + np.array([2e-5, 0.0]), t2, t2)["ok"]
+    assert oracle.truth_report(t2 + np.array([2e-5, 0.0]), t2, t2, cond=c2)["ok"]
+    assert not oracle.truth_report(t2 + np.array([2e-5, 2e-5]), t2, t2, cond=c2)["ok"]
+    assert not oracle.truth_report(np.zeros(2), np.zeros(3), np.zeros(3))["ok"]
+    # the two relaxations of parity_report apply to one-column outputs only
+    rng = np.random.default_rng(0)
+    ref = rng.standard_normal((50, 8)).astype(np.float32)
+    ref[3] *= 1e-6                                           # a tiny row: its relative row error is large for a fixed absolute error
+    y = ref + np.float32(2e-6) * np.abs(ref).max() * np.sign(ref)
+    assert not oracle.parity_ok(y, ref, 1e-5) and not oracle.parity_ok(y, ref, 1e-5, rowwise=False)       # wide output: unrelaxed
+    assert oracle.parity_ok(y[:, :1], ref[:, :1], 1e-5, rowwise=False) and not oracle.parity_ok(y[:, :1], ref[:, :1], 1e-5)
