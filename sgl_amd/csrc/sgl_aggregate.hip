@@ -213,51 +213,6 @@ __device__ __forceinline__ typename Vt<VEC>::type load_masked(const float *p, in
     return v;
 }
 
-// The H x CH hop vectors of a register-resident row kernel, ALL IN FLIGHT before the first one is consumed.  Written as
-// `if (h < n_hops && on) x = load(...)` each load sits in its own predicated block followed by a full `s_waitcnt vmcnt(0)` -- the
-// compiler may not speculate a load that could fault -- so a wavefront had ONE hop vector in flight at a time and the kernels leaned on
-// occupancy alone for memory parallelism (round 5, found in the ISA).  Here every lane loads unconditionally from an address that is
-// always valid -- a dead row reads row 0, a lane slot beyond the row reads the row's last data vector again (same line: no extra
-// traffic), a hop slot beyond n_hops reads hop 0 again -- and the masks (whole vector / the tail beyond column d) are applied to the
-// registers afterwards.  Same values as before, bit for bit.
-template <int LPR, int CH, int HMAX, bool NT>
-__device__ __forceinline__ void load_hop_rows(const Hops &hx, const int n_hops, const int64_t r, const int l, const bool live,
-                                              const int d, f4 (&x)[HMAX][CH]) {
-    const int last = ((d - 1) >> 2) << 2;          // first column of the last 16-byte vector that holds data (d >= 1)
-    uint32_t colc[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) colc[c] = (uint32_t)min((c * LPR + l) * 4, last);
-    // address = a UNIFORM 64-bit base (the hop's matrix at the block's first row: scalar registers) + a 32-bit per-lane byte offset:
-    // one integer multiply per hop instead of a 64-bit row x pitch product per load, and no 64-bit address pair held per load in flight
-    // (18 loads in flight at 16 lanes x 3 chunks x 6 hops were 36 VGPRs of addresses).  The kernels using this map row = blockIdx.x *
-    // (256 / LPR) + threadIdx.x / LPR.
-    const int64_t row0 = (int64_t)blockIdx.x * (256 / LPR);
-    const uint32_t rl = live ? (uint32_t)(threadIdx.x / LPR) : 0u;
-    (void)r;
-#pragma unroll
-    for (int h = 0; h < HMAX; ++h) {
-        const int hh = h < n_hops ? h : 0;         // uniform
-        const char *sbase = reinterpret_cast<const char *>(hx.p[hh] + row0 * hx.ld[hh]);
-        const uint32_t rowoff = rl * (uint32_t)hx.ld[hh];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const f4 *q = reinterpret_cast<const f4 *>(sbase + (size_t)((rowoff + colc[c]) * 4u));
-            x[h][c] = NT ? __builtin_nontemporal_load(q) : *q;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int col = (c * LPR + l) * 4;
-        const bool on = live && col < d;
-#pragma unroll
-        for (int h = 0; h < HMAX; ++h) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (!(on && h < n_hops && col + e < d)) x[h][c][e] = 0.f;
-        }
-    }
-}
-
 // ---- row-wise reductions: LPR lanes cooperate on one row, 64/LPR rows per wavefront ------------------------
 // All-lanes sum over groups of LPR consecutive lanes.  Inside a 16-lane row the exchange is done by the VALU's DPP
 // modifiers (quad permutes, half-row / row mirrors) -- no LDS-crossbar instruction; only the steps that cross rows
@@ -352,8 +307,10 @@ __global__ __launch_bounds__(256) void hop_rowdot_reg_kernel(const Hops hx, cons
         } else {
             gv[c] = on ? load_masked<4>(g + r * ldg, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            xv[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    load_hop_rows<LPR, CH, HMAX, false>(hx, n_hops, r, l, live, d, xv);
     float acc[HMAX];
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
@@ -547,43 +504,23 @@ __global__ __launch_bounds__(256) void nafs_prefix_kernel(const Hops hx, const i
     const int64_t r = live ? row : 0;
     f4 x0[CH], acc[CH];
     bool on[CH];
-    int colc[CH];
-    const int last = ((d - 1) >> 2) << 2;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         on[c] = live && ((c * LPR + l) * 4 < d);
-        colc[c] = min((c * LPR + l) * 4, last);
+        x0[c] = (f4){0.f, 0.f, 0.f, 0.f};
         acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (on[c]) x0[c] = load_masked<4, true>(hx.p[0] + r * hx.ld[0], (c * LPR + l) * 4, d);
     }
-    // all loads of a group of hops are issued before any is consumed (unconditional, from addresses that are always valid; masks
-    // afterwards -- see load_hop_rows)
-    auto masked = [&](f4 v, const int c, const bool keep) {
-        const int col = (c * LPR + l) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (!(keep && on[c] && col + e < d)) v[e] = 0.f;
-        return v;
-    };
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-        x0[c] = masked(__builtin_nontemporal_load(reinterpret_cast<const f4 *>(hx.p[0] + r * hx.ld[0] + colc[c])), c, true);
     float n0 = 1.f, den = 0.f;
     for (int hb = 0; hb < n_hops; hb += kPrefixUnroll) {
         f4 x[kPrefixUnroll][CH];
-#pragma unroll
-        for (int u = 0; u < kPrefixUnroll; ++u) {
-            const int h = hb + u;
-            const int hh = (h > 0 && h < n_hops) ? h : 0;     // uniform; hop 0 is re-read from cache for the slots that are not used
-            const float *base = hx.p[hh] + r * hx.ld[hh];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) x[u][c] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + colc[c]));
-        }
 #pragma unroll
         for (int u = 0; u < kPrefixUnroll; ++u)
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int h = hb + u;
-                x[u][c] = (h == 0) ? x0[c] : masked(x[u][c], c, h < n_hops);
+                x[u][c] = (h == 0) ? x0[c] : (f4){0.f, 0.f, 0.f, 0.f};
+                if (h > 0 && h < n_hops && on[c]) x[u][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
             }
 #pragma unroll
         for (int u = 0; u < kPrefixUnroll; ++u) {
@@ -647,7 +584,14 @@ __global__ __launch_bounds__(256, ROWREG_MIN_BLOCKS(HMAX, CH)) void nafs_fused_k
     bool on[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) on[c] = live && ((c * LPR + l) * 4 < d);
-    load_hop_rows<LPR, CH, HMAX, true>(hx, n_hops, r, l, live, d, x);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
     f4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -761,7 +705,14 @@ __global__ __launch_bounds__(256, GATE_MIN_BLOCKS(LPR, HMAX, CH)) void gate_fuse
         on[c] = live && col < d;
         vv[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    load_hop_rows<LPR, CH, HMAX, true>(hx, n_hops, r, l, live, d, x);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
     f4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -876,7 +827,14 @@ __global__ __launch_bounds__(256, RECUR_MIN_BLOCKS(LPR, HMAX, CH)) void recursiv
         vx[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
         va[c] = (col < d) ? load_masked<4>(vec + dv, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    load_hop_rows<LPR, CH, HMAX, true>(hx, n_hops, r, l, live, d, x);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            x[h][c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (h < n_hops && on[c]) x[h][c] = load_masked<4, true>(hx.p[h] + r * hx.ld[h], (c * LPR + l) * 4, d);
+        }
+    }
     f4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -1086,8 +1044,10 @@ __global__ __launch_bounds__(256) void hop_rowdot2_reg_kernel(const Hops hx, con
         const int col = (c * LPR + l) * 4;
         const bool on = live && col < d;
         vv[c] = (col < d) ? load_masked<4>(vec, col, d) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h)
+            x[h][c] = (on && h < n_hops) ? load_masked<4>(hx.p[h] + r * hx.ld[h], col, d) : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    load_hop_rows<LPR, CH, HMAX, false>(hx, n_hops, r, l, live, d, x);
     __syncthreads();
     float acc[HMAX];
     float shared = 0.f;
