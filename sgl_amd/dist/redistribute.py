@@ -36,7 +36,7 @@ def _staged(group, t):
 
 def _gather_ints(values, group):
     """[world, len(values)] int64 table of every rank's small integer list (identical everywhere)"""
-    rank, world = _world(group)
+    world = _world(group)[1]
     if world == 1:
         return np.asarray([values], dtype=np.int64)
     everyone = [None] * world
@@ -56,7 +56,7 @@ def exchange_var(sends, group=None):
     like = sends[rank]
     staged = _staged(group, like)
     recvs = [None] * world
-    ops, keep, landings = [], [], []
+    ops, keep = [], []
     for q in range(world):
         gq = dist.get_global_rank(group, q) if group is not None else q
         if q == rank:

@@ -83,7 +83,6 @@ def main():
     prep = dev.PreparedBlock(block0.rowptr, block0.col, block0.val, lo, n, symmetric=False, deg=deg)
     torch.cuda.synchronize()
     print(f"S4 prepare_block_ms={(time.time() - t0) * 1e3:8.1f}  (once per graph: T + I fp64 values, row sums; {prep.nnz_out} nnz)", flush=True)
-    m = prep.nnz_out
     for name, r, alpha in (("laplacian r=0.5", 0.5, None), ("ppr a=0.1", 0.5, 0.1), ("ppr a=0.2", 0.5, 0.2), ("ppr a=0.3", 0.5, 0.3),
                            ("laplacian r=0.3", 0.3, None)):
         for route in ((True, "auto") if name in ("laplacian r=0.5", "laplacian r=0.3") else ("auto",)):
