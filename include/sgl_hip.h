@@ -172,6 +172,13 @@ int sgl_download(void *h_dst, const void *d_src, int64_t bytes, void *stream);
  * Synchronises the stream. */
 int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_col, int64_t n, int rounds, int64_t *d_order,
                           int64_t *h_info, void *stream);
+/* One round of that label propagation over a ROW BLOCK of a row-sharded matrix (rows [row0, row0 + n_local): local row pointers,
+ * GLOBAL column ids): d_labels = the current labels of all n_global nodes (int32), d_out = the new labels of the block's nodes
+ * (int32 [n_local]), *d_moved (optional, a zeroed 64-bit device word) += nodes whose label changed.  The caller all-gathers the
+ * ranks' slices between rounds and passes last != 0 in the final round; the stable sort by label is the caller's.  Running it over
+ * the blocks of a partition reproduces sgl_reorder_community's labels exactly (sgl_amd/dist/redistribute.py). */
+int sgl_reorder_lpa_round(const int64_t *d_rowptr, const int32_t *d_col, int64_t n_local, int64_t row0, int64_t n_global,
+                          const int32_t *d_labels, int32_t *d_out, int round, int last, uint64_t *d_moved, void *stream);
 
 /* The rows of a CSR in processing order: storage row k of the output = input row d_perm[k]; column ids and the order of every
  * row's entries unchanged (out_rowptr [n+1], out_col / out_val [nnz] caller-allocated).  A handle created on the output and

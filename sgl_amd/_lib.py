@@ -75,6 +75,7 @@ PROTOTYPES = {
     "sgl_download": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_csr_permute_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sgl_csr_set_rowmap": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sgl_reorder_lpa_round": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sgl_reorder_community": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, POINTER(c_int64), c_void_p]),
     "sgl_hop_reduce_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                    c_void_p]),

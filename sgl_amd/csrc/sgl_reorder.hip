@@ -26,17 +26,19 @@ __device__ __forceinline__ bool lpa_active(int64_t node, int round, int last) {
     return (int)(x & 1ull) == (round & 1);
 }
 
+// rows [row0, row0 + n) of the matrix (rowptr local to the block, GLOBAL column ids); labels: one per node of the WHOLE graph;
+// out: the new labels of the block's nodes (local index).  row0 = 0 and n = all nodes: the whole matrix.
 __global__ __launch_bounds__(256) void lpa_round_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        const int64_t n, const int32_t *__restrict__ labels,
+                                                        const int64_t n, const int64_t row0, const int32_t *__restrict__ labels,
                                                         int32_t *__restrict__ out, const int round, const int last,
                                                         unsigned long long *__restrict__ moved) {
     __shared__ int32_t sl[4][kSample];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t node = (int64_t)blockIdx.x * 4 + w;
     if (node >= n) return;
-    const int32_t mine = labels[node];
+    const int32_t mine = labels[row0 + node];
     const int64_t p0 = rowptr[node], deg = rowptr[node + 1] - p0;
-    if (deg == 0 || !lpa_active(node, round, last)) {
+    if (deg == 0 || !lpa_active(row0 + node, round, last)) {
         if (lane == 0) out[node] = mine;
         return;
     }
@@ -158,7 +160,7 @@ SGL_EXPORT int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_c
     SGL_HIP_CHECK(hipGetLastError());
     int32_t *cur = la, *nxt = lb;
     for (int it = 0; it < rounds; ++it) {
-        hipLaunchKernelGGL(lpa_round_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_rowptr, d_col, n, cur, nxt, it,
+        hipLaunchKernelGGL(lpa_round_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_rowptr, d_col, n, (int64_t)0, cur, nxt, it,
                            it == rounds - 1 ? 1 : 0, counters + it);
         SGL_HIP_CHECK(hipGetLastError());
         std::swap(cur, nxt);
@@ -182,6 +184,33 @@ SGL_EXPORT int sgl_reorder_community(const int64_t *d_rowptr, const int32_t *d_c
         h_info[0] = (int64_t)h[0];
         h_info[1] = (int64_t)h[1];
     }
+    return SGL_OK;
+}
+
+// ONE round of the same label propagation for a ROW BLOCK of a matrix whose storage is row-sharded (sgl_amd/dist/redistribute.py):
+// rows [row0, row0 + n_local) with local row pointers and GLOBAL column ids, the labels of ALL nodes in (int32 [n_global]), the new
+// labels of the block's nodes out (int32 [n_local]); *d_moved (optional, a zeroed 64-bit word on the device) counts the nodes whose
+// label changed.  The caller all-gathers the ranks' slices between rounds; `last` != 0 in the final round (every node may move).
+// Exactly the per-node computation of sgl_reorder_community: running it over the blocks of a partition gives the whole-matrix labels.
+SGL_EXPORT int sgl_reorder_lpa_round(const int64_t *d_rowptr, const int32_t *d_col, int64_t n_local, int64_t row0, int64_t n_global,
+                                     const int32_t *d_labels, int32_t *d_out, int round, int last, uint64_t *d_moved, void *stream) {
+    SGL_REQUIRE(n_local >= 0 && row0 >= 0 && row0 + n_local <= n_global && n_global < INT32_MAX, "sgl_reorder_lpa_round: bad sizes");
+    SGL_REQUIRE(round >= 0 && round < 64, "sgl_reorder_lpa_round: round must lie in [0, 64)");
+    if (n_local == 0) return SGL_OK;
+    SGL_REQUIRE(d_rowptr && d_col && d_labels && d_out, "sgl_reorder_lpa_round: NULL arrays");
+    SGL_REQUIRE(sgl::launch_fits((n_local + 3) / 4, 256), "sgl_reorder_lpa_round: too many rows for one launch");
+    unsigned long long *moved = reinterpret_cast<unsigned long long *>(d_moved);
+    Tmp tmp;
+    hipStream_t st = sgl::as_stream(stream);
+    if (!moved) {
+        int rc;
+        if ((rc = tmp.alloc(&moved, 1)) != SGL_OK) return rc;
+        SGL_HIP_CHECK(hipMemsetAsync(moved, 0, sizeof(unsigned long long), st));
+    }
+    hipLaunchKernelGGL(lpa_round_kernel, dim3((unsigned)((n_local + 3) / 4)), dim3(256), 0, st, d_rowptr, d_col, n_local, row0, d_labels,
+                       d_out, round, last ? 1 : 0, moved);
+    SGL_HIP_CHECK(hipGetLastError());
+    if (!d_moved) SGL_HIP_CHECK(hipStreamSynchronize(st));   // the scratch counter is freed on return
     return SGL_OK;
 }
 

@@ -6,8 +6,9 @@ blocks, so that a block references mostly its own rows and the need-aware exchan
 first implementation assembled the normalised matrix on every rank to find and apply the relabelling -- 27 GB of CSR per rank at
 papers100M size, and the full feature matrix (57 GB) next to it.  Here every step works on the ranks' own rows:
 
-  labels    semi-synchronous label propagation (the algorithm of sgl_amd.reorder.community_order_reference, every neighbour
-            counted): a rank updates the labels of ITS rows from the labels of their neighbours; what is replicated is the label
+  labels    semi-synchronous label propagation -- on the device the very per-node kernel of sgl_reorder_community, one round at a time
+            (sgl_reorder_lpa_round); on CPU tensors the tensor-code statement of the same algorithm
+            (sgl_amd.reorder.community_order_reference): a rank updates the labels of ITS rows from the labels of their neighbours; what is replicated is the label
             VECTOR (one integer per node: 0.9 GB at papers100M size, against 27 GB of matrix), refreshed by an all-gather of
             the ranks' slices per round
   order     the stable sort by label of that vector: identical on every rank, no communication
@@ -18,8 +19,7 @@ papers100M size, and the full feature matrix (57 GB) next to it.  Here every ste
   features  a rank asks the owners (old ids) for exactly the feature rows its new compact table holds (fetch_rows)
 
 The result -- block boundaries, the block's CSR arrays, the node ids of its rows -- equals what the whole-matrix path computes
-(tests: both inputs give the same hops), as long as no node has more neighbours than the device kernel of that path samples
-(256); beyond that the two are different, equally valid, heuristics' outputs."""
+(tests: both inputs give the same hops): on the device both run the same per-node kernel."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -117,6 +117,8 @@ def sharded_community_order(block, bounds, group=None, rounds=8):
     The same rounds, activity masks and tie rule as sgl_amd.reorder.community_order_reference on the whole matrix."""
     n, lo, hi = block.n, block.lo, block.hi
     dev = block.device
+    if block.rowptr.is_cuda:
+        return _sharded_community_order_device(block, bounds, group, rounds)
     deg = (block.rowptr[1:] - block.rowptr[:-1]).to(torch.int64)
     row = torch.repeat_interleave(torch.arange(hi - lo, device=dev, dtype=torch.int64), deg)      # LOCAL row of every non-zero
     colq = block.col.to(torch.int64)
@@ -144,6 +146,35 @@ def sharded_community_order(block, bounds, group=None, rounds=8):
     order = torch.empty_like(perm)
     order[perm] = torch.arange(n, device=dev, dtype=torch.int64)
     total_moved = int(_gather_ints([moved], group).sum())
+    n_comm = int(torch.unique(labels).numel())
+    return order, f"{n_comm} communities after {rounds} rounds, {total_moved} nodes moved in the last"
+
+
+@torch.no_grad()
+def _sharded_community_order_device(block, bounds, group, rounds):
+    """the device form: every round is sgl_reorder_lpa_round -- the per-node kernel of sgl_reorder_community (one wavefront per
+    node, a strided sample of at most 256 neighbours) -- on this rank's rows, the slices all-gathered between rounds; the stable sort
+    by label is torch's.  Identical to what the whole-matrix kernel computes for ANY graph, long rows included."""
+    import ctypes
+    from .. import _lib
+    n, lo, hi = block.n, block.lo, block.hi
+    dev = block.device
+    rowptr = block.rowptr.to(torch.int64).contiguous()
+    col = block.col.to(torch.int32).contiguous()
+    labels = torch.arange(n, device=dev, dtype=torch.int32)
+    moved = torch.zeros(1, dtype=torch.int64, device=dev)
+    for it in range(rounds):
+        new = torch.empty(hi - lo, dtype=torch.int32, device=dev)
+        moved.zero_()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().sgl_reorder_lpa_round(_lib.ptr(rowptr), _lib.ptr(col), hi - lo, lo, n, _lib.ptr(labels), _lib.ptr(new), it,
+                                                        1 if it == rounds - 1 else 0, ctypes.c_void_p(moved.data_ptr()),
+                                                        _lib.current_stream_ptr()), "sgl_reorder_lpa_round")
+        labels = _allgather_slices(new, bounds, n, group)
+    perm = torch.argsort(labels, stable=True)
+    order = torch.empty(n, dtype=torch.int64, device=dev)
+    order[perm] = torch.arange(n, device=dev, dtype=torch.int64)
+    total_moved = int(_gather_ints([int(moved.item())], group).sum())
     n_comm = int(torch.unique(labels).numel())
     return order, f"{n_comm} communities after {rounds} rounds, {total_moved} nodes moved in the last"
 

@@ -2236,6 +2236,56 @@ def test_row_sharded_pieces_on_one_gpu(goldens, cuda):
         assert np.array_equal(hops[h].cpu().numpy(), ref[h])
 
 
+def test_label_propagation_round_by_round_over_row_blocks_equals_the_whole_matrix_kernel(cuda):
+    """sgl_reorder_lpa_round (one round of the plan-time label propagation on a ROW BLOCK, global labels in, the block's new labels
+    out) run over the blocks of a partition, slices assembled between rounds = what sgl_amd/dist/redistribute.py does with an
+    all-gather: the labels' stable sort equals sgl_reorder_community's order on the whole matrix -- also for rows with more than the
+    256 neighbours the kernel samples (planted communities + hubs, shuffled ids, unequal blocks incl. an empty one)"""
+    import ctypes
+    from sgl_amd.reorder import community_order
+    rng = np.random.default_rng(5)
+    n, bs = 9000, 300
+    a = np.repeat(np.arange(n), 10)
+    near = np.minimum((a // bs) * bs + rng.integers(0, bs, a.size), n - 1)
+    b = np.where(rng.random(a.size) < 0.85, near, rng.integers(0, n, a.size))
+    hubs = rng.choice(n, 3, replace=False)
+    a = np.concatenate([a, np.repeat(hubs, 900)])
+    b = np.concatenate([b, rng.integers(0, n, 2700)])
+    m = sp.coo_matrix((np.ones(a.size, np.float32), (a, b)), shape=(n, n)).tocsr()
+    m = ((m + m.T + sp.eye(n)) > 0).astype(np.float32).tocsr()
+    shuffle = rng.permutation(n)
+    P = sp.coo_matrix((np.ones(n, np.float32), (shuffle, np.arange(n))), shape=(n, n)).tocsr()
+    m = (P @ m @ P.T).tocsr()
+    m.sort_indices()
+    assert np.diff(m.indptr).max() > 256
+    rp = torch.from_numpy(m.indptr.astype(np.int64)).to(cuda)
+    cc = torch.from_numpy(m.indices.astype(np.int32)).to(cuda)
+    want, _ = community_order(rp, cc, n)
+    bounds = [0, 2500, 2500, 7001, n]
+    labels = torch.arange(n, dtype=torch.int32, device=cuda)
+    rounds = 8
+    for it in range(rounds):
+        nxt = torch.empty_like(labels)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if hi == lo:
+                continue
+            brp = (rp[lo:hi + 1] - rp[lo]).contiguous()
+            bcc = cc[int(m.indptr[lo]):int(m.indptr[hi])].contiguous()
+            out = torch.empty(hi - lo, dtype=torch.int32, device=cuda)
+            _lib.check(_lib.lib().sgl_reorder_lpa_round(_lib.ptr(brp), _lib.ptr(bcc), hi - lo, lo, n, _lib.ptr(labels), _lib.ptr(out), it,
+                                                        1 if it == rounds - 1 else 0, None, _lib.current_stream_ptr()), "sgl_reorder_lpa_round")
+            nxt[lo:hi] = out
+        labels = nxt
+    perm = torch.argsort(labels, stable=True)
+    order = torch.empty(n, dtype=torch.int64, device=cuda)
+    order[perm] = torch.arange(n, device=cuda)
+    assert torch.equal(order, want)
+    # and through the module (one rank: its block is the whole matrix)
+    from sgl_amd.dist import RowBlock, sharded_community_order
+    got, text = sharded_community_order(RowBlock(0, n, n, rp, cc, torch.ones(cc.numel(), device=cuda)), [0, n])
+    assert torch.equal(got, want) and "communities after 8 rounds" in text
+
+
 def test_row_pieces_cut_long_rows_where_the_whole_matrix_does(cuda):
     """default (non-strict) order: where a long row is cut depends on the matrix's nnz (sgl_csr_create: 32 / 128 / 512 / 2048).  A
     row block of a sharded matrix has fewer non-zeros than the whole and would fall into another bracket; the distributed paths
