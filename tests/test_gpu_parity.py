@@ -2151,6 +2151,21 @@ def test_nafs_hop_sweep_in_one_propagation(goldens, cuda):
     with pytest.raises(_lib.SglHipError):
         wide = [dev.upload_rows(hash_matrix(64, 516, seed=1), cuda)] * 2
         dev.nafs_prefix(wide, [1])
+    # the C entry point refuses what it cannot do, with a message (no kernel is launched): a prefix beyond the hop list, an unknown
+    # combination, a zero divisor, an output that is not 16-byte aligned
+    small = [dev.alloc_rows(8, 12, cuda).normal_() for _ in range(3)]
+    out = dev.alloc_rows(8, 12, cuda)
+    ptrs, lds = _lib.hop_arrays(small)
+    optrs, olds = _lib.hop_arrays([out])
+
+    def raw(mask, combine=0, divisor=1.0, op=optrs, ol=olds):
+        return _lib.lib().sgl_nafs_prefix_f32(3, ptrs, lds, mask, op, ol, 0, combine, divisor, 8, 12, _lib.current_stream_ptr())
+    assert raw(0b100) == 0
+    for bad in (raw(0b1000), raw(0), raw(0b1, combine=4), raw(0b1, combine=2, divisor=0.0)):
+        assert bad != 0 and _lib.last_error()
+    off = torch.empty(8 * 16 + 1, device=cuda)[1:].view(8, 16)[:, :12]            # rows 4 bytes off a 16-byte boundary
+    op2, ol2 = _lib.hop_arrays([off])
+    assert raw(0b1, op=op2, ol=ol2) != 0 and "16-byte aligned" in _lib.last_error()
 
 
 def test_ingest_raw_files_to_device_adjacency(goldens, cuda, tmp_path):
