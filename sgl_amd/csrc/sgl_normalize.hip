@@ -561,7 +561,8 @@ static int norm_block_build_impl(int64_t n, int64_t row0, int64_t nnz, const int
                                  double *d_out_val64, double *d_rowsum, unsigned long long *d_sym_hash, void *stream) {
     SGL_REQUIRE(n >= 0 && nnz >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_build: bad sizes");
     SGL_REQUIRE(nnz_out >= nnz && nnz_out <= nnz + n, "sgl_norm_block_build: nnz_out inconsistent (call sgl_norm_block_prepare)");
-    SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX, "sgl_norm_block_build: nnz >= 2^32 per block not supported (use more row blocks)");
+    // (the build / scale kernels index a group of rows with 32-bit offsets and step them by 1 024: stay clear of the wrap)
+    SGL_REQUIRE(nnz_out < (int64_t)UINT32_MAX - 4096, "sgl_norm_block_build: nnz >= 2^32 per block not supported (use more row blocks)");
     SGL_REQUIRE(d_out_rowptr != nullptr, "sgl_norm_block_build: NULL output row pointers");
     hipStream_t st = sgl::as_stream(stream);
     if (n == 0) {
