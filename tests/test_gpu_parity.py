@@ -2501,6 +2501,25 @@ def test_c_abi_row_sharded_program(cuda, tmp_path):
     assert "exchange backend: process" in out.stdout            # the library used the program's own RCCL, not a second copy
 
 
+def test_c_abi_sweeps_program(cuda, tmp_path):
+    """examples/c_abi_sweeps.c: the round-5 sweep entry points from plain C99 -- one preparation serving two r x (Laplacian + three
+    alpha) normalisations (sgl_norm_block_prepare / build once, sgl_norm_degree_powers, sgl_norm_block_scale, sgl_norm_block_mix) and
+    every NAFS prefix of a 6-hop propagation from one pass (sgl_nafs_prefix_f32), each checked on the host inside the program"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "sgl_amd", "csrc")
+    exe = str(tmp_path / "c_abi_sweeps")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(root, "examples", "c_abi_sweeps.c"), "-o", exe,
+                           "-L", libdir, "-lsgl_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C-ABI sweeps OK" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+
+
 def test_int64_offsets_beyond_2_31_elements(cuda):
     """papers100M-shard shape: the dense operand has more than 2^31 elements (the reference's `int` offsets overflow
     there, matmul.c:29,33) and the gathered rows sit at byte offsets beyond 8 GiB"""
