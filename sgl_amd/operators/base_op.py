@@ -48,6 +48,45 @@ class AdjIdentity:
         return held is adj and self._print == self.fingerprint(adj)
 
 
+_GRAPHS = []            # at most two entries: (AdjIdentity, device string, PreparedAdjacency)
+
+
+def prepared_graph(adj, device=None):
+    """device.PreparedAdjacency of `adj` (scipy sparse matrix or sgl_amd.io.DeviceAdjacency), shared process-wide between all
+    operators over the same matrix object with unchanged contents (AdjIdentity: object identity + full content hashes / device
+    buffer versions).  Holds the device copy of A and A + I in fp64 (24 bytes per non-zero) for the two most recently used
+    graphs while they are alive; clear_graph_cache() releases them, sgl_amd.config.cache_prepared = False turns the sharing off."""
+    from ..io import DeviceAdjacency
+    from .utils import canonical_csr
+    device = torch.device(device or "cuda")
+    key = str(device)
+    _GRAPHS[:] = [e for e in _GRAPHS if e[0]._ref is None or e[0]._ref() is not None]      # matrices that are gone
+    for i, (ident, dkey, prep) in enumerate(_GRAPHS):
+        if dkey == key and ident.matches(adj):
+            _GRAPHS.append(_GRAPHS.pop(i))
+            return prep
+    if isinstance(adj, DeviceAdjacency):
+        rowptr, col, val, n = adj.rowptr, adj.col, adj.val, adj.shape[0]
+    else:
+        csr = canonical_csr(adj)
+        if csr.shape[0] != csr.shape[1]:
+            raise ValueError("the adjacency matrix must be square")
+        n = csr.shape[0]
+        rowptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(device)
+        col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
+        val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+    prep = dev.PreparedAdjacency(rowptr, col, val, n)
+    _GRAPHS.append((AdjIdentity(adj), key, prep))
+    del _GRAPHS[:-2]
+    return prep
+
+
+def clear_graph_cache():
+    """release the device copies prepared_graph() keeps"""
+    _GRAPHS.clear()
+    dev.clear_power_cache()
+
+
 def _lib_reduce(kind):
     from .. import _lib
     return {"sum": _lib.SGL_REDUCE_SUM, "mean": _lib.SGL_REDUCE_MEAN, "wsum": _lib.SGL_REDUCE_WSUM,
@@ -105,7 +144,12 @@ class GraphOp:
             ident, cached_params = self._adj_key
             if cached_params == params and ident.matches(adj):
                 return self._adj
-        if isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
+        if config.cache_prepared:
+            # the (r, alpha)-independent part of the normalisation -- the device copy of A, A + I in fp64, the degrees, the symmetry
+            # check -- is shared by EVERY operator over the same matrix (prepared_graph below): a PaSca-style search builds a fresh
+            # GraphOp per trial (sgl/search/search_models.py:19-46) and pays one scaling pass per trial instead of upload + preparation
+            rowptr, col, val = prepared_graph(adj, self._opt("device")).normalize(r, alpha)
+        elif isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, adj.shape[0], r, alpha)
         else:
             rowptr, col, val = adj_to_symmetric_norm_device(adj, r, alpha, device=self._opt("device"))

@@ -453,6 +453,48 @@ def test_prepared_adjacency_symmetric_fast_path(goldens, cuda):
     assert np.array_equal(v32.cpu().numpy(), ref[2].astype(np.float32))
 
 
+def test_operators_over_one_matrix_share_its_preparation(goldens, cuda):
+    """a fresh GraphOp per trial over the same scipy matrix (a PaSca-style search) re-uses ONE device copy of A, A + I and the
+    degrees (operators.base_op.prepared_graph: keyed on object identity + content); results stay bit-identical to the goldens; an
+    in-place edit of the matrix is noticed; clear_graph_cache() releases the copies; cache_prepared = False restores the old path"""
+    from sgl_amd import config
+    from sgl_amd.operators import base_op
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    g = goldens.graph("pl2000")
+    g1 = goldens.npz("g1_norm")
+    x = hash_matrix(2000, 16, seed=3)
+    base_op.clear_graph_cache()
+    ops = [LaplacianGraphOp(2, r=0.5, strict_order=True), PprGraphOp(2, r=0.5, alpha=0.15, strict_order=True),
+           LaplacianGraphOp(2, r=0.3, strict_order=True)]
+    hops = [op.propagate(g, x) for op in ops]
+    assert len(base_op._GRAPHS) == 1
+    prep = base_op._GRAPHS[0][2]
+    assert base_op.prepared_graph(g, cuda) is prep
+    for op, key in zip(ops, ("pl2000|lap|0.5", "pl2000|ppr|0.5|0.15", "pl2000|lap|0.3")):
+        ref = oracle.propagate((g1["pl2000|indptr"], g1["pl2000|indices"], g1[key].astype(np.float32)), x, 2)
+        assert all(np.array_equal(h.cpu().numpy(), r_) for h, r_ in zip(hops[ops.index(op)], ref)), key
+    g2 = g.copy()
+    LaplacianGraphOp(1).propagate(g2, x)
+    assert len(base_op._GRAPHS) == 2                                    # another object: its own entry
+    g2.data[7] = 3.0                                                    # edited in place: the old preparation must not be served
+    y = LaplacianGraphOp(1, strict_order=True).propagate(g2, x)[1]
+    want = oracle.propagate(oracle.laplacian_adj(g2.indptr, g2.indices, g2.data, 2000, 0.5), x, 1)[1]
+    assert np.array_equal(y.cpu().numpy(), want) and len(base_op._GRAPHS) == 2
+    del g2
+    import gc
+    gc.collect()
+    base_op.prepared_graph(g, cuda)
+    assert len(base_op._GRAPHS) == 1                                    # the entry of the matrix that is gone was dropped
+    base_op.clear_graph_cache()
+    assert not base_op._GRAPHS
+    config.cache_prepared = False
+    try:
+        again = LaplacianGraphOp(2, r=0.5, strict_order=True).propagate(g, x)
+        assert not base_op._GRAPHS and all(torch.equal(a_, b_) for a_, b_ in zip(again, hops[0]))
+    finally:
+        config.cache_prepared = True
+
+
 def test_long_weighted_rows_are_summed_in_scipy_order(cuda):
     """the fp64 degrees of A + I are SEQUENTIAL sums in column order (what scipy's row sum forms); rows beyond 64 elements are summed
     by a whole wavefront fed from registers -- same operations, same order: bit-identical degrees for real-valued weights, and the

@@ -20,6 +20,16 @@ for host_out in (False, True):
         hops = op.propagate(adj, x)
         torch.cuda.synchronize()
         print(f"E2E host_output={host_out} {call}: {time.perf_counter() - t0:.3f} s for k=3 on N={n}, nnz(A)={adj.nnz}, d={d}", flush=True)
+    if not host_out:
+        # a FRESH operator per trial over the same matrix (what a PaSca-style search does, search_models.py:19-46): the device copy
+        # of A, A + I and the degrees are shared process-wide (operators.base_op.prepared_graph); a trial pays the content hash that
+        # proves the matrix unchanged, one scaling pass, the plan and its k hops
+        from sgl_amd.operators.graph_op import PprGraphOp
+        for trial in (LaplacianGraphOp(3, r=0.3), PprGraphOp(3, r=0.5, alpha=0.15), PprGraphOp(3, r=0.5, alpha=0.3)):
+            t0 = time.perf_counter()
+            trial.propagate(adj, x)
+            torch.cuda.synchronize()
+            print(f"E2E fresh {type(trial).__name__} on the same matrix: {time.perf_counter() - t0:.3f} s for k=3", flush=True)
     if host_out:
         from sgl_amd import hostpool
         ref = LaplacianGraphOp(3, r=0.5).propagate(adj, x)
