@@ -59,6 +59,8 @@ def prepared_graph(adj, device=None):
     from ..io import DeviceAdjacency
     from .utils import canonical_csr
     device = torch.device(device or "cuda")
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())     # "cuda" and "cuda:0" are the same place
     key = str(device)
     _GRAPHS[:] = [e for e in _GRAPHS if e[0]._ref is None or e[0]._ref() is not None]      # matrices that are gone
     for i, (ident, dkey, prep) in enumerate(_GRAPHS):
