@@ -1240,6 +1240,63 @@ def test_reorder_auto_and_row_sharded_blocks(cuda):
                     assert op.halo_plan.reorder_info["applied"] is True and op._props["halo"][2].rowmap is not None
 
 
+def test_round5_kernels_fuzz_random_shapes(cuda):
+    """40 random (rows, width, hops) shapes through the kernels added in round 5: every NAFS prefix from one pass against the
+    oracle per prefix (widths up to 512: every lane layout; 1 ... 40 hops: more than the fused kernel holds), the ensemble
+    combinations, the max / min backward against torch's autograd of stack(...).max(0) with ties and NaNs planted, the padded row
+    gather from aligned matrices, column views and duplicate / negative indices"""
+    rng = np.random.default_rng(20260928)
+    for case in range(40):
+        n = int(rng.integers(1, 300))
+        d = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 33, 64, 65, 100, 127, 128, 129, 147, 255, 256, 257, 300, 511, 512]))
+        H = int(rng.integers(1, 41))
+        host = [np.ascontiguousarray((rng.standard_normal((n, d)) * (1.0 - 0.01 * h)).astype(np.float32)) for h in range(H)]
+        if n > 2:
+            host[0][1] = 0.0                                             # a zero row: cosine 0 with every hop
+        feats = []
+        for x in host:
+            t = dev.alloc_rows(n, d, cuda)
+            t.copy_(torch.from_numpy(x))
+            feats.append(t)
+        tag = (case, n, d, H)
+        emit = sorted(set(int(v) for v in rng.integers(0, H, size=min(H, 4))) | {H - 1})
+        outs = dev.nafs_prefix(feats, emit)
+        for h, o in zip(emit, outs):
+            assert oracle.parity_ok(o.cpu().numpy(), oracle.agg_over_smooth_distance(host[:h + 1]), 2e-5, rowwise=False), (tag, h)
+            if o.stride(0) != d and n > 1:
+                assert float(dev.padded_parent(o)[:, d:].abs().max()) == 0.0, (tag, h)
+        acc = [o.clone() * 0.25 for o in outs]
+        accp = []
+        for a in acc:                                                   # the combinations need padded outputs of their own
+            t = dev.alloc_rows(n, d, cuda)
+            t.copy_(a)
+            accp.append(t)
+        dev.nafs_prefix(feats, emit, outs=accp, combine=dev.NAFS_MAX, outs_padded=True)
+        assert all(torch.equal(a, torch.maximum(o * 0.25, o)) for a, o in zip(accp, outs)), tag
+        # max / min backward
+        Hs = min(H, 9)
+        base = [h_.copy() for h_ in host[:Hs]]
+        if Hs > 2 and n > 3:
+            base[2][0] = base[0][0]                                      # ties
+            base[1][3, 0] = np.nan                                       # NaN
+        g = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(cuda)
+        for op, name in ((_lib.SGL_REDUCE_MAX, "max"), (_lib.SGL_REDUCE_MIN, "min")):
+            leaves = [torch.from_numpy(b.copy()).to(cuda).requires_grad_(True) for b in base]
+            dev.hop_reduce_grad(op, leaves).backward(g)
+            ref = [torch.from_numpy(b.copy()).to(cuda).requires_grad_(True) for b in base]
+            getattr(torch.stack(ref, 0), name)(0)[0].backward(g)
+            assert all(torch.equal(a.grad, b.grad) for a, b in zip(leaves, ref)), (tag, name)
+        # row gather: padded source, a column view of a wider matrix, duplicate and negative indices
+        m = int(rng.integers(1, 2 * n + 2))
+        idx = torch.from_numpy(rng.integers(-n, n, size=m)).to(cuda)
+        assert torch.equal(dev.gather_rows(feats[0], idx), feats[0][idx]), tag
+        wide = torch.from_numpy(rng.standard_normal((n, d + 9)).astype(np.float32)).to(cuda)
+        got = dev.gather_rows(wide[:, 4:4 + d], idx)
+        assert torch.equal(got, wide[:, 4:4 + d][idx]), tag
+        if got.stride(0) != d and m > 1:
+            assert float(dev.padded_parent(got)[:, d:].abs().max()) == 0.0, tag
+
+
 def test_aggregators_fuzz_random_shapes(cuda):
     """40 random (rows, width, hops, padded / dense) shapes through every aggregator kernel family: the bit-exact ones
     (sum / max / concat) against numpy bit for bit, the weighted ones and their gradients within tolerance -- widths 1..600
