@@ -276,6 +276,12 @@ int sgl_norm_block_scale(int64_t n, int64_t row0, const int64_t *d_rowptr, const
  * sweep at one r pays the degree factors and the gather of d_right_global once. */
 int sgl_norm_block_mix(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, const double *d_hat64,
                        double alpha, float *d_out_val, double *d_out_val64, void *stream);
+/* The same mix without any row lookup: d_diag[i] = the position of row i's diagonal entry in the block's CSR (sgl_norm_block_diag_positions,
+ * once per block; -1 if a row has none), then a flat stream (1 - alpha) A_hat over the nnz values and alpha added at the n diagonal
+ * positions.  Same roundings as sgl_norm_block_mix: bit-identical.  d_hat64 16-byte aligned. */
+int sgl_norm_block_diag_positions(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, int64_t *d_diag, void *stream);
+int sgl_norm_block_mix_at(int64_t nnz, int64_t n, const double *d_hat64, const int64_t *d_diag, double alpha, float *d_out_val,
+                          double *d_out_val64, void *stream);
 /* d_left = deg^(r-1), d_right = deg^(-r), inf -> 0 (utils.py:79-84) with the device's pow(): within 1 ulp(fp64) of the host
  * libm route described above -- for callers that want 1e-5 parity, not bit-identity, and no host round trip. */
 int sgl_norm_degree_powers(int64_t n, const double *d_deg, double r, double *d_left, double *d_right, void *stream);

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "sgl_norm_block_scale": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                      c_void_p, c_void_p, c_void_p]),
     "sgl_norm_block_mix": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_block_diag_positions": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sgl_norm_block_mix_at": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "sgl_norm_degree_powers": (c_int, [c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "sgl_coo_to_csr": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(c_int64), c_void_p]),

@@ -377,6 +377,54 @@ __global__ __launch_bounds__(256) void block_scale_kernel(const int64_t *__restr
     }
 }
 
+// Position of the diagonal entry of every row of T' = T + I (it always exists): one binary search per row, once per block.  With it the
+// PPR mix of an alpha sweep needs no row lookup at all: a flat stream (1 - alpha) * A_hat over all non-zeros, then alpha added at the
+// n diagonal positions -- the same two roundings per element as block_scale_kernel<true>, bit-identical.
+__global__ __launch_bounds__(256) void block_diagpos_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                            const int64_t n, const int64_t row0, int64_t *__restrict__ diag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t me = (int32_t)(row0 + i);
+    int64_t lo = rowptr[i], hi = rowptr[i + 1];
+    const int64_t end = hi;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col[mid] < me) lo = mid + 1; else hi = mid;
+    }
+    diag[i] = (lo < end && col[lo] == me) ? lo : -1;
+}
+
+__global__ __launch_bounds__(256) void mix_flat_kernel(const double *__restrict__ hat, const int64_t m, const double one_minus_alpha,
+                                                       float *__restrict__ o_val, double *__restrict__ o_val64) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; p < m; p += stride) {
+        if (p + 1 < m) {                                  // two doubles = one 16-byte load per lane (hat is 16-byte aligned)
+            using d2 = double __attribute__((ext_vector_type(2)));
+            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(hat + p));
+            const double a = __dmul_rn(one_minus_alpha, v[0]), b = __dmul_rn(one_minus_alpha, v[1]);
+            using f2 = float __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store((f2){(float)a, (float)b}, reinterpret_cast<f2 *>(o_val + p));
+            if (o_val64) __builtin_nontemporal_store((d2){a, b}, reinterpret_cast<d2 *>(o_val64 + p));
+        } else {
+            const double a = __dmul_rn(one_minus_alpha, hat[p]);
+            o_val[p] = (float)a;
+            if (o_val64) o_val64[p] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_diag_kernel(const double *__restrict__ hat, const int64_t *__restrict__ diag, const int64_t n,
+                                                       const double one_minus_alpha, const double alpha, float *__restrict__ o_val,
+                                                       double *__restrict__ o_val64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t p = diag[i];
+    if (p < 0) return;
+    const double x = __dadd_rn(__dmul_rn(one_minus_alpha, hat[p]), alpha);
+    o_val[p] = (float)x;
+    if (o_val64) o_val64[p] = x;
+}
+
 struct Tmp {
     std::vector<void *> ptrs;
     ~Tmp() {
@@ -394,6 +442,7 @@ struct Tmp {
 };
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+inline bool aligned_to16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
@@ -641,6 +690,37 @@ SGL_EXPORT int sgl_norm_block_mix(int64_t n, int64_t row0, const int64_t *d_rowp
     hipLaunchKernelGGL(block_scale_kernel<true>, dim3((unsigned)((n + kScaleRows - 1) / kScaleRows)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, d_hat64,
                        (const double *)nullptr, (const double *)nullptr, n, row0, 1, 1.0 - alpha, alpha, d_out_val, d_out_val64);
     SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_norm_block_diag_positions(int64_t n, int64_t row0, const int64_t *d_rowptr, const int32_t *d_col, int64_t *d_diag,
+                                             void *stream) {
+    SGL_REQUIRE(n >= 0 && row0 >= 0 && row0 + n < INT32_MAX, "sgl_norm_block_diag_positions: bad sizes");
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_rowptr && d_col && d_diag, "sgl_norm_block_diag_positions: NULL arrays");
+    hipLaunchKernelGGL(block_diagpos_kernel, dim3(blocks_for(n)), dim3(256), 0, sgl::as_stream(stream), d_rowptr, d_col, n, row0, d_diag);
+    SGL_HIP_CHECK(hipGetLastError());
+    return SGL_OK;
+}
+
+// sgl_norm_block_mix with the diagonal positions known (sgl_norm_block_diag_positions, once per block): a flat stream + n fix-ups
+SGL_EXPORT int sgl_norm_block_mix_at(int64_t nnz, int64_t n, const double *d_hat64, const int64_t *d_diag, double alpha, float *d_out_val,
+                                     double *d_out_val64, void *stream) {
+    SGL_REQUIRE(nnz >= 0 && n >= 0, "sgl_norm_block_mix_at: bad sizes");
+    if (nnz == 0) return SGL_OK;
+    SGL_REQUIRE(d_hat64 && d_diag && d_out_val, "sgl_norm_block_mix_at: NULL arrays");
+    SGL_REQUIRE(aligned_to16(d_hat64) && (reinterpret_cast<uintptr_t>(d_out_val) & 7u) == 0 && (!d_out_val64 || aligned_to16(d_out_val64)),
+                "sgl_norm_block_mix_at: arrays must be 16-byte (fp64) / 8-byte (fp32) aligned");
+    hipStream_t st = sgl::as_stream(stream);
+    const int64_t pairs = (nnz + 1) / 2;
+    const unsigned grid = (unsigned)std::min<int64_t>((pairs + 255) / 256, (int64_t)1 << 22);
+    hipLaunchKernelGGL(mix_flat_kernel, dim3(grid), dim3(256), 0, st, d_hat64, nnz, 1.0 - alpha, d_out_val, d_out_val64);
+    SGL_HIP_CHECK(hipGetLastError());
+    if (n > 0) {
+        hipLaunchKernelGGL(mix_diag_kernel, dim3(blocks_for(n)), dim3(256), 0, st, d_hat64, d_diag, n, 1.0 - alpha, alpha, d_out_val,
+                           d_out_val64);
+        SGL_HIP_CHECK(hipGetLastError());
+    }
     return SGL_OK;
 }
 

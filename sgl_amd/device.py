@@ -585,8 +585,14 @@ def _scaled_values(owner, n_loc, row0, rowptr, col, t64, deg, r, alpha, return_f
         # pass says what it does
         o_val.copy_(hat64)
         return (o_val, hat64.clone()) if return_fp64 else (o_val,)
-    check(lib().sgl_norm_block_mix(n_loc, row0, ptr(rowptr), ptr(col), ptr(hat64), float(alpha), ptr(o_val),
-                                   ptr(o_v64) if return_fp64 else None, current_stream_ptr()), "sgl_norm_block_mix")
+    diag = getattr(owner, "_diag", None)
+    if diag is None:                                  # where each row's diagonal entry sits: once per prepared block
+        diag = torch.empty(n_loc, dtype=torch.int64, device=dev)
+        check(lib().sgl_norm_block_diag_positions(n_loc, row0, ptr(rowptr), ptr(col), ptr(diag), current_stream_ptr()),
+              "sgl_norm_block_diag_positions")
+        owner._diag = diag
+    check(lib().sgl_norm_block_mix_at(m, n_loc, ptr(hat64), ptr(diag), float(alpha), ptr(o_val), ptr(o_v64) if return_fp64 else None,
+                                      current_stream_ptr()), "sgl_norm_block_mix_at")
     return (o_val, o_v64) if return_fp64 else (o_val,)
 
 
