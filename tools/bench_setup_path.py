@@ -51,6 +51,20 @@ def main():
     print(f"SETUP scale   one (r, alpha)                        ms={t:8.2f}", flush=True)
     t, _ = wall(lambda: dev.normalize_adj(a_ptr, a_col, a_val, n, 0.5, None, host_pow=False), reps=2)
     print(f"SETUP general directed pipeline (transpose by sort) ms={t:8.2f}", flush=True)
+    # the same matrix with ONE value changed: not symmetric any more -> the directed route of PreparedAdjacency (the transpose is
+    # built once, then every (r, alpha) is the single pass of the symmetric case)
+    d_val = a_val.clone()
+    d_val[12345] = 3.0
+    t, dprep = wall(lambda: dev.PreparedAdjacency(a_ptr, a_col, d_val, n))
+    print(f"SETUP directed: prepare (A + I, degrees, symmetry check) ms={t:8.2f}  symmetric={dprep.symmetric}", flush=True)
+    t, _ = wall(lambda: dprep.normalize(0.5, None))
+    print(f"SETUP directed: first (r, alpha) incl. the transposition ms={t:8.2f}", flush=True)
+    t, _ = wall(lambda: dprep.normalize(0.3, None))
+    print(f"SETUP directed: every further r                      ms={t:8.2f}", flush=True)
+    t, _ = wall(lambda: dprep.normalize(0.3, 0.2))
+    t2, _ = wall(lambda: dprep.normalize(0.3, 0.1))
+    print(f"SETUP directed: PPR at a new r / a further alpha     ms={t:8.2f} / {t2:.2f}", flush=True)
+    del dprep, d_val
     t, csr = wall(lambda: dev.DeviceCSR(rowptr, col, val, (n, n)))
     print(f"SETUP plan    sgl_csr_create                        ms={t:8.2f}", flush=True)
     x = synthetic.features_torch(n, wl["d"], seed=0, device=device)
