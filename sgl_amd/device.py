@@ -531,7 +531,7 @@ class PreparedAdjacency:
         transposition; otherwise the transpose is built once (one stable sort) and every (r, alpha) is the same single pass over it.
         Both are bit-identical to the reference's scipy result (host_pow=True; see degree_powers).  PPR requests keep the fp64
         Laplacian of their r: the next alpha of a sweep is one stream over it (sgl_norm_block_mix), bit-identical to the one-pass form."""
-        dev = self.rowptr.device
+        dev = self.src[0].device
         with torch.cuda.device(dev):
             if self.symmetric:
                 vals = _scaled_values(self, self.n, 0, self.rowptr, self.col, self.t64, self.deg, r, alpha, return_fp64, host_pow)
