@@ -323,6 +323,14 @@ int sgl_hop_rowdot_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx
 int64_t sgl_hop_wsum1d_bwd_scratch(int n_hops);
 int sgl_hop_wsum1d_bwd_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, const float *d_dout,
                            int64_t lddo, float *d_dw, float *d_scratch, int64_t n, int64_t d, void *stream);
+/* out_k = sum_j W[k, j] X_j (k < n_out <= 64, j < n_in <= 16): a small dense matrix applied across the hop dimension in ONE pass --
+ * every input element is read once for all outputs.  d_w: [n_out, ldw] floats on the device; zero weights are skipped (hops that do
+ * not enter an output cannot contaminate it with NaN / Inf); each sum is one fma chain in j order.  Outputs must not alias inputs.
+ * Use: the hop matrices of PprGraphOp(K, r, alpha) are polynomials in the Laplacian's of the same r,
+ *   ((1 - alpha) A_hat + alpha I)^k X = sum_j C(k, j) (1 - alpha)^j alpha^(k - j) A_hat^j X   (ppr_graph_op.py:20, base_op.py:29-35),
+ * so every alpha of a sweep follows from ONE propagation chain (sgl_amd.operators.graph_op.ppr_hops_from_laplacian). */
+int sgl_hop_lincomb_f32(int n_in, const float *const *h_x, const int64_t *h_ldx, int n_out, float *const *h_out, const int64_t *h_ldo,
+                        const float *d_w, int64_t ldw, int64_t n, int64_t d, void *stream);
 /* Backward of MaxMessageOp / MinMessageOp (torch.stack(hops).max(0)[0], max_message_op.py:12): dX_h = dOut where hop h is the one
  * torch selects for the element -- the first NaN if there is one, otherwise the first hop attaining the extremum -- and 0 elsewhere.
  * op = SGL_REDUCE_MAX or SGL_REDUCE_MIN; h_dx[h] may be NULL for hops that need no gradient. */

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "sgl_reorder_community": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, POINTER(c_int64), c_void_p]),
     "sgl_hop_reduce_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                    c_void_p]),
+    "sgl_hop_lincomb_f32": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "sgl_hop_select_bwd_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                        c_void_p]),
     "sgl_hop_wsum2d_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,

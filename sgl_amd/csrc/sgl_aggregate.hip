@@ -144,6 +144,41 @@ __global__ __launch_bounds__(256) void hop_select_bwd_kernel(const Hops hx, cons
     }
 }
 
+// out_k = sum_j W[k, j] X_j for k < n_out: a small dense matrix applied across the HOP dimension, every input element read once for
+// all outputs.  What it is for: the hop matrices of PprGraphOp(K, r, alpha) are polynomials in the Laplacian's --
+// ((1 - alpha) A_hat + alpha I)^k X = sum_j C(k, j) (1 - alpha)^j alpha^(k - j) A_hat^j X -- so every alpha of a PaSca-style sweep
+// (sgl/search/search_config.py:14-15) follows from ONE propagation chain by a triangular mix of its K + 1 hop matrices: K + 1
+// streams read, K written, instead of K more SpMMs.  Zero weights are skipped (a NaN / Inf in a hop that does not enter an output
+// must not reach it); the sum is one fma chain in j order.
+template <int NIN, int VEC>
+__global__ __launch_bounds__(256) void hop_lincomb_kernel(const Hops hx, const int n_in, const HopsOut outs, const int n_out,
+                                                          const float *__restrict__ w, const int ldw, const int64_t n, const int d) {
+    using V = typename Vt<VEC>::type;
+    const int dv = d / VEC;
+    const int64_t total = n * (int64_t)dv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / dv;
+        const int col = (int)(i - row * dv) * VEC;
+        V x[NIN];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j)
+            if (j < n_in) x[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(hx.p[j] + row * hx.ld[j] + col));
+        for (int k = 0; k < n_out; ++k) {
+            V acc;
+            if constexpr (VEC == 1) acc = 0.f; else acc = (V){0.f, 0.f, 0.f, 0.f};
+            const float *wk = w + (int64_t)k * ldw;
+#pragma unroll
+            for (int j = 0; j < NIN; ++j)
+                if (j < n_in) {
+                    const float wkj = wk[j];                    // uniform: a scalar load
+                    if (wkj != 0.f) acc = vmap2<VEC>(acc, x[j], [wkj](float a, float b) { return __builtin_fmaf(wkj, b, a); });
+                }
+            __builtin_nontemporal_store(acc, reinterpret_cast<V *>(outs.p[k] + row * outs.ld[k] + col));
+        }
+    }
+}
+
 // out[n,k] = sum_h W[n,h] X_h[n,k]; FMA: fma chain from 0 (bmm-like); !FMA: rounded product then add (NAFS loop)
 template <int VEC, bool FMA>
 __global__ __launch_bounds__(256) void hop_wsum2d_kernel(const Hops hx, const int n_hops, const float *__restrict__ w,
@@ -1934,6 +1969,45 @@ SGL_EXPORT int sgl_hop_select_bwd_f32(int op, int n_hops, const float *const *h_
         else hipLaunchKernelGGL((hop_select_bwd_kernel<false, 1>), dim3(grid), dim3(256), 0, st, hx, n_hops, d_gout, ldg, dx, n, (int)d);
     }
     SGL_LAUNCH_CHECK("sgl_hop_select_bwd_f32");
+    return SGL_OK;
+}
+
+SGL_EXPORT int sgl_hop_lincomb_f32(int n_in, const float *const *h_x, const int64_t *h_ldx, int n_out, float *const *h_out,
+                                   const int64_t *h_ldo, const float *d_w, int64_t ldw, int64_t n, int64_t d, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_hop_lincomb_f32: bad sizes");
+    SGL_REQUIRE(n_in >= 1 && n_in <= 16, "sgl_hop_lincomb_f32: between 1 and 16 input matrices (n_in=%d)", n_in);
+    SGL_REQUIRE(n_out >= 1 && n_out <= SGL_MAX_HOPS, "sgl_hop_lincomb_f32: between 1 and %d outputs", SGL_MAX_HOPS);
+    SGL_REQUIRE(d_w && ldw >= n_in && ldw < INT32_MAX, "sgl_hop_lincomb_f32: the [n_out, ldw] weight matrix is required (ldw >= n_in)");
+    SGL_REQUIRE(h_out && h_ldo, "sgl_hop_lincomb_f32: NULL output arrays");
+    Hops hx;
+    bool vec4 = (d % 4 == 0);
+    int rc = fill_hops(hx, n_in, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    HopsOut outs;
+    for (int k = 0; k < SGL_MAX_HOPS; ++k) {
+        outs.p[k] = k < n_out ? h_out[k] : nullptr;
+        outs.ld[k] = k < n_out ? h_ldo[k] : 0;
+        if (k < n_out) {
+            SGL_REQUIRE(outs.p[k] && outs.ld[k] >= d && aligned_to(outs.p[k], 4), "sgl_hop_lincomb_f32: bad output %d", k);
+            if (outs.ld[k] % 4 != 0 || !aligned_to(outs.p[k], 16)) vec4 = false;
+            for (int j = 0; j < n_in; ++j)
+                SGL_REQUIRE(outs.p[k] != hx.p[j], "sgl_hop_lincomb_f32: output %d aliases input %d", k, j);
+        }
+    }
+    if (n == 0 || d == 0) return SGL_OK;
+    hipStream_t st = sgl::as_stream(stream);
+    const int grid = stream_grid(n * (d / (vec4 ? 4 : 1)));
+#define SGL_LC(NI)                                                                                                                 \
+    do {                                                                                                                           \
+        if (vec4) hipLaunchKernelGGL((hop_lincomb_kernel<NI, 4>), dim3(grid), dim3(256), 0, st, hx, n_in, outs, n_out, d_w, (int)ldw, n, (int)d); \
+        else hipLaunchKernelGGL((hop_lincomb_kernel<NI, 1>), dim3(grid), dim3(256), 0, st, hx, n_in, outs, n_out, d_w, (int)ldw, n, (int)d);      \
+    } while (0)
+    if (n_in <= 4) SGL_LC(4);
+    else if (n_in <= 8) SGL_LC(8);
+    else if (n_in <= 12) SGL_LC(12);
+    else SGL_LC(16);
+#undef SGL_LC
+    SGL_LAUNCH_CHECK("sgl_hop_lincomb_f32");
     return SGL_OK;
 }
 

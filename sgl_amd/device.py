@@ -17,7 +17,7 @@ __all__ = [
     "DeviceCSR", "default_long_row_nnz", "ChainGraph", "round_up", "row_pitch", "expected_lines", "alloc_rows", "upload_rows", "normalize_adj",
     "normalize_block", "degree_powers", "PreparedAdjacency", "PreparedBlock",
     "placed_empty", "MEM_MODES",
-    "hop_reduce", "hop_concat", "hop_reduce_grad", "hop_concat_grad", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
+    "hop_reduce", "hop_concat", "hop_reduce_grad", "hop_concat_grad", "hop_lincomb", "hop_wsum1d", "hop_wsum2d", "hop_scores", "hop_scores2", "hop_gate", "gate_fusable", "nafs_aggregate", "nafs_prefix",
     "gather_rows",
 ]
 
@@ -760,6 +760,37 @@ def hop_concat(feats):
         check(lib().sgl_hop_concat_padded_f32(H, ptrs, lds, ptr(out), _ld(out), own_pad(out), n, d, current_stream_ptr()),
               "sgl_hop_concat_padded_f32")
     return out
+
+
+def hop_lincomb(feats, weights, outs=None):
+    """out_k = sum_j weights[k, j] * feats[j]: a small dense matrix applied across the hop dimension, every input element read once
+    for all outputs (sgl_hop_lincomb_f32; zero weights skipped, one fma chain in j order per output).  feats: up to 16 [n, d] hop
+    matrices; weights: [n_out, len(feats)] (host or device); outs: optional list of n_out [n, d] matrices (not aliasing the inputs).
+    Returns the list of outputs."""
+    _check_hops(feats)
+    n, d = feats[0].shape
+    w = torch.as_tensor(weights, dtype=torch.float32).to(feats[0].device).contiguous()
+    if w.dim() != 2 or w.shape[1] != len(feats):
+        raise ValueError("weights must be [n_out, len(feats)]")
+    n_out = int(w.shape[0])
+    if len(feats) > 16:
+        raise ValueError("hop_lincomb takes at most 16 input matrices per call")
+    if outs is None:
+        outs = [alloc_rows(n, d, feats[0].device) for _ in range(n_out)]
+    if len(outs) != n_out or any(tuple(o.shape) != (n, d) for o in outs):
+        raise ValueError("one [n, d] output per row of weights")
+    # stream whole pitches when every matrix shares one (pad columns: zeros in, zeros out)
+    wide_in, _, dw = _widened(list(feats) + list(outs), outs[0])
+    if dw != d:
+        f_w, o_w = wide_in[:len(feats)], wide_in[len(feats):]
+    else:
+        f_w, o_w = list(feats), list(outs)
+    ptrs, lds = _lib.hop_arrays(f_w)
+    optrs, olds = _lib.hop_arrays(o_w)
+    with torch.cuda.device(feats[0].device):
+        check(lib().sgl_hop_lincomb_f32(len(feats), ptrs, lds, n_out, optrs, olds, ptr(w), int(w.stride(0)), n, dw, current_stream_ptr()),
+              "sgl_hop_lincomb_f32")
+    return outs
 
 
 class _ReduceGrad(torch.autograd.Function):

@@ -1880,6 +1880,67 @@ def test_config5_ppr_and_laplacian_k10_match_reference_goldens(goldens, cuda):
     print(f"config 5 propagation: {n_exact}/{n_total} golden hop matrices (PPR / Laplacian, k = 10) reproduced bit-for-bit")
 
 
+def test_ppr_hops_are_a_mix_of_the_laplacian_chain(goldens, cuda):
+    """BASELINE config 5's sweep over graph operators with ONE propagation: the hop matrices of PprGraphOp(K, r, alpha) are
+    polynomials in the Laplacian's, sum_j C(k, j) (1 - alpha)^j alpha^(k - j) A_hat^j X, so every alpha follows from the
+    LaplacianGraphOp(K, r) chain by a triangular mix (sgl_hop_lincomb_f32) -- against the hop matrices the REFERENCE recorded for its
+    own PPR chains (G9: k = 10 and k = 1, three graphs incl. the directed one, d = 16 and 128) at 1e-5, and against this library's
+    own chain; the mixing kernel itself with arbitrary weights, zero weights skipping a NaN hop, 1 ... 16 inputs, odd widths"""
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp, ppr_hops_from_laplacian
+    g9 = goldens.npz("g9_config5")
+    meta = goldens.json("g9_config5")["prop"]
+    chains = {}
+    n_checked = 0
+    for key, m in meta.items():
+        if m["kind"] != "ppr":
+            continue
+        g = goldens.graph(m["graph"])
+        x = hash_matrix(g.shape[0], m["d"], seed=m["seed"])
+        ck = (m["graph"], m["d"], m["seed"], m["r"], m["K"])
+        if ck not in chains:
+            chains[ck] = LaplacianGraphOp(m["K"], r=m["r"]).propagate(g, x)              # ONE chain per (graph, features, r, K)
+        mixed = PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"]).propagate_from_laplacian(chains[ck])
+        assert len(mixed) == m["K"] + 1 and mixed[0] is chains[ck][0]
+        for h in m["keep"]:
+            rep = oracle.parity_report(mixed[h].cpu().numpy(), g9[f"prop|{key}|h{h}"], TOL)
+            assert rep["ok"], (key, h, rep)
+            n_checked += 1
+        own = PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"]).propagate(g, x)
+        assert all(oracle.parity_ok(a_.cpu().numpy(), b_.cpu().numpy(), TOL) for a_, b_ in zip(mixed, own)), key
+    assert n_checked >= 20 and len(chains) < n_checked
+    with pytest.raises(ValueError):
+        PprGraphOp(3, alpha=0.2, strict_order=True).propagate_from_laplacian(chains[ck][:4])
+    with pytest.raises(ValueError):
+        PprGraphOp(3, alpha=0.2).propagate_from_laplacian(chains[ck][:3])
+    # more than 16 matrices: the deeper hops are one weighted sum each
+    g = goldens.graph("pl256")
+    x = hash_matrix(256, 20, seed=2)
+    deep = ppr_hops_from_laplacian(LaplacianGraphOp(20, r=0.5).propagate(g, x), 0.25)
+    own = PprGraphOp(20, r=0.5, alpha=0.25).propagate(g, x)
+    assert len(deep) == 21 and all(oracle.parity_ok(a_.cpu().numpy(), b_.cpu().numpy(), TOL) for a_, b_ in zip(deep, own))
+    # the kernel: out_k = sum_j W[k, j] X_j
+    rng = np.random.default_rng(11)
+    for n, d, n_in, n_out in ((300, 100, 11, 10), (257, 147, 6, 3), (64, 3, 16, 16), (1, 37, 1, 2), (500, 128, 4, 20)):
+        host = [rng.standard_normal((n, d)).astype(np.float32) for _ in range(n_in)]
+        feats = [dev.upload_rows(h_, cuda) for h_ in host]
+        w = rng.standard_normal((n_out, n_in)).astype(np.float32)
+        w[rng.random((n_out, n_in)) < 0.3] = 0.0
+        outs = dev.hop_lincomb(feats, w)
+        want = np.einsum("kj,jnd->knd", w.astype(np.float64), np.stack(host).astype(np.float64))
+        scale = np.einsum("kj,jnd->knd", np.abs(w).astype(np.float64), np.abs(np.stack(host)).astype(np.float64))
+        for k in range(n_out):
+            assert np.abs(outs[k].cpu().numpy() - want[k]).max() <= 1e-6 * max(scale[k].max(), 1e-30), (n, d, n_in, k)
+            if outs[k].stride(0) != d and n > 1:
+                assert float(dev.padded_parent(outs[k])[:, d:].abs().max()) == 0.0
+    feats[1].fill_(float("nan"))                                          # a hop with weight 0 cannot contaminate an output
+    w = np.zeros((2, 4), np.float32)
+    w[0, 0], w[1, 1], w[1, 2] = 1.0, 2.0, 1.0
+    o = dev.hop_lincomb(feats, w)
+    assert torch.equal(o[0], feats[0]) and bool(torch.isnan(o[1]).all())
+    with pytest.raises(_lib.SglHipError):
+        dev.hop_lincomb(feats, w, outs=[feats[0], dev.alloc_rows(500, 128, cuda)])       # an output aliasing an input
+
+
 @pytest.mark.parametrize("d", [16, 128])
 def test_config5_every_message_op_over_eleven_hops(goldens, cuda, d):
     """every op of sgl/operators/message_op/ over H = 11 hop matrices (k = 10) against reference-generated goldens: stateless ops

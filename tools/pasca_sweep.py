@@ -56,6 +56,18 @@ def main():
         nnz = col.numel()
         print(f"SWEEP graph_op={name:16s} normalise_ms={t_norm:8.2f} propagate_k10_ms={t_prop:8.2f} "
               f"({nnz * d * K / (t_prop * 1e-3) / 1e12:.3f}e12 edge*feat/s)", flush=True)
+        if alpha is None:
+            lap_feats = feats
+        else:
+            # the same K + 1 hop matrices WITHOUT propagating: ((1 - a) A_hat + a I)^k X is a polynomial in A_hat, i.e. a triangular
+            # mix of the Laplacian chain's hop matrices (ppr_hops_from_laplacian -> sgl_hop_lincomb_f32: 11 streams read, 10 written)
+            from sgl_amd.operators.graph_op import ppr_hops_from_laplacian
+            t_mix, mixed = timed(lambda: ppr_hops_from_laplacian(lap_feats, alpha))
+            err = max(float((m_ - f_).abs().max() / f_.abs().max()) for m_, f_ in zip(mixed, feats))
+            by = (2 * K + 1) * n * d * 4
+            print(f"SWEEP   the same hop matrices mixed from the Laplacian chain: ms={t_mix:8.2f} ({by / (t_mix * 1e-3) / 1e12:.2f} TB/s; "
+                  f"max |mixed - propagated| / max |propagated| = {err:.1e}) instead of {t_prop:8.2f}", flush=True)
+            del mixed
         if alpha not in (None, 0.1):
             continue
         ops = [("last", M.LastMessageOp()), ("concat", M.ConcatMessageOp(0, K + 1)), ("mean", M.MeanMessageOp(0, K + 1)),
@@ -71,7 +83,9 @@ def main():
             with torch.no_grad():
                 t, _ = timed(lambda: op.aggregate(feats))
             print(f"SWEEP   msg_op={oname:24s} aggregate_ms={t:8.3f}", flush=True)
-        del feats, csr
+        del csr
+        if alpha is not None:
+            del feats
         # the same aggregates with the aggregation folded into the propagation (round 2): sum / mean / simple_weighted ride
         # on the SpMM epilogue (GraphOp.propagate_reduce), concat is the layout the hops are produced in (slab_hops)
         adj = DeviceAdjacency(a_ptr, a_col, a_val, (n, n))
