@@ -108,6 +108,16 @@ def main():
         alg = nnz * d * 4 + nnz * 8 + (hi - lo + 1) * 4 + (hi - lo) * d * 4
         print(f"S4 graph_op={name:16s} normalise_block_ms={t_norm:8.2f} propagate_k10_ms={t_prop:8.1f} per_hop_ms={t_prop / K:7.2f} "
               f"({nnz * d * K / (t_prop * 1e-3) / 1e12:.3f}e12 edge*feat/s per GPU, roofline frac {alg / (t_prop / K * 1e-3) / 8e12:.3f})", flush=True)
+        if alpha is None:
+            # every PPR alpha of the sweep WITHOUT propagating again: a triangular mix of this chain's 11 hop shards (row-wise: no
+            # communication in the row-sharded job either) -- 11 streams read, 10 written per alpha
+            from sgl_amd.operators.graph_op import ppr_hops_from_laplacian
+            for a_ in (0.1, 0.2, 0.3):
+                t_mix, mixed = timed(lambda: ppr_hops_from_laplacian(hops, a_), reps=1)
+                by = (2 * K + 1) * (hi - lo) * d * 4
+                print(f"S4   ppr a={a_}: the k = 10 hop shards mixed from the Laplacian chain in {t_mix:7.2f} ms ({by / (t_mix * 1e-3) / 1e12:.2f} TB/s) "
+                      f"instead of a propagation ({t_prop:.1f} ms + the exchange of 10 hops)", flush=True)
+                del mixed
         if alpha not in (None, 0.1):
             del csr
             continue
