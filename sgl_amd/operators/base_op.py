@@ -56,8 +56,10 @@ def prepared_graph(adj, device=None):
     operators over the same matrix object with unchanged contents (AdjIdentity: object identity + full content hashes / device
     buffer versions).  Holds the device copy of A and A + I in fp64 (24 bytes per non-zero) for the two most recently used
     graphs while they are alive; clear_graph_cache() releases them, sgl_amd.config.cache_prepared = False turns the sharing off."""
+    from .. import _lib
     from ..io import DeviceAdjacency
     from .utils import canonical_csr
+    _lib.require_gpu()                                   # no GPU: the library's own error, loudly (there is no CPU path)
     device = torch.device(device or "cuda")
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())     # "cuda" and "cuda:0" are the same place
