@@ -27,6 +27,10 @@ reorder       None -> the rows of A_hat are processed in the caller's node order
               Pays on graphs that HAVE communities their ids do not show (-32 % per hop on the shuffled community graph of
               tools/bench_reorder.py), neutral on the random benchmark graph; "auto" -> run the ordering and keep it only
               when it makes the graph measurably more local than its own ids do (sgl_amd.reorder.plan_rowmap)
+share_hops    True -> GraphOp.propagate consults a process-wide store of device-resident hop lists keyed on the CONTENT of adjacency +
+              features + operator parameters (sgl_amd/hopcache.py: SharedHops): a fresh operator per search trial re-uses the chain an
+              earlier one produced, and a PprGraphOp is served from the LaplacianGraphOp chain of the same r by a mixing pass (not under
+              strict_order).  The lists are shared: treat hop matrices as read-only.  share_hops_gb bounds the store (default 64)
 trace         True (SGL_AMD_TRACE=1) -> every GraphOp.propagate() records the wall time of its phases (adjacency: fingerprint /
               upload / normalise / plan; features: upload; hops: the k SpMMs; output: download or cache), synchronising at the phase
               ends, in `op.last_trace` and prints them on stderr -- the reference times its whole preprocess() with time.time() and a
@@ -51,6 +55,8 @@ strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
 strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
 cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
 cache_prepared = _env_bool("SGL_AMD_CACHE_PREPARED", True)
+share_hops = _env_bool("SGL_AMD_SHARE_HOPS", False)
+share_hops_gb = float(os.environ.get("SGL_AMD_SHARE_HOPS_GB", "64"))
 _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()
 fuse_aggregate = "auto" if _fa == "auto" else _fa in ("1", "true", "yes", "on")
 slab_hops = _env_bool("SGL_AMD_SLAB_HOPS", False)

@@ -124,3 +124,97 @@ class HopCache:
         with open(tmp, "w") as f:
             json.dump({"n_hops": len(hops), "shape": list(hops[0].shape)}, f)
         os.replace(tmp, os.path.join(d, "meta.json"))        # written last: a directory without it is a miss
+
+
+class SharedHops:
+    """Device-resident hop matrices shared between operators, process-wide (sgl_amd.config.share_hops; off by default).
+
+    A PaSca-style search builds a fresh model per trial -- 4 graph operators x 11 message operators, every trial re-propagating the
+    same graph and features (sgl/search/search_models.py:19-46, search_config.py:14-15).  With the store on, GraphOp.propagate
+    (i) returns the hop list a previous operator with the same parameters produced for the same CONTENT of adjacency and features
+    (content_key: full hashes, so an edited matrix or feature array is another key), and (ii) serves a PprGraphOp from the
+    LaplacianGraphOp chain of the same r by the triangular mix of sgl_amd.operators.graph_op.ppr_hops_from_laplacian -- propagating
+    that Laplacian chain first when nobody has (GraphOp._propagate_or_cache), so that a search pays k SpMMs per (graph, features, r)
+    and one mixing pass per alpha (not under strict_order: the mix equals the chain to float32 rounding, not bit for bit).  The lists are SHARED: callers must treat hop
+    matrices as read-only (the library's aggregators do).  Least recently used entries leave when the byte budget
+    (config.share_hops_gb) is exceeded."""
+
+    def __init__(self):
+        self.entries = {}          # (graph_feat_key, cls, r, alpha, strict) -> [hops, last_use]
+        self.clock = 0
+        self._memo = {}            # id(device object) -> (weakref, buffer marks, content key)
+        self.stats = {"hits": 0, "derived": 0, "misses": 0, "evicted": 0}
+
+    def _content(self, obj):
+        """content_key, remembered for DEVICE objects while they are alive and untouched (same buffers, same torch version counters:
+        every in-place torch write bumps them) -- the digest of a gigabyte on the device costs about as much as a hop"""
+        import weakref
+        if torch.is_tensor(obj) and obj.is_cuda:
+            mark = (obj.data_ptr(), obj._version, tuple(obj.shape), tuple(obj.stride()), str(obj.dtype))
+        elif hasattr(obj, "rowptr") and hasattr(obj, "val") and torch.is_tensor(obj.val):
+            mark = tuple((t.data_ptr(), t._version, t.numel()) for t in (obj.rowptr, obj.col, obj.val)) + (tuple(obj.shape),)
+        else:
+            return content_key(obj)                                   # host arrays: hashed in full every time
+        held = self._memo.get(id(obj))
+        if held is not None and held[0]() is obj and held[1] == mark:
+            return held[2]
+        key = content_key(obj)
+        try:
+            self._memo[id(obj)] = (weakref.ref(obj), mark, key)
+        except TypeError:
+            return key
+        if len(self._memo) > 64:
+            for q in [q for q, v in self._memo.items() if v[0]() is None]:
+                del self._memo[q]
+        return key
+
+    def data_key(self, adj, feature):
+        import hashlib
+        return hashlib.blake2b(repr((_lib.lib().sgl_version(), self._content(adj), self._content(feature))).encode(), digest_size=16).hexdigest()
+
+    def _touch(self, k):
+        self.clock += 1
+        self.entries[k][1] = self.clock
+        return list(self.entries[k][0])
+
+    def lookup(self, dkey, cls, r, alpha, K, strict):
+        """exact entry with at least K hops, else (PPR, not strict) a Laplacian chain of the same r to mix from, else None"""
+        for s_ in ((True,) if strict else (False, True)):          # a strict-order chain also answers a relaxed request
+            k = (dkey, cls, float(r), None if alpha is None else float(alpha), s_)
+            if k in self.entries and len(self.entries[k][0]) >= K + 1:
+                self.stats["hits"] += 1
+                return self._touch(k)[:K + 1]
+        if alpha is not None and not strict:
+            for s_ in (False, True):
+                lk = (dkey, "LaplacianGraphOp", float(r), None, s_)
+                if lk in self.entries and len(self.entries[lk][0]) >= K + 1:
+                    from .operators.graph_op import ppr_hops_from_laplacian
+                    hops = ppr_hops_from_laplacian(self._touch(lk)[:K + 1], alpha)
+                    self.stats["derived"] += 1
+                    self.store(dkey, cls, r, alpha, strict, hops)
+                    return list(hops)
+        self.stats["misses"] += 1
+        return None
+
+    def store(self, dkey, cls, r, alpha, strict, hops):
+        from . import config
+        k = (dkey, cls, float(r), None if alpha is None else float(alpha), bool(strict))
+        self.clock += 1
+        self.entries[k] = [list(hops), self.clock]
+        budget = float(getattr(config, "share_hops_gb", 64.0)) * (1 << 30)
+
+        def nbytes(e):
+            return sum(h.numel() * h.element_size() for h in e[0][1:])
+        while len(self.entries) > 1 and sum(nbytes(e) for e in self.entries.values()) > budget:
+            old = min(self.entries, key=lambda q: self.entries[q][1])
+            if old == k:
+                break
+            del self.entries[old]
+            self.stats["evicted"] += 1
+
+    def clear(self):
+        self.entries.clear()
+        self._memo.clear()
+
+
+SHARED = SharedHops()

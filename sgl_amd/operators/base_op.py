@@ -282,6 +282,27 @@ class GraphOp:
 
     def _propagate_or_cache(self, adj, feature):
         cache_dir = self._opt("hop_cache_dir")
+        if config.share_hops and not cache_dir and not self._opt("host_output") and not self._opt("slab_hops"):
+            # process-wide store of device-resident hop lists (hopcache.SharedHops): the reference's exceptions first, then the lookup
+            self._checked(adj, feature)
+            from ..hopcache import SHARED
+            r, alpha = self._norm_params()
+            dkey = SHARED.data_key(adj, feature)
+            strict = bool(self._opt("strict_order"))
+            hops = SHARED.lookup(dkey, type(self).__name__, r, alpha, self._prop_steps, strict)
+            if hops is None and alpha is not None and not strict:
+                # a PPR chain nobody has yet: propagate the LAPLACIAN chain of this r once (same k SpMMs) and mix -- every other
+                # alpha of the search then costs the mixing pass only (hopcache.SharedHops.lookup, ppr_hops_from_laplacian)
+                from .graph_op import LaplacianGraphOp
+                LaplacianGraphOp(self._prop_steps, r=r, device=self._device, strict_types=self._strict_types, strict_order=False,
+                                 cache_adj=self._cache_adj, reorder=self._reorder).propagate(adj, feature)
+                hops = SHARED.lookup(dkey, type(self).__name__, r, alpha, self._prop_steps, strict)
+            if hops is None:
+                hops = self._propagate(adj, feature, checked=True)
+                if torch.is_tensor(feature) and hops[0].data_ptr() == feature.data_ptr():
+                    hops[0] = hops[0].clone()                  # the caller may edit its tensor later; the stored hop 0 must not follow
+                SHARED.store(dkey, type(self).__name__, r, alpha, strict, hops)
+            return hops
         if not cache_dir or self._opt("host_output") or self._opt("slab_hops"):
             return self._propagate(adj, feature)
         # on-disk hop cache (sgl_amd/hopcache.py): the reference's exceptions first, then content-keyed lookup

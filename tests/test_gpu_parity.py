@@ -2841,3 +2841,101 @@ def test_papers_shard_million_sampled_rows_vs_oracle(cuda):
         rep = oracle.parity_report(got[~whole], ref[~whole], TOL, scale=scale[~whole])
         assert rep["ok"], rep
     print(f"papers shard: {int(whole.sum())} sampled rows bit-equal, {int((~whole).sum())} split rows within {TOL}")
+
+
+@pytest.mark.gpu
+def test_shared_hop_store_serves_fresh_operators(goldens, cuda):
+    """BASELINE config 5 (a fresh model per search trial, sgl/search/search_models.py:19-46): with sgl_amd.config.share_hops a fresh
+    GraphOp returns the chain an earlier operator produced for the same CONTENT of (adjacency, features), a PprGraphOp is mixed
+    from the LaplacianGraphOp chain of the same r (against the reference's recorded PPR hops, 1e-5), a strict_order request never
+    takes a mixed chain, edited features are another key, and the byte budget evicts the least recently used chain"""
+    from sgl_amd import config, hopcache
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    g9 = goldens.npz("g9_config5")
+    meta = goldens.json("g9_config5")["prop"]
+    store = hopcache.SHARED
+    store.clear()
+    before = dict(store.stats)
+    old = (config.share_hops, config.share_hops_gb)
+    config.share_hops = True
+    try:
+        done = set()
+        n_checked = 0
+        for key, m in meta.items():
+            if m["kind"] != "ppr":
+                continue
+            g = goldens.graph(m["graph"])
+            x = hash_matrix(g.shape[0], m["d"], seed=m["seed"])
+            ck = (m["graph"], m["d"], m["seed"], m["r"], m["K"])
+            if ck not in done:
+                lap = LaplacianGraphOp(m["K"], r=m["r"]).propagate(g, x)
+                again = LaplacianGraphOp(m["K"], r=m["r"]).propagate(g.copy(), x.copy())      # other objects, same content
+                assert all(a_ is b_ for a_, b_ in zip(lap, again))
+                done.add(ck)
+            d0 = store.stats["derived"]
+            hops = PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"]).propagate(g, x)
+            assert store.stats["derived"] == d0 + 1, key
+            for h in m["keep"]:
+                rep = oracle.parity_report(hops[h].cpu().numpy(), g9[f"prop|{key}|h{h}"], TOL)
+                assert rep["ok"], (key, h, rep)
+                n_checked += 1
+            h0 = store.stats["hits"]
+            assert all(a_ is b_ for a_, b_ in zip(hops, PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"]).propagate(g, x)))
+            assert store.stats["hits"] == h0 + 1
+        assert n_checked >= 15
+        # strict order: propagates itself (bit-identical to the strict chain without the store), and then answers relaxed requests
+        g = goldens.graph("pl256")
+        x = hash_matrix(256, 24, seed=5)
+        LaplacianGraphOp(4, r=0.5).propagate(g, x)
+        d0, m0 = store.stats["derived"], store.stats["misses"]
+        strict = PprGraphOp(4, r=0.5, alpha=0.3, strict_order=True).propagate(g, x)
+        assert store.stats["derived"] == d0 and store.stats["misses"] == m0 + 1
+        config.share_hops = False
+        plain = PprGraphOp(4, r=0.5, alpha=0.3, strict_order=True).propagate(g, x)
+        config.share_hops = True
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(strict, plain))
+        relaxed = PprGraphOp(4, r=0.5, alpha=0.3).propagate(g, x)
+        assert all(a_ is b_ for a_, b_ in zip(relaxed, strict))
+        # a shorter chain is a prefix of a longer one; a longer one is a miss
+        assert len(LaplacianGraphOp(2, r=0.5).propagate(g, x)) == 3
+        m0 = store.stats["misses"]
+        assert len(LaplacianGraphOp(6, r=0.5).propagate(g, x)) == 7 and store.stats["misses"] == m0 + 1
+        # edited content is another key -- features and matrix -- and a device tensor passed as features is not aliased by the store
+        x2 = x.copy()
+        x2[17, 3] += 1.0
+        m0 = store.stats["misses"]
+        LaplacianGraphOp(4, r=0.5).propagate(g, x2)
+        g2 = g.copy().tolil()
+        g2[3, 200] = 1.0
+        g2[200, 3] = 1.0
+        LaplacianGraphOp(4, r=0.5).propagate(g2.tocsr(), x)
+        assert store.stats["misses"] == m0 + 2
+        xt = torch.from_numpy(hash_matrix(256, 8, seed=9)).to(cuda)
+        kept = LaplacianGraphOp(2, r=0.5).propagate(g, xt)
+        want0 = kept[0].clone()
+        xt.add_(1.0)
+        assert torch.equal(kept[0], want0)
+        # the reference's exceptions come before the lookup
+        with pytest.raises(TypeError):
+            LaplacianGraphOp(2).propagate(g.toarray(), x)
+        # a PPR request nobody can serve propagates the Laplacian chain of its r ONCE; every alpha is then a mixing pass
+        store.clear()
+        d0 = store.stats["derived"]
+        got = {a_: PprGraphOp(3, r=0.4, alpha=a_).propagate(g, x) for a_ in (0.1, 0.2, 0.35)}
+        assert store.stats["derived"] == d0 + 3 and sum(1 for k_ in store.entries if k_[1] == "LaplacianGraphOp") == 1
+        config.share_hops = False
+        for a_, hops in got.items():
+            own = PprGraphOp(3, r=0.4, alpha=a_).propagate(g, x)
+            assert all(oracle.parity_ok(p_.cpu().numpy(), q_.cpu().numpy(), TOL) for p_, q_ in zip(hops, own)), a_
+        config.share_hops = True
+        # the budget: one chain of 4 hops x 256 x 24 floats is 98 KB; a 150 KB budget keeps one
+        store.clear()
+        config.share_hops_gb = 150e3 / (1 << 30)
+        e0 = store.stats["evicted"]
+        LaplacianGraphOp(4, r=0.5).propagate(g, x)
+        LaplacianGraphOp(4, r=0.3).propagate(g, x)
+        assert store.stats["evicted"] == e0 + 1 and len(store.entries) == 1
+    finally:
+        config.share_hops, config.share_hops_gb = old
+        store.clear()
+    assert store.stats["hits"] > before["hits"]
