@@ -10,6 +10,7 @@ where RANK / WORLD_SIZE are already in the environment and nothing here runs.  W
   * relays rank 0's stdout (the ONE JSON line) and sends every other rank's stdout to stderr;
   * ends the job when any rank fails (the others would wait in a collective for ever), prints a `value: null` line naming
     the rank, its exit code and the tail of its stderr, and exits non-zero;
+  * ends a job that is still running after SGL_BENCH_LAUNCH_TIMEOUT seconds (default 5400) the same way;
   * never prints more than one line to stdout.
 """
 import json
@@ -66,6 +67,8 @@ def self_launch(args, argv, script, metric, grace_s=15.0, poll_s=0.2):
         procs.append(subprocess.Popen([sys.executable, script, *argv], env=env, stdout=out0 if r == 0 else err, stderr=err,
                                       start_new_session=True))
     failed = None
+    limit_s = float(os.environ.get("SGL_BENCH_LAUNCH_TIMEOUT", "5400"))     # a job that hangs without any rank dying
+    t_start = time.monotonic()
     try:
         while True:
             codes = [p.poll() for p in procs]
@@ -77,6 +80,10 @@ def self_launch(args, argv, script, metric, grace_s=15.0, poll_s=0.2):
                 break
             if failed is not None and time.monotonic() - t_fail > grace_s:
                 break                                  # the survivors are waiting for the dead rank: end them
+            if failed is None and time.monotonic() - t_start > limit_s:
+                alive = [r for r, c in enumerate(codes) if c is None]
+                failed = (alive[0], f"none: still running after {limit_s:.0f} s (SGL_BENCH_LAUNCH_TIMEOUT)")
+                break
             time.sleep(poll_s)
     finally:
         for p in procs:

@@ -199,6 +199,8 @@ def redistribute_rows(block, order, group=None):
     from .. import _lib
     rank, world = _world(group)
     n, dev = block.n, block.device
+    if not block.rowptr.is_cuda:
+        raise RuntimeError("redistribute_rows builds the new block with the library's device kernel: the row block must live on a GPU")
     deg = (block.rowptr[1:] - block.rowptr[:-1]).to(torch.int64)
     old_bounds = _gather_ints([block.lo, block.hi], group)
     ob = [int(v) for v in old_bounds[:, 0]] + [int(old_bounds[-1, 1])]

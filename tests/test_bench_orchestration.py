@@ -465,6 +465,8 @@ elif mode == "rank1_dies":
     if rank == 1:
         sys.stderr.write("boom on rank 1\n"); sys.exit(7)
     time.sleep(120)                                          # the survivors wait in a "collective" for ever
+elif mode == "hangs":
+    time.sleep(120)                                          # nobody dies, nobody finishes
 elif mode == "dies_after_line":
     if rank == 0:
         print(json.dumps({"value": 2.0, "n_gpus": world}), flush=True)
@@ -509,6 +511,17 @@ def test_self_launch_ends_the_job_when_a_rank_dies(tmp_path):
     j = json.loads(lines[0])
     assert rc != 0 and len(lines) == 1 and j["value"] is None and j["n_gpus"] == 3
     assert "rank 1 exited with code 7" in j["error"] and "boom on rank 1" in j["stderr_tail"]
+
+
+def test_self_launch_ends_a_job_that_hangs(tmp_path, monkeypatch):
+    """no rank dies and none finishes: after SGL_BENCH_LAUNCH_TIMEOUT the parent ends the ranks and prints ONE null line"""
+    import time
+    monkeypatch.setenv("SGL_BENCH_LAUNCH_TIMEOUT", "2")
+    t0 = time.monotonic()
+    rc, lines = _launch(tmp_path, "hangs", n=2)
+    assert time.monotonic() - t0 < 60
+    j = json.loads(lines[0])
+    assert rc != 0 and len(lines) == 1 and j["value"] is None and "still running after 2 s" in j["error"]
 
 
 def test_self_launch_keeps_a_measured_line_when_a_rank_fails_later(tmp_path):
