@@ -1330,11 +1330,8 @@ def scatter_rows(x, src, dst, out):
     return out
 
 
-def gather_rows(x, idx, out=None):
-    """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60).  `out`: optional
-    preallocated [len(idx), d] destination (the pack step of the need-aware exchange re-uses one send buffer per hop)."""
-    _check_mat(x, "x")
-    n_rows, d = x.shape
+def _device_index(idx, n_rows, device):
+    """row indices of any kind as a flat int64 tensor on `device`"""
     if not (torch.is_tensor(idx) and idx.is_cuda):
         # host indices (range / list / ndarray / CPU tensor): validate here, like torch's CPU indexing does
         if isinstance(idx, range):
@@ -1347,7 +1344,32 @@ def gather_rows(x, idx, out=None):
             raise IndexError("index out of range in row gather")
         idx = torch.from_numpy(np.ascontiguousarray(host))
     # device indices are range-checked inside the kernel (it traps on a bad index): no host round trip
-    idx = idx.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
+    return idx.to(device=device, dtype=torch.int64).contiguous().view(-1)
+
+
+def gather_hops(feats, idx):
+    """[x[idx] for x in feats]: the training feed of the learnable aggregators, `[feat[idx].to(device) for feat in
+    self._processed_feat_list]` (sgl/models/base_model.py:58-60), with the indices validated and uploaded ONCE for all hop
+    matrices.  Host indices (what the reference's tasks pass) are where the time of the hop-by-hop form goes: 200 000 rows of 4 /
+    6 / 11 hop matrices 0.46 / 0.78 / 1.25 ms -> 0.24 / 0.42 / 0.55 ms; with device indices the H queued launches already run back
+    to back, and one launch over all hops (measured: profiles/r05_gather_hops.txt) is no faster."""
+    feats = list(feats)
+    if not feats:
+        return []
+    _check_mat(feats[0], "feat_list[0]")
+    same_rows = all(torch.is_tensor(f) and f.is_cuda and f.dim() == 2 and f.shape[0] == feats[0].shape[0] and f.device == feats[0].device
+                    for f in feats)
+    if same_rows:
+        idx = _device_index(idx, feats[0].shape[0], feats[0].device)
+    return [gather_rows(x, idx) for x in feats]
+
+
+def gather_rows(x, idx, out=None):
+    """x[idx] on device (BaseSGAPModel.forward's per-step row gather, models/base_model.py:58,60).  `out`: optional
+    preallocated [len(idx), d] destination (the pack step of the need-aware exchange re-uses one send buffer per hop)."""
+    _check_mat(x, "x")
+    n_rows, d = x.shape
+    idx = _device_index(idx, n_rows, x.device)
     own_out = out is None
     if out is None:
         # (the pad columns of our own output are written by the kernel below whenever the vector path applies: no separate zero fill)

@@ -33,6 +33,18 @@ def take_rows(feat, idx, device):
     return feat[idx].to(device)
 
 
+def take_hop_rows(feats, idx, device):
+    """[take_rows(feat, idx, device) for feat in feats] (reference: models/base_model.py:58-60) -- for device-resident hop matrices
+    the indices are validated and uploaded once for all of them (device.gather_hops)"""
+    feats = list(feats)
+    same = len(feats) > 1 and all(torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32 and f.dim() == 2
+                                  and f.shape[0] == feats[0].shape[0] and f.device == feats[0].device for f in feats)
+    contiguous_range = isinstance(idx, range) and idx.step == 1
+    if not same or contiguous_range:
+        return [take_rows(feat, idx, device) for feat in feats]
+    return [t.to(device) for t in dev.gather_hops(feats, idx)]
+
+
 class BaseSGAPModel(nn.Module):
     def __init__(self, prop_steps, feat_dim, output_dim):
         super(BaseSGAPModel, self).__init__()
@@ -153,7 +165,7 @@ class BaseSGAPModel(nn.Module):
 
     def forward(self, idx, device):
         if self._pre_msg_learnable:
-            hop_rows = [take_rows(feat, idx, device) for feat in self._processed_feat_list]
+            hop_rows = take_hop_rows(self._processed_feat_list, idx, device)
             processed_feature = self._pre_msg_op.aggregate(hop_rows)
         else:
             feat = self._processed_feature

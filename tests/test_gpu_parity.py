@@ -2939,3 +2939,57 @@ def test_shared_hop_store_serves_fresh_operators(goldens, cuda):
         config.share_hops, config.share_hops_gb = old
         store.clear()
     assert store.stats["hits"] > before["hits"]
+
+
+@pytest.mark.gpu
+def test_gather_hops_uploads_the_indices_once(cuda, monkeypatch):
+    """the training feed `[feat[idx].to(device) for feat in feat_list]` (sgl/models/base_model.py:58-60): bit-identical to torch
+    indexing for every index kind torch takes, widths with and without a padded pitch, 1 ... 11 hops, mixed pitches; the indices are
+    validated and uploaded ONCE for all hop matrices, also through a learnable model's forward"""
+    rng = np.random.default_rng(3)
+    for n, d, H in ((5000, 100, 4), (3000, 147, 6), (2048, 128, 11), (700, 3, 2), (900, 500, 3), (64, 37, 1)):
+        host = [rng.standard_normal((n, d)).astype(np.float32) for _ in range(H)]
+        feats = [dev.upload_rows(h_, cuda) for h_ in host]
+        picks = rng.integers(-n, n, size=1501)
+        mask = rng.random(n) < 0.3
+        for idx in (picks, picks.tolist(), torch.from_numpy(picks), torch.from_numpy(picks).to(cuda), mask, torch.from_numpy(mask), range(3, n, 7)):
+            got = dev.gather_hops(feats, idx)
+            ref_idx = list(idx) if isinstance(idx, range) else (idx.cpu() if torch.is_tensor(idx) else idx)
+            for h in range(H):
+                want = torch.from_numpy(host[h])[ref_idx]
+                assert got[h].shape == want.shape and torch.equal(got[h].cpu(), want), (n, d, H, type(idx), h)
+                assert not bool(dev.padded_parent(got[h])[:, d:].abs().sum())            # the outputs' own padding is zeros
+    with pytest.raises(IndexError):
+        dev.gather_hops(feats, [0, n])
+    assert [tuple(t.shape) for t in dev.gather_hops(feats, [])] == [(0, 37)] and dev.gather_hops([], [1]) == []
+    # a column view (pitch not the allocator's) and a packed odd-width matrix next to padded ones
+    wide = dev.upload_rows(rng.standard_normal((800, 110)).astype(np.float32), cuda)
+    packed = torch.from_numpy(rng.standard_normal((800, 50)).astype(np.float32)).to(cuda)
+    mixed = [wide[:, 3:53], packed, dev.upload_rows(packed.cpu().numpy(), cuda)]
+    ids = rng.integers(0, 800, size=333)
+    for g_, f_ in zip(dev.gather_hops(mixed, ids), mixed):
+        assert torch.equal(g_, f_[torch.from_numpy(ids).to(cuda)])
+    # one upload: host indices become a device tensor once, whatever the number of hop matrices -- also through the model
+    calls = []
+    real = dev._device_index
+
+    def counting(idx, n_rows, device):
+        if not (torch.is_tensor(idx) and idx.is_cuda):
+            calls.append(type(idx).__name__)
+        return real(idx, n_rows, device)
+    monkeypatch.setattr(dev, "_device_index", counting)
+    dev.gather_hops(feats * 5, [1, 2, 3])
+    assert len(calls) == 1
+    from sgl_amd.models.homo import GAMLP
+    g = long_row_graph(1500, seed=4)
+    g = (abs(g) + abs(g).T).tocsr().astype(np.float32)
+    x = hash_matrix(1500, 24, seed=1)
+    model = GAMLP(3, 24, 5, 16, 2).to(cuda).eval()
+    model.preprocess(g, x)
+    batch = rng.integers(0, 1500, size=400)
+    with torch.no_grad():
+        want = model._pre_msg_op.aggregate([f_[torch.from_numpy(batch).to(cuda)] for f_ in model._processed_feat_list])
+        del calls[:]
+        out = model.model_forward(batch, cuda)
+        assert len(calls) == 1 and len(model._processed_feat_list) == 4
+        assert torch.equal(out, model._base_model(want))

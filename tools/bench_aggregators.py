@@ -90,6 +90,13 @@ def main():
         rep("nafs (weights + sum)", timeit(lambda: dev.nafs_aggregate(feats)), (H + 1) * nb)
         idx = torch.randint(0, n, (200_000,), device=device)
         rep("gather_rows 200k", timeit(lambda: dev.gather_rows(feats[0], idx)), 2 * 200_000 * d * 4)
+        # the training feed of the learnable aggregators: the same 200k rows of EVERY hop matrix (models/base_model.py:58-60) -- hop by hop
+        # against ONE index upload for all of them (device.gather_hops), device and host (numpy int64) indices
+        idx_host = idx.cpu().numpy()
+        rep(f"gather 200k rows of {H} hops, hop by hop", timeit(lambda: [dev.gather_rows(f_, idx) for f_ in feats]), 2 * H * 200_000 * d * 4)
+        rep(f"gather 200k rows of {H} hops, gather_hops", timeit(lambda: dev.gather_hops(feats, idx)), 2 * H * 200_000 * d * 4)
+        rep(f"  ... host indices, hop by hop", timeit(lambda: [dev.gather_rows(f_, idx_host) for f_ in feats]), 2 * H * 200_000 * d * 4)
+        rep(f"  ... host indices, gather_hops", timeit(lambda: dev.gather_hops(feats, idx_host)), 2 * H * 200_000 * d * 4)
         # the kernel alone: ten launches queued back to back into a preallocated output (the host's ~20 us per call -- allocation,
         # index checks, ctypes -- hide behind the GPU as they do in a training loop; a single timed call includes them)
         gout_ = dev.alloc_rows(200_000, d, device)
