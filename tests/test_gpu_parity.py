@@ -2915,6 +2915,23 @@ def test_shared_hop_store_serves_fresh_operators(goldens, cuda):
         want0 = kept[0].clone()
         xt.add_(1.0)
         assert torch.equal(kept[0], want0)
+        # device inputs: their content key is remembered while buffers and version counters stand, recomputed after an in-place write
+        from sgl_amd.io import DeviceAdjacency
+        da = DeviceAdjacency(torch.from_numpy(g.indptr.astype(np.int64)).to(cuda), torch.from_numpy(g.indices.astype(np.int32)).to(cuda),
+                             torch.from_numpy(g.data.astype(np.float32)).to(cuda), g.shape)
+        m0, h0 = store.stats["misses"], store.stats["hits"]
+        edited = LaplacianGraphOp(2, r=0.5).propagate(da, xt)                 # xt was edited: not the chain kept above
+        assert store.stats["misses"] == m0 + 1 and not torch.equal(edited[1], kept[1])
+        again = LaplacianGraphOp(2, r=0.5).propagate(da, xt)
+        assert store.stats["hits"] == h0 + 1 and all(a_ is b_ for a_, b_ in zip(again, edited))
+        config.share_hops = False
+        plain = LaplacianGraphOp(2, r=0.5).propagate(da, xt)
+        config.share_hops = True
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, edited))
+        da.val.mul_(2.0)                                                      # the matrix edited in place: another key
+        m0 = store.stats["misses"]
+        LaplacianGraphOp(2, r=0.5).propagate(da, xt)
+        assert store.stats["misses"] == m0 + 1
         # the reference's exceptions come before the lookup
         with pytest.raises(TypeError):
             LaplacianGraphOp(2).propagate(g.toarray(), x)
