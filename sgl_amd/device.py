@@ -806,7 +806,7 @@ class _ReduceGrad(torch.autograd.Function):
         if op == _lib.SGL_REDUCE_MEAN and divisor is not None and divisor != len(feats_d):
             # the reference divides by (end - start) whatever the slice held (mean_message_op.py:10)
             out = hop_reduce(_lib.SGL_REDUCE_SUM, feats_d)
-            out = out / torch.tensor(float(divisor), device=out.device)
+            out = out / torch.full((), float(divisor), dtype=torch.float32, device=out.device)   # (a fill kernel, not an upload: capturable)
         else:
             out = hop_reduce(op, feats_d)
         if op in (_lib.SGL_REDUCE_MAX, _lib.SGL_REDUCE_MIN):
@@ -822,7 +822,7 @@ class _ReduceGrad(torch.autograd.Function):
             return (None, None, *[gout if nd else None for nd in need])
         if ctx.op == _lib.SGL_REDUCE_MEAN:
             div = float(ctx.divisor if ctx.divisor is not None else H)
-            g = gout / torch.tensor(div, device=gout.device)         # DivBackward: a true division (0-dim device divisor)
+            g = gout / torch.full((), div, dtype=torch.float32, device=gout.device)         # DivBackward: a true division (0-dim device divisor)
             return (None, None, *[g if nd else None for nd in need])
         feats = list(ctx.saved_tensors)
         n, d = feats[0].shape
@@ -1237,7 +1237,9 @@ class _HopScores2(torch.autograd.Function):
             du = torch.zeros((L, d), dtype=torch.float32, device=gp.device)
             ref = [j for j in range(L) if (mask >> j) & 1]
             if ref:                                                    # X_j^T ga for every hop of the reference part: one pass
-                du[ref] = hop_colsum([feats[j] for j in ref], ga, shared=True)
+                part = hop_colsum([feats[j] for j in ref], ga, shared=True)
+                for k_, j in enumerate(ref):                           # (row by row: a list index would be uploaded, which a
+                    du[j] = part[k_]                                   # HIP-graph capture of the training step does not allow)
             du = du.view_as(u)
         dxs = []
         uu = u.view(L, d)

@@ -73,7 +73,7 @@ def _reduction(kind, doc):
                 total = reduce_hops("sum", hops)
                 # a 0-dim DEVICE divisor: torch's GPU kernel turns division by a host scalar into a multiplication by
                 # its reciprocal, which is not the reference's (CPU) true division in the last bit
-                return total / torch.tensor(float(self._end - self._start), device=total.device)
+                return total / torch.full((), float(self._end - self._start), dtype=torch.float32, device=total.device)
             return reduce_hops(kind, hops)
 
         def fused_spec(self, n_hops):
