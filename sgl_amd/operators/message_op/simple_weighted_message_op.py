@@ -63,4 +63,14 @@ class SimpleWeightedMessageOp(MessageOp):
         return {"kind": "wsum", "start": self._start, "end": self._end, "weights": w}
 
     def _combine(self, feat_list):
-        return one_dim_weighted_add(feat_list[self._start:self._end], weight_list=self.weights(len(feat_list)))
+        w = self.weights(len(feat_list))
+        first = feat_list[0] if len(feat_list) else None
+        if torch.is_tensor(first) and first.is_cuda and not w.is_cuda:
+            # the fixed weights live on the device after their first use: no upload per call (and the call records into a HIP graph)
+            key = (len(feat_list), first.device, w.data_ptr() if self._kind != "alpha" else None, w._version if self._kind != "alpha" else None)
+            held = getattr(self, "_w_dev", None)
+            if held is None or held[0] != key:
+                held = (key, w.to(first.device))
+                self._w_dev = held
+            w = held[1]
+        return one_dim_weighted_add(feat_list[self._start:self._end], weight_list=w)

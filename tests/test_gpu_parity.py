@@ -3027,7 +3027,9 @@ def test_training_steps_record_into_a_hip_graph(goldens, cuda):
            "gate": mo.LearnableWeightedMessageOp(0, H, "gate", d), "ori_ref": mo.LearnableWeightedMessageOp(0, H, "ori_ref", d),
            "jk": mo.LearnableWeightedMessageOp(0, H, "jk", H - 1, d), "iterate": mo.IterateLearnableWeightedMessageOp(0, H, "recursive", d),
            "sum": mo.SumMessageOp(0, H), "mean": mo.MeanMessageOp(0, H + 1), "max": mo.MaxMessageOp(0, H), "min": mo.MinMessageOp(1, H),
-           "concat": mo.ConcatMessageOp(0, H), "last": mo.LastMessageOp(), "over_smooth": mo.OverSmoothDistanceWeightedOp()}
+           "concat": mo.ConcatMessageOp(0, H), "last": mo.LastMessageOp(), "over_smooth": mo.OverSmoothDistanceWeightedOp(),
+           "simple_weighted": mo.SimpleWeightedMessageOp(0, H, "alpha", 0.85),
+           "hand_crafted": mo.SimpleWeightedMessageOp(1, H, "hand_crafted", [0.5, 0.25, 0.125])}
     for name, op in ops.items():
         torch.manual_seed(1)
         op = op.to(cuda)
