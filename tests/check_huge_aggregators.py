@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Robustness check at the largest shape of the contract: the aggregators over WHOLE ogbn-papers100M-sized hop matrices
 ([111 059 956, 128] = 14.2 G elements = 57 GB each) on one GPU -- more elements than a 32-bit index, more threads than one HIP
-launch carries.  Checks sampled rows against numpy and that kernels which cannot take the shape say so."""
+launch carries.  Checks sampled rows against numpy / the oracle and that kernels which cannot take the shape say so.
+(A script, not a collected test: it needs 120 GB of HBM and a minute.  It lives under tests/ because it uses the oracle.)"""
 import os
 import sys
 

@@ -305,6 +305,29 @@ def test_sgl_amd_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_only_the_checkers_use_the_oracle():
+    """outside tests/: __graft_entry__.smoke() and the bench's cpu_baseline leg (benchlib/engine.py) -- nothing under tools/,
+    examples/ or bench.py itself imports the oracle or loads its library"""
+    allowed = {os.path.join(ROOT, "benchlib", "engine.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    bad = []
+    for top in ("tools", "examples", "benchlib", "sgl_amd"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                path = os.path.join(dp, f)
+                if f.endswith(".py") and path not in allowed:
+                    src = open(path).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
+                        bad.append(path)
+    for f in ("bench.py",):
+        src = open(os.path.join(ROOT, f)).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+            bad.append(f)
+    assert not bad, bad
+    # and where it is allowed it is the baseline / the checker, inside one function each
+    eng = open(os.path.join(ROOT, "benchlib", "engine.py")).read()
+    assert len(re.findall(r"^\s*import oracle\b", eng, flags=re.M)) == 1 and "def cpu_baseline" in eng
+
+
 # ---- row sharding arithmetic -----------------------------------------------------------------------------
 def test_balanced_bounds_properties():
     rng = np.random.default_rng(0)
