@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- SGAP pre-propagation SpMM throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S1_products] [--no-cpu-baseline] [--no-papers]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S1_products] [--no-cpu-baseline] [--no-papers] [--no-extras]
 
 One "step" = one full k-hop propagation (prop_steps SpMM launches, k=3 for the headline config
 "SGC prop_steps=3 on ogbn-products") over a synthetic ogbn-products-shaped graph (Chung-Lu, N=2 449 029,
@@ -26,6 +26,11 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
   roofline     : dominant kernel (spmm_kernel) algorithmic bytes per launch / measured launch time vs 8 TB/s HBM
   cpu_baseline : the reference's own CPU kernel (oracle/_ref, else the C restatement) timed on this node's host
                  cores on a bounded row sample of the same workload (N=1 only)
+  sections     : (S1 single-GPU runs only, unless --no-extras) the BASELINE configs the headline does not cover, each with workload,
+                 ms, roofline, validated: S0_pubmed (config 1, compared with the CPU oracle and timed beside the reference CPU
+                 path), S2_gamlp (config 3), S4_products (config 5's operator sweep + a torch-CPU aggregator baseline),
+                 S1_community (the products degree law WITH communities: reorder=None vs "auto"), S4_papers_shard (configs 4/5 as
+                 one rank of the 8-GPU job: NAFS + every MessageOp); benchlib/extras.py
   papers100M   : (S1 runs only, unless --no-papers) the same measurement on an ogbn-papers100M-shaped graph
                  (111 M nodes, ~3.34 G non-zeros, d=128, k=3, rows generated per rank on device), row-sharded in
                  storage over the same N ranks: value, ms per hop, roofline fraction.  Bounded by a watchdog: if it
@@ -96,6 +101,15 @@ def parse_args(argv=None):
                     help="watchdog (s) of the papers100M-shaped section: on overrun the JSON line is printed without it")
     ap.add_argument("--papers-k", type=int, default=3,
                     help="prop_steps of the papers100M-shaped section (3 by default; 10 = BASELINE config 5's hop count: raise --papers-budget)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary sections of an S1_products single-GPU run (BASELINE configs 1, 3, 5 and the per-rank share "
+                         "of 4/5: benchlib/extras.py); with --no-papers and --no-cpu-baseline this is the fast path")
+    ap.add_argument("--extras-budget", type=float, default=float(os.environ.get("SGL_BENCH_EXTRAS_BUDGET", "240")),
+                    help="seconds the secondary sections may take in total: a section that would start later is recorded as skipped")
+    ap.add_argument("--detail-out", default=os.environ.get("SGL_BENCH_DETAIL_OUT"),
+                    help="file that receives the secondary sections in full (the line carries their short form)")
+    ap.add_argument("--extras-scale", choices=("full", "small"), default=os.environ.get("SGL_BENCH_EXTRAS_SCALE", "full"),
+                    help="small = the same sections on graphs that finish in seconds (tests)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dup2", action="store_true",
                     help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "
@@ -289,52 +303,86 @@ def run(args, engine_cls=None, workloads=None, emit=print):
             cpu = {"value": None, "unit": "edge\u00b7featdim/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         out["cpu_baseline"] = cpu
 
-    # ---- secondary: the papers100M-shaped graph on the same ranks (bounded; never endangers the line above) -------------
+    # ---- secondary sections (bounded; never endanger the line above): the other BASELINE configs on this GPU (benchlib/extras.py)
+    # and the papers100M-shaped graph on the same ranks.  ONE watchdog covers them all: on overrun the line goes out with whatever
+    # sections are finished.
     def emit_line():
         if rank == 0:
             quiet.unmute()
-            emit(json.dumps(out))
+            try:
+                text = json.dumps(out)
+            except RuntimeError:                  # the watchdog thread caught the main thread adding a key: once more
+                time.sleep(0.2)
+                text = json.dumps(out)
+            emit(text)
             sys.stdout.flush()
             if emit is print:
                 quiet.mute()                  # late library chatter (communicator teardown) goes to stderr too
 
-    want_papers = (args.workload == "S1_products" and not args.no_papers and not args.force_sharded
-                   and hasattr(engine, "hashed_block"))
-    if want_papers:
+    small = getattr(args, "extras_scale", "full") == "small" and args.workload == "S1_small"      # (tests: the same sections, in seconds)
+    can_extra = (args.workload == "S1_products" or small) and not args.force_sharded and hasattr(engine, "hashed_block")
+    want_papers = can_extra and not small and not args.no_papers
+    want_extras = can_extra and world == 1 and not getattr(args, "no_extras", False)
+    if want_papers or want_extras:
         import threading
-        _phase("papers100M section")
+        _phase("secondary sections")
         done = threading.Event()
+        budget = (args.papers_budget if want_papers else 0) + (args.extras_budget + 60 if want_extras else 0)
 
         def overrun():
             if done.is_set():
                 return
             if rank == 0:
-                out["papers100M"] = {"skipped": f"did not finish within the {args.papers_budget:.0f} s watchdog"}
+                out["secondary_sections_watchdog"] = f"not finished within {budget:.0f} s (phase {_PHASE[0]!r}): the line is printed with what was done"
+                if want_papers and "papers100M" not in out:
+                    out["papers100M"] = {"skipped": f"did not finish within the {budget:.0f} s watchdog"}
                 emit_line()
             os._exit(0)                       # a collective may be stuck: do not wait for it
 
-        timer = threading.Timer(args.papers_budget, overrun)
+        timer = threading.Timer(budget, overrun)
         timer.daemon = True
         timer.start()
-        try:
-            exchange = info.get("exchange", "p2p")
-            args.col_chunks_chosen = getattr(job, "col_chunks_chosen", None)
-            del step, halves
-            job.drop_full()
-            job.block = job.x0 = None
-            engine._single = None             # the operands validate_single() looked at
-            import gc
+        exchange = info.get("exchange", "p2p")
+        args.col_chunks_chosen = getattr(job, "col_chunks_chosen", None)
+        del step, halves
+        job.drop_full()
+        job.block = job.x0 = None
+        engine._single = None             # the operands validate_single() looked at
+        import gc
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        extras_fn = None
+        if want_extras:
+            from benchlib.extras import compact_sections, run_extras as extras_fn
+            detail = {}
+            _phase("extras: S0 / S2 / S4_products / S1_community")
+            t_x = time.perf_counter()
+            extras_fn(args, engine, detail, budget_s=args.extras_budget, which=("S0_pubmed", "S2_gamlp", "S4_products", "S1_community"))
+            t_x = time.perf_counter() - t_x
+        if want_papers:
+            _phase("papers100M section")
+            try:
+                papers = papers_section(args, engine, rank, world, exchange)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                papers = {"failed": repr(e)[:200], "where": traceback.format_exc()[-700:]}
+            if rank == 0:
+                out["papers100M"] = papers
+        if want_extras:
+            _phase("extras: S4_papers_shard")
             gc.collect()
-            if torch.cuda.is_available():
-                torch.cuda.empty_cache()
-            papers = papers_section(args, engine, rank, world, exchange)
-        except Exception as e:  # noqa: BLE001
-            import traceback
-            papers = {"failed": repr(e)[:200], "where": traceback.format_exc()[-700:]}
+            torch.cuda.empty_cache()
+            extras_fn(args, engine, detail, budget_s=args.extras_budget - t_x, which=("S4_papers_shard",))
+        if want_extras and rank == 0:
+            # LAST key of the line and short on purpose (4 significant digits, tables as rows): whoever keeps only the tail of a long
+            # line still reads every section.  The complete dictionaries go to --detail-out.
+            out["sections"] = compact_sections(detail["sections"])
+            if getattr(args, "detail_out", None):
+                with open(args.detail_out, "w") as f:
+                    json.dump({"head": {k: out[k] for k in ("metric", "value", "ms_per_step", "n_gpus", "steps", "warmup")}, "sections": detail["sections"]}, f, indent=1)
         done.set()
         timer.cancel()
-        if rank == 0:
-            out["papers100M"] = papers
     emit_line()
     if guard is not None:
         guard.cancel()

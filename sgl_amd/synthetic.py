@@ -14,6 +14,12 @@ WORKLOADS = {
     "S1_small": dict(n=200_000, m=5_000_000, d_max=5_000, d=100, k=3),
     "T_small": dict(n=20_000, m=150_000, d_max=800, d=100, k=3),     # launch rehearsals (N ranks on one GPU), seconds
     "S2_gamlp": dict(n=2_449_029, m=61_859_140, d_max=17_481, d=147, k=5),
+    "S2_small": dict(n=200_000, m=5_000_000, d_max=5_000, d=147, k=5),
+    # the S1 degree law with communities (degree-corrected planted partition, ids SHUFFLED: what a real co-purchase dump such as
+    # ogbn-products looks like, dataset/ogbn.py:45-53 loads its ids as they come): the workload on which a locality ordering
+    # (GraphOp(reorder=...)) has something to find.  The Chung-Lu workloads above have no communities by construction.
+    "S1_community": dict(n=2_449_029, m=61_859_140, d_max=17_481, d=100, k=3, community=dict(block=4096, p_in=0.8)),
+    "T_community": dict(n=40_000, m=400_000, d_max=800, d=100, k=3, community=dict(block=512, p_in=0.8)),
     # ogbn-papers100M-shaped: directed hash-generated graph, rows generated per shard on device
     # (`hashed=True`: sgl_synth_*, mirrored on the host below).  mean_deg 30.07 -> nnz ~ 3.34 G over all rows.
     # S3_papers_shard = ONE rank's share of the 8-GPU job on one GPU: rows [0, N/8) against the full 111 M x 128 replica.
@@ -87,6 +93,70 @@ def chung_lu_torch(n, m, d_max, seed=0, weight=1.0, sigma=1.2, device="cuda"):
     rowptr[1:] = torch.cumsum(counts, 0)
     val = torch.full((col.numel(),), float(weight), dtype=torch.float32, device=device)
     return rowptr, col, val
+
+
+def planted_partition_torch(n, m, d_max, block, p_in=0.8, seed=0, weight=1.0, sigma=1.2, device="cuda", shuffle=True):
+    """Degree-corrected planted partition with chung_lu's degree law: node i has the log-normal weight w_i of chung_lu_torch
+    (same clipping and rescaling), communities are runs of `block` consecutive nodes of the GENERATOR's numbering, an edge's
+    first endpoint is drawn proportionally to w and its partner proportionally to w INSIDE the first endpoint's community with
+    probability p_in, over the whole graph otherwise.  Self loops dropped, duplicates removed, symmetrised; finally (shuffle)
+    the node ids are permuted at random, so the ids carry no trace of the communities.  Returns canonical CSR tensors
+    (rowptr int64, col int32, val float32) and `truth` (int64 [n]: the community of every node under the returned ids)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w = torch.exp(torch.randn(n, generator=g, device=device, dtype=torch.float64) * sigma)
+    w = torch.clamp(w / w.sum() * (2 * m), 1.0, float(d_max))
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1]
+    cdf0 = torch.cat([torch.zeros(1, dtype=cdf.dtype, device=cdf.device), cdf])      # cdf0[i] = mass of nodes < i
+    n_blocks = (n + block - 1) // block
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    need = m
+    for _ in range(8):
+        draw = int(need * 1.05) + 1024
+        a = torch.searchsorted(cdf, torch.rand(draw, generator=g, device=device, dtype=torch.float64)).clamp_(0, n - 1)
+        u = torch.rand(draw, generator=g, device=device, dtype=torch.float64)
+        inside = torch.rand(draw, generator=g, device=device) < p_in
+        blk = a // block
+        lo_m = cdf0[blk * block]
+        hi_m = cdf0[torch.clamp((blk + 1) * block, max=n)]
+        target = torch.where(inside, lo_m + u * (hi_m - lo_m), u)
+        b = torch.searchsorted(cdf, target).clamp_(0, n - 1)
+        b = torch.where(inside, torch.minimum(torch.maximum(b, blk * block), torch.clamp((blk + 1) * block, max=n) - 1), b)
+        del u, inside, blk, lo_m, hi_m, target
+        keep = a != b
+        lo, hi = torch.minimum(a, b)[keep], torch.maximum(a, b)[keep]
+        keys = torch.unique(torch.cat([keys, lo * n + hi]))
+        del a, b, keep, lo, hi
+        if keys.numel() >= m:
+            break
+        need = m - keys.numel()
+    if keys.numel() > m:
+        sel = torch.randperm(keys.numel(), generator=g, device=device)[:m]
+        keys = keys[sel]
+        del sel
+    lo, hi = keys // n, keys % n
+    del keys
+    truth = torch.arange(n, device=device, dtype=torch.int64) // block
+    if shuffle:
+        new_id = torch.randperm(n, generator=g, device=device)           # new id of generator node i
+        lo, hi = new_id[lo], new_id[hi]
+        t2 = torch.empty_like(truth)
+        t2[new_id] = truth
+        truth = t2
+        del new_id
+    full = torch.cat([lo * n + hi, hi * n + lo])
+    del lo, hi
+    full = torch.sort(full).values
+    rows = full // n
+    col = (full % n).to(torch.int32)
+    del full
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    del rows
+    val = torch.full((col.numel(),), float(weight), dtype=torch.float32, device=device)
+    assert n_blocks >= 1
+    return rowptr, col, val, truth
 
 
 def features_torch(n, d, seed=0, device="cuda", kind="normal"):

@@ -544,3 +544,120 @@ def test_bare_bench_command_with_more_ranks_than_gpus_prints_a_null_line():
     assert out.returncode != 0 and len(lines) == 1
     j = json.loads(lines[0])
     assert j["value"] is None and j["n_gpus"] == 2 and "GPU(s) visible" in j["error"]
+
+
+# ---- secondary sections of the single-GPU line (benchlib/extras.py) ----------------------------------------------------------
+def test_extras_runner_records_failures_and_budget_and_compacts(monkeypatch):
+    """run_extras: a section that raises is recorded in place of its numbers, a section that would start after the budget is
+    recorded as skipped, the others carry wall_s; compact_sections keeps the REQUIRED_KEYS of every section that ran and the
+    failure text of those that did not -- none of it can touch the headline"""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import time
+    from benchlib import extras
+
+    def ok_section(name, cfg):
+        return {"workload": f"{name}: long text", "short": "short text", "baseline_config": cfg, "ms": 1.23456789, "validated": True,
+                "roofline": extras._roof(1e9, 1.0)}
+
+    class Eng:
+        def build_raw(self, args, wl):
+            return ("raw",)
+    monkeypatch.setattr(extras, "section_s0", lambda a, e: dict(ok_section("S0_pubmed", 1), ms_per_hop=0.4, value=1e12,
+                        validation={"strict_order_all_hops_bit_equal": True, "fast_order": {"row_l2_rel": 2e-7}},
+                        cpu_baseline={"kind": "port", "cores": 8, "normalise_ms": 1.0, "propagate_ms": 2.0, "value": 1e9}))
+    monkeypatch.setattr(extras, "section_s2", lambda a, e, raw: (_ for _ in ()).throw(RuntimeError("boom")))
+    monkeypatch.setattr(extras, "section_s4_products", lambda a, e, raw: (time.sleep(0.3), ok_section("S4_products", 5))[1])
+    args = argparse.Namespace(seed=0, extras_scale="small")
+    detail = {}
+    extras.run_extras(args, Eng(), detail, budget_s=20.2, which=("S0_pubmed", "S2_gamlp", "S4_products", "S1_community"))
+    sec = detail["sections"]
+    assert sec["S0_pubmed"]["validated"] is True and "wall_s" in sec["S0_pubmed"]
+    assert "boom" in sec["S2_gamlp"]["failed"] and "where" in sec["S2_gamlp"]
+    assert "skipped" in sec["S1_community"] and "budget" in sec["S1_community"]["skipped"]        # 20.2 - 0.3 s < the 20 s a section needs
+    assert "S4_papers_shard" not in sec                                                          # not asked for
+    # S4_products' stub has no tables: compact what has the full shape
+    c = extras.compact_sections({k: sec[k] for k in ("S0_pubmed", "S2_gamlp", "S1_community")})
+    assert all(k in c["S0_pubmed"] for k in extras.REQUIRED_KEYS)
+    assert c["S0_pubmed"]["ms"] == 1.235 and c["S0_pubmed"]["roofline"]["frac"] == extras._r(1e9 / 1e-3 / 8e12)
+    assert c["S0_pubmed"]["workload"] == "S0_pubmed: short text" and c["S0_pubmed"]["cpu_baseline"]["cores"] == 8
+    assert "failed" in c["S2_gamlp"] and "skipped" in c["S1_community"]
+
+
+def test_recorded_bench_line_carries_every_baseline_config():
+    """the bench line kept under profiles/ (the builder's run of the driver's command): sections for BASELINE configs 1, 3, 5 and the
+    per-rank share of 4/5, each with workload / ms / roofline{frac, achieved, algorithmic_bytes_per_launch} / validated, the MessageOp
+    tables, the CPU baselines -- the format a reader of BENCH_rNN.json relies on"""
+    import glob
+    sys.path.insert(0, ROOT)
+    from benchlib import extras
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_S1*.json")))
+    assert files, "profiles/r06_bench_S1.json is missing"
+    j = json.loads(open(files[0]).read().strip().splitlines()[-1])
+    assert j["config"]["workload"].startswith("S1_products") and j["value"] > 0 and j["roofline"]["frac"] > 0.6
+    sec = j["sections"]
+    assert list(j)[-1] == "sections", "the sections must be the LAST key of the line"
+    assert set(sec) == {"S0_pubmed", "S2_gamlp", "S4_products", "S1_community", "S4_papers_shard"}
+    for name, s in sec.items():
+        assert all(k in s for k in extras.REQUIRED_KEYS), (name, list(s))
+        assert s["validated"] is True and s["ms"] > 0 and {"frac", "achieved", "algorithmic_bytes_per_launch"} <= set(s["roofline"]), name
+    assert sec["S0_pubmed"]["baseline_config"] == 1 and sec["S0_pubmed"]["strict_order_bit_equal_to_cpu_oracle"] is True
+    assert sec["S0_pubmed"]["cpu_baseline"]["kind"] in ("reference", "port") and sec["S0_pubmed"]["cpu_baseline"]["cores"] >= 1
+    assert sec["S2_gamlp"]["baseline_config"] == 3 and len(sec["S2_gamlp"]["preprocess_calls_ms"]) == 3
+    for name in ("S4_products", "S4_papers_shard"):
+        ops = {r[0]: r for r in sec[name]["message_ops"]}
+        assert len(ops) == 10 and all(r[3] is True for r in ops.values()), name                  # the nine ops of the search space + NAFS
+        assert {"last", "concat", "mean", "sum", "max", "min"} <= set(ops) and any(k.startswith("nafs") for k in ops)
+        assert all(g[4] is True for g in sec[name]["graph_ops"])
+    assert len(sec["S4_products"]["graph_ops"]) == 4                                             # Laplacian + PPR alpha .1 / .2 / .3
+    cb = sec["S4_products"]["cpu_baseline_combine"]
+    assert set(cb["ms"]) == {"mean", "max", "concat", "nafs"} and cb["threads"] >= 1 and cb["rows"] > 0
+    com = sec["S1_community"]
+    assert com["reorder_auto"]["applied"] is True and com["reorder_auto"]["bit_identical"] is True
+    assert com["reorder_auto"]["ms_per_hop"] < com["reorder_none"]["ms_per_hop"]
+    assert len(json.dumps(sec)) < 6000, "the sections are meant to stay short enough to be read from the tail of the line"
+
+
+def test_cpu_legs_of_the_secondary_sections():
+    """benchlib/cpu_legs.py on small inputs: config 1's reference path returns a baseline AND a verdict on the candidate hops
+    (a perturbed candidate fails, the oracle's own hops pass bit for bit); the torch-CPU combine leg reports all four aggregates"""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from benchlib import cpu_legs
+    from sgl_amd.synthetic import chung_lu_numpy
+    n, d, K = 3000, 24, 3
+    ip, ix, dt = chung_lu_numpy(n, 20_000, 300, seed=2)
+    x = np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)
+    ref = oracle.propagate(oracle.laplacian_adj(ip, ix, dt, n, 0.5), x, K)
+    cpu, chk = cpu_legs.config1_reference_path(ip, ix, dt, x, n, K, ref[K], ref, 1e-5)
+    assert chk["fast_order"]["ok"] and chk["fast_order"]["bit_equal"] and chk["strict_order_all_hops_bit_equal"]
+    assert cpu["value"] > 0 and cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["normalise_ms"] > 0
+    bad = [h.copy() for h in ref]
+    bad[2][5, 3] += 1e-3
+    _, chk = cpu_legs.config1_reference_path(ip, ix, dt, x, n, K, ref[K] * (1 + 1e-4), bad, 1e-5)
+    assert not chk["fast_order"]["ok"] and not chk["strict_order_all_hops_bit_equal"]
+    hops = [torch.from_numpy(h) for h in ref]
+    res = cpu_legs.combine_baseline(hops, d, rows_fast=2000, rows_loop=50)
+    assert res["rows"] == 2000 and res["nafs_rows"] == 50 and all(res[k]["ms"] > 0 and res[k]["rows_per_s"] > 0 for k in ("mean", "max", "concat", "nafs"))
+
+
+def test_planted_partition_generator_properties():
+    """sgl_amd.synthetic.planted_partition_torch (workload S1_community): canonical symmetric CSR without self loops, the stated
+    share of edges inside communities, and NO trace of the communities in the (shuffled) ids"""
+    sys.path.insert(0, ROOT)
+    from sgl_amd import synthetic as sy
+    n, m, blk = 20_000, 200_000, 512
+    rp, col, val, truth = sy.planted_partition_torch(n, m, 600, blk, 0.8, seed=3, device="cpu")
+    rows = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    c = col.long()
+    assert int(rp[-1]) == col.numel() == val.numel() and bool((rows != c).all()) and bool((val == 1).all())
+    k1, k2 = torch.sort(rows * n + c).values, torch.sort(c * n + rows).values
+    assert torch.equal(k1, k2) and torch.unique(k1).numel() == k1.numel()                       # symmetric, no duplicates
+    assert bool((torch.diff(rows * n + c) > 0).all())                                            # canonical: rows ascending, columns sorted
+    inside = float((truth[rows] == truth[c]).float().mean())
+    assert 0.7 < inside < 0.85
+    near = float(((rows - c).abs() < blk).float().mean())
+    assert near < 0.1                                                                            # ids are shuffled: neighbours are not id-neighbours
+    rp2, col2, _, truth2 = sy.planted_partition_torch(n, m, 600, blk, 0.8, seed=3, device="cpu")
+    assert torch.equal(rp, rp2) and torch.equal(col, col2) and torch.equal(truth, truth2)        # seeded
+    assert int(truth.max()) == (n - 1) // blk and sy.WORKLOADS["S1_community"]["n"] == sy.WORKLOADS["S1_products"]["n"]

@@ -2593,6 +2593,63 @@ def test_bench_single_gpu_line_validates_itself(cuda, monkeypatch):
     assert j["config"]["validated"] is False and j["config"]["validation"]["sampled_rows_fp64_ok"] is False and j["value"] > 0
 
 
+def test_bench_secondary_sections_cover_every_baseline_config(cuda, monkeypatch, tmp_path):
+    """bench.py's single-GPU line carries one section per BASELINE config the headline does not cover (benchlib/extras.py), here on
+    the small graphs of --extras-scale small: config 1 compared with the CPU oracle (strict order bit for bit), config 3's three
+    preprocess calls, config 5's operator sweep with every MessageOp checked on sampled rows against the float64 formula, the
+    per-rank share of configs 4/5, and the community graph with reorder=None / "auto" (bit-identical).  A check that is handed the
+    wrong formula parameters fails its op and its section -- the validation has teeth."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    import bench
+    from benchlib import extras
+    detail = str(tmp_path / "detail.json")
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--workload", "S1_small", "--extras-scale", "small", "--no-cpu-baseline",
+                             "--detail-out", detail])
+    lines = []
+    bench.run(args, emit=lines.append)
+    j = json.loads(lines[0])
+    assert list(j)[-1] == "sections" and j["config"]["validated"] is True and "papers100M" not in j
+    sec = j["sections"]
+    assert set(sec) == {"S0_pubmed", "S2_gamlp", "S4_products", "S1_community", "S4_papers_shard"}
+    for name, s_ in sec.items():
+        assert "failed" not in s_ and "skipped" not in s_, (name, s_)
+        assert all(k in s_ for k in extras.REQUIRED_KEYS), (name, list(s_))
+        assert s_["validated"] is True and s_["ms"] > 0 and 0 < s_["roofline"]["frac"] < 2, (name, s_)
+    assert sec["S0_pubmed"]["strict_order_bit_equal_to_cpu_oracle"] is True and sec["S0_pubmed"]["fast_order_row_l2_rel"] <= TOL
+    assert sec["S0_pubmed"]["cpu_baseline"]["propagate_ms"] > 0
+    assert len(sec["S2_gamlp"]["preprocess_calls_ms"]) == 3 and sec["S2_gamlp"]["train_feed_ms"] > 0
+    for name in ("S4_products", "S4_papers_shard"):
+        assert len(sec[name]["message_ops"]) == 10 and all(r[3] is True for r in sec[name]["message_ops"]), sec[name]["message_ops"]
+        assert all(g[4] is True for g in sec[name]["graph_ops"])
+    assert len(sec["S4_products"]["graph_ops"]) == 4 and all(g[5] is not None for g in sec["S4_products"]["graph_ops"][1:])
+    assert set(sec["S4_products"]["cpu_baseline_combine"]["ms"]) == {"mean", "max", "concat", "nafs"}
+    com = sec["S1_community"]["reorder_auto"]
+    assert com["applied"] is True and com["bit_identical"] is True and com["edge_locality"][1] > com["edge_locality"][0] + 0.15
+    full = json.load(open(detail))["sections"]
+    assert full["S4_products"]["graph_ops"][0]["message_ops"][2]["preprocess_objective_ms"] > 0
+    assert "sample" in full["S0_pubmed"]["cpu_baseline"] and full["S2_gamlp"]["validation"]["ok"] is True
+
+    # the aggregate check fails when it is handed another formula than the one the op computes
+    real = extras._search_space_ops
+
+    def wrong(K, d, device, with_nafs=True):
+        ops = real(K, d, device, with_nafs)
+        return [(n_, k_, op, dict(p, alpha=0.8) if k_ == "simple_weighted" else p) for n_, k_, op, p in ops]
+    monkeypatch.setattr(extras, "_search_space_ops", wrong)
+    args2 = bench.parse_args(["--steps", "1", "--warmup", "1", "--workload", "S1_small", "--extras-scale", "small", "--no-cpu-baseline"])
+    eng = bench.GpuEngine(0)
+    d2 = {}
+    extras.run_extras(args2, eng, d2, budget_s=120, which=("S4_products",))
+    s4 = d2["sections"]["S4_products"]
+    assert s4["validated"] is False
+    bad = [t["msg_op"] for t in s4["graph_ops"][0]["message_ops"] if not t["validated"]]
+    assert bad == ["simple_weighted a=.85"], bad
+
+
 def test_c_abi_from_plain_c_program(cuda, tmp_path):
     """examples/c_abi_propagate.c: a C99 program with raw hipMalloc'ed buffers (no Python, no PyTorch) normalises a
     graph and runs the k-hop chain through include/sgl_hip.h, and checks every hop bit for bit against the

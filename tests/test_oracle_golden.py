@@ -325,3 +325,24 @@ def test_truth_report_rule():
     y = ref + np.float32(2e-6) * np.abs(ref).max() * np.sign(ref)
     assert not oracle.parity_ok(y, ref, 1e-5) and not oracle.parity_ok(y, ref, 1e-5, rowwise=False)       # wide output: unrelaxed
     assert oracle.parity_ok(y[:, :1], ref[:, :1], 1e-5, rowwise=False) and not oracle.parity_ok(y[:, :1], ref[:, :1], 1e-5)
+
+
+def test_torch_combine_equals_the_numpy_oracle(goldens):
+    """oracle/torch_combine.py (the torch-CPU execution of the reference's _combine bodies, timed by the bench's cpu_baseline leg)
+    against the golden vectors recorded from the reference and against the numpy restatement"""
+    import torch
+    from oracle import torch_combine as tc
+    feats, g3 = _feats(goldens)
+    tf = [torch.from_numpy(np.ascontiguousarray(f)) for f in feats]
+    H = 5
+    for (s, e) in ((0, H), (1, H - 1)):
+        tag = f"{s}_{e}"
+        assert np.array_equal(tc.combine_concat(tf, s, e).numpy(), g3[f"concat|{tag}"])
+        assert np.array_equal(tc.combine_sum(tf, s, e).numpy(), g3[f"sum|{tag}"])
+        assert np.array_equal(tc.combine_mean(tf, s, e).numpy(), g3[f"mean|{tag}"])
+        assert np.array_equal(tc.combine_max(tf, s, e).numpy(), g3[f"max|{tag}"])
+        assert np.array_equal(tc.combine_min(tf, s, e).numpy(), g3[f"min|{tag}"])
+    loop = tc.combine_over_smooth_distance(tf).numpy()
+    assert np.array_equal(loop, g3["over_smooth"])                           # the reference's own loop, restated: bit for bit
+    assert oracle.parity_ok(tc.combine_over_smooth_distance_vectorised(tf).numpy(), g3["over_smooth"], 1e-6)
+    assert oracle.parity_ok(loop, oracle.agg_over_smooth_distance(feats), 1e-6)

@@ -60,6 +60,35 @@ def main():
     alg = nnz * d * 4 + nnz * 8 + (rows + 1) * 4 + rows * d * 4
     print(f"PAPERS shard: {ms:.2f} ms per hop per rank  = {nnz * d / (ms * 1e-3) / 1e12:.3f}e12 edge*feat/s per GPU, "
           f"{nnz / (ms * 1e-3) / 1e9:.2f} G gathers/s, algorithmic-roofline fraction {alg / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    if os.environ.get("PAPERS_SWEEP", "0") == "group":
+        # d = 128 as 32 lanes x float4 with TWO non-zeros per step (R = 2) instead of 64 lanes of which 32 idle
+        from sgl_amd import _lib
+        ref = y.clone()
+
+        def timed_g():
+            for _ in range(2):
+                csr.spmm(x, out=y)
+            torch.cuda.synchronize()
+            tt = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                csr.spmm(x, out=y)
+                e1.record()
+                torch.cuda.synchronize()
+                tt.append(e0.elapsed_time(e1))
+            return float(np.median(tt))
+        for group in (0, 32):
+            for unroll in (0, 1, 3, 2, 4):            # default / 4 / 8 / 16 / (32) gathers in flight per lane
+                _lib.set_tuning("spmm_group", group)
+                _lib.set_tuning("spmm_unroll", unroll)
+                ms_g = timed_g()
+                err = float((y - ref).abs().max() / ref.abs().max())
+                print(f"PAPERS group sweep group={group or 64} unroll_knob={unroll} ms={ms_g:.2f}  frac={alg / (ms_g * 1e-3) / 8e12:.3f}  "
+                      f"max|dy|/max|y| vs default = {err:.2e}", flush=True)
+        _lib.set_tuning("spmm_group", 0)
+        _lib.set_tuning("spmm_unroll", 0)
+        return
     if os.environ.get("PAPERS_SWEEP", "0") == "1":
         from sgl_amd import _lib
         def timed():
