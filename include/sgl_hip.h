@@ -206,6 +206,12 @@ int sgl_allgather_rows(void *nccl_comm, int rank, int world, const int64_t *h_bo
 int sgl_exchange_rows(void *nccl_comm, int rank, int world, const float *d_send, const int64_t *h_send_off, float *d_recv,
                       const int64_t *h_recv_off, int64_t ld, void *stream);
 const char *sgl_exchange_backend(void);
+/* Loop-back check of the RCCL binding on the caller's communicator: n floats travel from d_src to d_dst (disjoint device buffers)
+ * as n_ops grouped ncclSend / ncclRecv pairs whose peer is `rank` itself -- posted by the same internal routine, function table
+ * and data-type constant as the two exchanges above.  Works on a one-rank communicator (one GPU) and on every rank of a real job
+ * before its first hop; the reference's only communicator set-up is dist.init_process_group('nccl'),
+ * tasks/node_classification_dist.py:61.  Stream-ordered; SGL_ERR_UNSUPPORTED without RCCL. */
+int sgl_exchange_selftest(void *nccl_comm, int rank, const float *d_src, float *d_dst, int64_t n, int n_ops, void *stream);
 
 /* ---- reference-signature host shims (H2D -> kernel -> D2H; synchronous) ------------------------------------ */
 /* matmul.h:5 -- accumulates into `answer` (caller pre-zeroes it, utils.py:31).  Errors are recorded in

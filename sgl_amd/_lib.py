@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sgl_allgather_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_exchange_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sgl_exchange_backend": (c_char_p, []),
+    "sgl_exchange_selftest": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "FloatCSRMulDenseOMP": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "FloatCSRMulDense": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "sgl_shim_cache_stats": (c_int, [POINTER(c_int64), POINTER(c_int64)]),

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <mutex>
+#include <vector>
 
 #include "sgl_common.h"
 
@@ -54,6 +55,38 @@ Rccl &rccl() {   // resolved once, also when several host threads (one per GPU) 
 
 constexpr int kNcclFloat32 = 7;   // ncclFloat32 (rccl.h: ncclDataType_t)
 
+// One transfer pair of a grouped batch: `n_send` floats to rank `dst`, `n_recv` floats from rank `src` (either may be 0).
+struct Xfer {
+    const float *send;
+    size_t n_send;
+    int dst;
+    float *recv;
+    size_t n_recv;
+    int src;
+};
+
+// THE place where RCCL is called: ncclGroupStart, the sends / receives in the order given, ncclGroupEnd -- through the
+// run-time resolved table, with kNcclFloat32, on the caller's communicator and stream.  sgl_allgather_rows, sgl_exchange_rows
+// and sgl_exchange_selftest all end here, so a self-test that passes has exercised the exact calls of the multi-GPU exchange.
+int post_group(void *comm, hipStream_t st, const Xfer *x, int n, const char *who) {
+    Rccl &r = rccl();
+    if (!r.send || !r.recv || !r.group_start || !r.group_end)
+        return sgl::fail(SGL_ERR_UNSUPPORTED, "%s: no RCCL in this process (ncclSend / ncclRecv not found)", who);
+    auto fail = [&](int rc, const char *what) {
+        return sgl::fail(rc, "%s: %s failed: %s", who, what, r.errstr ? r.errstr(rc) : "RCCL error");
+    };
+    int rc = r.group_start();
+    if (rc != 0) return fail(rc, "ncclGroupStart");
+    for (int i = 0; i < n && rc == 0; ++i) {
+        if (x[i].n_send) rc = r.send(x[i].send, x[i].n_send, kNcclFloat32, x[i].dst, comm, st);
+        if (rc == 0 && x[i].n_recv) rc = r.recv(x[i].recv, x[i].n_recv, kNcclFloat32, x[i].src, comm, st);
+    }
+    const int rc_end = r.group_end();
+    if (rc != 0) return fail(rc, "ncclSend / ncclRecv");
+    if (rc_end != 0) return fail(rc_end, "ncclGroupEnd");
+    return SGL_OK;
+}
+
 }  // namespace
 
 SGL_EXPORT int sgl_allgather_rows(void *nccl_comm, int rank, int world, const int64_t *h_bounds, float *d_x, int64_t ldx,
@@ -64,27 +97,16 @@ SGL_EXPORT int sgl_allgather_rows(void *nccl_comm, int rank, int world, const in
         SGL_REQUIRE(h_bounds[q] <= h_bounds[q + 1] && h_bounds[0] >= 0, "sgl_allgather_rows: row bounds must not decrease");
     if (world == 1 || ldx == 0) return SGL_OK;
     SGL_REQUIRE(d_x != nullptr && nccl_comm != nullptr, "sgl_allgather_rows: NULL matrix or communicator");
-    Rccl &r = rccl();
-    if (!r.send || !r.recv || !r.group_start || !r.group_end)
-        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_allgather_rows: no RCCL in this process (ncclSend / ncclRecv not found)");
-    hipStream_t st = sgl::as_stream(stream);
-    auto fail = [&](int rc, const char *what) {
-        return sgl::fail(rc, "sgl_allgather_rows: %s failed: %s", what, r.errstr ? r.errstr(rc) : "RCCL error");
-    };
     const size_t mine = (size_t)(h_bounds[rank + 1] - h_bounds[rank]) * (size_t)ldx;
-    int rc = r.group_start();
-    if (rc != 0) return fail(rc, "ncclGroupStart");
+    std::vector<Xfer> xs;
+    xs.reserve((size_t)world);
     // stagger the peer order per rank so that at any moment every link carries one transfer in each direction
-    for (int k = 1; k < world && rc == 0; ++k) {
+    for (int k = 1; k < world; ++k) {
         const int dst = (rank + k) % world, src = (rank - k + world) % world;
-        if (mine) rc = r.send(d_x + h_bounds[rank] * ldx, mine, kNcclFloat32, dst, nccl_comm, st);
         const size_t theirs = (size_t)(h_bounds[src + 1] - h_bounds[src]) * (size_t)ldx;
-        if (rc == 0 && theirs) rc = r.recv(d_x + h_bounds[src] * ldx, theirs, kNcclFloat32, src, nccl_comm, st);
+        xs.push_back(Xfer{d_x + h_bounds[rank] * ldx, mine, dst, d_x + h_bounds[src] * ldx, theirs, src});
     }
-    const int rc_end = r.group_end();
-    if (rc != 0) return fail(rc, "ncclSend / ncclRecv");
-    if (rc_end != 0) return fail(rc_end, "ncclGroupEnd");
-    return SGL_OK;
+    return post_group(nccl_comm, sgl::as_stream(stream), xs.data(), (int)xs.size(), "sgl_allgather_rows");
 }
 
 // Need-aware form of the same exchange (sgl_amd/dist/halo.py is the plan that produces the offsets): the rows of this rank
@@ -103,26 +125,35 @@ SGL_EXPORT int sgl_exchange_rows(void *nccl_comm, int rank, int world, const flo
     if (world == 1 || ld == 0) return SGL_OK;
     const bool any_send = h_send_off[world] > h_send_off[0], any_recv = h_recv_off[world] > h_recv_off[0];
     SGL_REQUIRE(nccl_comm != nullptr && (!any_send || d_send) && (!any_recv || d_recv), "sgl_exchange_rows: NULL buffer or communicator");
-    Rccl &r = rccl();
-    if (!r.send || !r.recv || !r.group_start || !r.group_end)
-        return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_exchange_rows: no RCCL in this process (ncclSend / ncclRecv not found)");
-    hipStream_t st = sgl::as_stream(stream);
-    auto fail = [&](int rc, const char *what) {
-        return sgl::fail(rc, "sgl_exchange_rows: %s failed: %s", what, r.errstr ? r.errstr(rc) : "RCCL error");
-    };
-    int rc = r.group_start();
-    if (rc != 0) return fail(rc, "ncclGroupStart");
-    for (int k = 1; k < world && rc == 0; ++k) {
+    std::vector<Xfer> xs;
+    xs.reserve((size_t)world);
+    for (int k = 1; k < world; ++k) {
         const int dst = (rank + k) % world, src = (rank - k + world) % world;
         const size_t out = (size_t)(h_send_off[dst + 1] - h_send_off[dst]) * (size_t)ld;
         const size_t in = (size_t)(h_recv_off[src + 1] - h_recv_off[src]) * (size_t)ld;
-        if (out) rc = r.send(d_send + h_send_off[dst] * ld, out, kNcclFloat32, dst, nccl_comm, st);
-        if (rc == 0 && in) rc = r.recv(d_recv + h_recv_off[src] * ld, in, kNcclFloat32, src, nccl_comm, st);
+        xs.push_back(Xfer{d_send + h_send_off[dst] * ld, out, dst, d_recv + h_recv_off[src] * ld, in, src});
     }
-    const int rc_end = r.group_end();
-    if (rc != 0) return fail(rc, "ncclSend / ncclRecv");
-    if (rc_end != 0) return fail(rc_end, "ncclGroupEnd");
-    return SGL_OK;
+    return post_group(nccl_comm, sgl::as_stream(stream), xs.data(), (int)xs.size(), "sgl_exchange_rows");
+}
+
+// Loop-back check of the RCCL binding on the CALLER's communicator: `n` floats travel from d_src to d_dst as a grouped
+// ncclSend / ncclRecv pair whose peer is this very rank -- the same post_group(), function table and data-type constant the two
+// exchanges above use, so it proves on ONE GPU (or on every rank of a real job, before the first hop) that the library found a
+// working RCCL, that its idea of ncclFloat32 and of the argument order matches that RCCL's, and that the communicator and the
+// stream are accepted.  `n_ops` pairs are posted in the one group (the shape of a world of n_ops + 1 ranks), each moving its
+// share of the n floats.  d_src and d_dst must not overlap.  Stream-ordered.
+SGL_EXPORT int sgl_exchange_selftest(void *nccl_comm, int rank, const float *d_src, float *d_dst, int64_t n, int n_ops, void *stream) {
+    SGL_REQUIRE(nccl_comm != nullptr && rank >= 0, "sgl_exchange_selftest: NULL communicator or negative rank");
+    SGL_REQUIRE(n >= 0 && n_ops >= 1 && n_ops <= 64, "sgl_exchange_selftest: n >= 0 and 1 <= n_ops <= 64");
+    SGL_REQUIRE(n == 0 || (d_src && d_dst), "sgl_exchange_selftest: NULL buffer");
+    SGL_REQUIRE(n == 0 || d_src + n <= d_dst || d_dst + n <= d_src, "sgl_exchange_selftest: source and destination overlap");
+    if (n == 0) return SGL_OK;
+    std::vector<Xfer> xs;
+    for (int i = 0; i < n_ops; ++i) {
+        const int64_t a = n * i / n_ops, b = n * (i + 1) / n_ops;
+        xs.push_back(Xfer{d_src + a, (size_t)(b - a), rank, d_dst + a, (size_t)(b - a), rank});
+    }
+    return post_group(nccl_comm, sgl::as_stream(stream), xs.data(), (int)xs.size(), "sgl_exchange_selftest");
 }
 
 // which RCCL the exchange resolved to: "process" (symbols the host already had), "librccl.so" (loaded here) or "" (none)

@@ -290,6 +290,32 @@ int main(int argc, char **argv) {
         CHECK(exchange(&c, 0, 2, x.data(), self, x.data(), ro, 3, kStreamTag) != 0 && strstr(last_error(), "itself"));
         CHECK(std::string(backend()) == "process");      // resolved from the host process, not from a librccl.so on disk
     }
+    // ---- sgl_exchange_selftest: the loop-back pairs go through the same post_group() as the exchanges (one group, float32, the
+    // caller's stream, peer = the rank itself), on a one-rank world and as rank 3 of a larger one; overlap and bad counts refused ----
+    {
+        typedef int (*selftest_t)(void *, int, const float *, float *, int64_t, int, void *);
+        auto selftest = (selftest_t)dlsym(h, "sgl_exchange_selftest");
+        CHECK(selftest);
+        for (int rank : {0, 3}) {
+            World w;
+            Comm c{rank, rank + 1, &w};
+            std::vector<float> src(1000), dst(1000, -1.f);
+            for (int i = 0; i < 1000; ++i) src[i] = cell(i, 3, rank);
+            CHECK(selftest(&c, rank, src.data(), dst.data(), 1000, 3, kStreamTag) == 0);
+            CHECK(src == dst && c.groups == 1 && c.ops_outside_group == 0 && c.bad_dtype == 0 && c.bad_stream == 0 && c.log.size() == 6);
+            size_t moved = 0;
+            for (auto &op : c.log) {
+                CHECK(op.peer == rank && op.count > 0);
+                if (op.send) moved += op.count;
+            }
+            CHECK(moved == 1000);
+            for (auto &kv : w.box) CHECK(kv.second.empty());
+            CHECK(selftest(&c, rank, src.data(), src.data() + 10, 100, 1, kStreamTag) != 0 && strstr(last_error(), "overlap"));
+            CHECK(selftest(&c, rank, src.data(), dst.data(), 10, 0, kStreamTag) != 0);
+            c.fail_on_send_to = rank;
+            CHECK(selftest(&c, rank, src.data(), dst.data(), 10, 1, kStreamTag) != 0 && strstr(last_error(), "mock failure injected"));
+        }
+    }
     printf("exchange_mock: OK (%d multi-rank cases, worlds 2..8)\n", cases);
     return 0;
 }

@@ -2669,10 +2669,12 @@ def test_c_abi_from_plain_c_program(cuda, tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("C-ABI OK"), (out.returncode, out.stdout, out.stderr)
 
 
-def test_c_abi_allgather_rows_on_a_real_communicator(cuda):
-    """sgl_allgather_rows on an RCCL communicator created by the caller (here: one rank -- RCCL refuses two ranks on one
-    device, so the multi-peer batch itself is covered by the gloo tests of the identical Python transport): the library
-    finds RCCL at run time, accepts the communicator and stream, and leaves the replica intact."""
+def test_c_abi_exchange_moves_bytes_through_a_real_rccl_communicator(cuda):
+    """The C ABI's RCCL binding against the REAL librccl: a one-rank communicator created by the caller (RCCL refuses two ranks on
+    one device) carries grouped ncclSend / ncclRecv pairs whose peer is the rank itself -- sgl_exchange_selftest posts them through
+    the same post_group(), dlsym'ed function table and ncclFloat32 constant as sgl_allgather_rows / sgl_exchange_rows
+    (sgl_exchange.hip), so the bytes that arrive prove the argument order, the data type and the stream / communicator hand-over.
+    (The multi-peer bookkeeping itself is checked with 2-8 ranks against the mock RCCL, tests/native/exchange_mock.cpp.)"""
     import ctypes
 
     class UniqueId(ctypes.Structure):
@@ -2687,15 +2689,44 @@ def test_c_abi_allgather_rows_on_a_real_communicator(cuda):
     rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
     assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
     lib = _lib.lib()
-    assert lib.sgl_exchange_backend() in (b"process", b"librccl.so")
-    x = torch.arange(40 * 16, dtype=torch.float32, device=cuda).view(40, 16)
-    keep = x.clone()
-    bounds = (ctypes.c_int64 * 2)(0, 40)
-    _lib.check(lib.sgl_allgather_rows(comm, 0, 1, bounds, _lib.ptr(x), 16, _lib.current_stream_ptr()), "sgl_allgather_rows")
-    torch.cuda.synchronize()
-    assert torch.equal(x, keep)
-    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
-    rccl.ncclCommDestroy(comm)
+    try:
+        assert lib.sgl_exchange_backend() in (b"process", b"librccl.so") and lib.sgl_exchange_backend() != b""
+        g = torch.Generator(device=cuda).manual_seed(5)
+        # a feature block's worth of rows (whole padded rows travel): 4096 x 128 floats, as 1, 3 and 7 pairs in one group
+        src = torch.randn((4096, 128), generator=g, device=cuda)
+        for n_ops in (1, 3, 7):
+            dst = torch.full_like(src, float("nan"))
+            _lib.check(lib.sgl_exchange_selftest(comm, 0, _lib.ptr(src), _lib.ptr(dst), src.numel(), n_ops, _lib.current_stream_ptr()),
+                       "sgl_exchange_selftest")
+            torch.cuda.synchronize()
+            assert torch.equal(dst, src), n_ops                              # every byte arrived, bit for bit
+        # on a side stream, ordered behind the kernel that produces the source (stream-ordered like the exchanges)
+        side = torch.cuda.Stream(device=cuda)
+        dst = torch.zeros(1000, device=cuda)
+        with torch.cuda.stream(side):
+            part = torch.arange(1000, dtype=torch.float32, device=cuda) * 0.5
+            _lib.check(lib.sgl_exchange_selftest(comm, 0, _lib.ptr(part), _lib.ptr(dst), 1000, 2, ctypes.c_void_p(side.cuda_stream)),
+                       "sgl_exchange_selftest")
+        side.synchronize()
+        assert torch.equal(dst, torch.arange(1000, dtype=torch.float32, device=cuda) * 0.5)
+        # an odd count (not a multiple of anything) and the refusals
+        a, b = torch.randn(1237, generator=g, device=cuda), torch.zeros(1237, device=cuda)
+        _lib.check(lib.sgl_exchange_selftest(comm, 0, _lib.ptr(a), _lib.ptr(b), 1237, 5, _lib.current_stream_ptr()), "sgl_exchange_selftest")
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        assert lib.sgl_exchange_selftest(comm, 0, _lib.ptr(a), _lib.ptr(a), 16, 1, _lib.current_stream_ptr()) != 0
+        assert b"overlap" in lib.sgl_last_error()
+        assert lib.sgl_exchange_selftest(None, 0, _lib.ptr(a), _lib.ptr(b), 16, 1, _lib.current_stream_ptr()) != 0
+        # the exchanges themselves on this communicator: a one-rank world has nothing to move and leaves the replica alone
+        x = torch.arange(40 * 16, dtype=torch.float32, device=cuda).view(40, 16)
+        keep = x.clone()
+        bounds = (ctypes.c_int64 * 2)(0, 40)
+        _lib.check(lib.sgl_allgather_rows(comm, 0, 1, bounds, _lib.ptr(x), 16, _lib.current_stream_ptr()), "sgl_allgather_rows")
+        torch.cuda.synchronize()
+        assert torch.equal(x, keep)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
 
 
 def test_c_abi_row_sharded_program(cuda, tmp_path):

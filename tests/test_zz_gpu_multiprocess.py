@@ -201,6 +201,8 @@ def test_two_ranks_on_one_gpu_end_to_end(cuda, tmp_path):
 
 def _rccl_world1_worker(rank, port, out_dir):
     import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
     _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -227,6 +229,20 @@ def _rccl_world1_worker(rank, port, out_dir):
             w.wait()
         torch.cuda.synchronize()
         ok = ok and torch.equal(got[2:4], x[1:3]) and float(got[0].abs().sum()) == 0.0
+        # the SAME thing through the product's own helper (sgl_amd/dist/transports.py:_post -- what _DirectTransport.begin and
+        # HaloPropagator.begin_exchange call), incl. a zero-width slice that both sides must skip
+        from sgl_amd.dist.transports import _post
+        got2 = torch.zeros((6, 4), dtype=torch.float32, device=dev_)
+        _post(None, [(x[0:2], 0), (x[0:0], 0)], [(got2[3:5], 0), (got2[0:0], 0)]).wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(got2[3:5], x[0:2]) and float(got2[:3].abs().sum()) == 0.0
+        # the need-aware exchange as ONE collective (sgl_amd/dist/halo.py: begin_exchange with collective=True): all_to_all_single
+        # with explicit split sizes from a packed send buffer into the ghost range of a compact table, asynchronously
+        table = torch.zeros((7, 4), dtype=torch.float32, device=dev_)
+        packed = torch.arange(8, dtype=torch.float32, device=dev_).view(2, 4) + 100
+        dist.all_to_all_single(table[5:], packed, output_split_sizes=[2], input_split_sizes=[2], async_op=True).wait()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(table[5:], packed) and float(table[:5].abs().sum()) == 0.0
         gathered = torch.empty((3, 4), dtype=torch.float32, device=dev_)
         dist.all_gather_into_tensor(gathered, x, async_op=True).wait()
         flag = torch.tensor([1], dtype=torch.int32, device=dev_)
