@@ -19,7 +19,13 @@ fuse_aggregate  BaseSGAPModel.preprocess folds last / sum / mean / max / min / s
               "auto" (default) folds them only when the K+1 hop matrices would take more than a quarter of the free
               device memory; True / False force it
 cache_prepared  keep the (r, alpha)-independent part of a normalisation (A + I in fp64, degrees: 12 bytes per non-zero) with the
-              device adjacency / row block it was computed from, so that a sweep over r / alpha pays one pass per candidate
+              device adjacency / row block it was computed from, so that a sweep over r / alpha pays one pass per candidate.
+              cache_prepared_gb (default 8) bounds what the process-wide cache of whole-matrix preparations may keep resident: a
+              matrix whose preparation would exceed it is prepared transiently (freed before the hop matrices are allocated, as if
+              the cache were off -- a papers100M-sized matrix on one GPU would otherwise pin ~40 GB), least recently used entries
+              are evicted to stay under it, and entries die with their matrix (weak-reference callback).
+              keep_sweep_values (default False): additionally keep the fp64 Laplacian of the last PPR request (8 bytes per
+              non-zero) so that the next alpha at the same r is a pure stream (0.36 instead of 2.0 ms at the products shape)
 reorder       None -> the rows of A_hat are processed in the caller's node order; "community" -> a plan-time locality ordering
               (sgl_amd/reorder.py -> sgl_reorder_community: label propagation on the device, ~70 ms at products size, cached
               with the adjacency) decides the order in which the rows are STORED and PROCESSED (sgl_csr_permute_rows +
@@ -55,6 +61,8 @@ strict_types = _env_bool("SGL_AMD_STRICT_TYPES", False)
 strict_order = _env_bool("SGL_AMD_STRICT_ORDER", False)
 cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
 cache_prepared = _env_bool("SGL_AMD_CACHE_PREPARED", True)
+cache_prepared_gb = float(os.environ.get("SGL_AMD_CACHE_PREPARED_GB", "8"))
+keep_sweep_values = _env_bool("SGL_AMD_KEEP_SWEEP_VALUES", False)
 share_hops = _env_bool("SGL_AMD_SHARE_HOPS", False)
 share_hops_gb = float(os.environ.get("SGL_AMD_SHARE_HOPS_GB", "64"))
 _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()

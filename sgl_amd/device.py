@@ -163,6 +163,15 @@ def download_rows(t):
     return host
 
 
+def _wrote(*tensors):
+    """The library wrote into these caller-visible tensors through raw pointers: bump their torch version counters, as any in-place
+    torch write would.  Whatever keys on (data_ptr, _version) -- autograd's saved-tensor checks, the content memo of
+    hopcache.SharedHops, degree_powers' cache -- then sees the write."""
+    for t in tensors:
+        if torch.is_tensor(t):
+            torch.autograd.graph.increment_version(t)
+
+
 def _check_mat(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
         raise TypeError(f"{name} must be a 2-D float32 CUDA tensor")
@@ -265,6 +274,7 @@ class DeviceCSR:
         with torch.cuda.device(self.device):
             check(lib().sgl_spmm_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), d, int(bool(accumulate)),
                                      current_stream_ptr()), "sgl_spmm_f32")
+        _wrote(out)
         return out
 
     ACC_MODES = {"sum": 0, "wsum": 1, "max": 2, "min": 3}
@@ -283,6 +293,7 @@ class DeviceCSR:
             check(lib().sgl_spmm_acc_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), x.shape[1], ptr(acc), _ld(acc),
                                          float(w), mode, float(divisor), current_stream_ptr()),
                   "sgl_spmm_acc_f32")
+        _wrote(out, acc)
         return out
 
     def spmm_multi(self, x, out_ptrs, ld, row_mask=None):
@@ -326,6 +337,7 @@ class DeviceCSR:
             with torch.cuda.device(self.device):
                 check(lib().sgl_spmm_chain_f32(self._h, n_hops, ptr(x), _ld(x), ptrs, lds, d, current_stream_ptr()),
                       "sgl_spmm_chain_f32")
+            _wrote(*outs)
         return outs
 
     def capture_chain(self, x, outs):
@@ -364,6 +376,7 @@ class DeviceCSR:
             check(lib().sgl_spmm_axpb_clamp_f32(self._h, ptr(x), _ld(x), ptr(out), _ld(out), d, float(alpha),
                                                 ptr(res) if res is not None else None, _ld(res) if res is not None else 0,
                                                 float(lo), float(hi), current_stream_ptr()), "sgl_spmm_axpb_clamp_f32")
+        _wrote(out)
         return out
 
     def close(self):
@@ -387,6 +400,7 @@ class ChainGraph:
     def replay(self):
         with torch.cuda.device(self.csr.device):
             check(lib().sgl_chain_graph_launch(self._g, current_stream_ptr()), "sgl_chain_graph_launch")
+        _wrote(*self.outs)
         return self.outs
 
     def close(self):
@@ -525,13 +539,38 @@ class PreparedAdjacency:
                   "sgl_norm_build_symcheck")
             self.symmetric = int(fp.item()) == 0
         self.nnz_out = m
+        self.device = dev
+        if self.symmetric:
+            self.src = None            # the raw matrix is only needed again for the one-off transposition of a directed graph
+
+    def nbytes(self):
+        """device bytes this object keeps alive beyond the caller's own matrix (A + I in fp64, degrees, cached Laplacian, ...)"""
+        seen, total = set(), 0
+        objs = [self] + ([self.__dict__["_tblock"]] if self.__dict__.get("_tblock") is not None else [])
+        for o in objs:
+            for name, v in o.__dict__.items():
+                if name == "src":
+                    continue
+                if isinstance(v, tuple) and len(v) == 2 and torch.is_tensor(v[1]):
+                    v = v[1]                                         # _hat64 = (key, tensor)
+                if torch.is_tensor(v) and v.is_cuda and v.data_ptr() not in seen:
+                    seen.add(v.data_ptr())
+                    total += v.numel() * v.element_size()
+        return total
+
+    def drop_values(self):
+        """release the cached fp64 Laplacian of the last PPR request (8 bytes per non-zero)"""
+        self.__dict__["_hat64"] = None
+        tb = self.__dict__.get("_tblock")
+        if tb is not None:
+            tb.drop_values()
 
     def normalize(self, r, alpha=None, return_fp64=False, host_pow=True):
         """A_hat for this (r, alpha).  Symmetric A: one scaling pass over A + I, A_hat[j,i] = (A'[j,i] L[j]) R[i] -- no
         transposition; otherwise the transpose is built once (one stable sort) and every (r, alpha) is the same single pass over it.
         Both are bit-identical to the reference's scipy result (host_pow=True; see degree_powers).  PPR requests keep the fp64
         Laplacian of their r: the next alpha of a sweep is one stream over it (sgl_norm_block_mix), bit-identical to the one-pass form."""
-        dev = self.src[0].device
+        dev = self.device
         with torch.cuda.device(dev):
             if self.symmetric:
                 vals = _scaled_values(self, self.n, 0, self.rowptr, self.col, self.t64, self.deg, r, alpha, return_fp64, host_pow)
@@ -548,7 +587,7 @@ class PreparedAdjacency:
                 rows = torch.repeat_interleave(torch.arange(self.n, dtype=torch.int64, device=dev), rowptr[1:] - rowptr[:-1])
                 t = coo_to_csr_device(col.to(torch.int64), rows, val, self.n, device=dev)
                 tb = self._tblock = PreparedBlock(t.rowptr, t.col, t.val, 0, self.n, symmetric=False, deg=self.deg)
-                self.rowptr = self.col = self.t64 = None          # A + I itself is not needed any more
+                self.rowptr = self.col = self.t64 = self.src = None   # neither A + I nor the raw matrix is needed any more
             return tb.normalize(r, alpha, return_fp64=return_fp64, host_pow=host_pow)
 
 
@@ -576,6 +615,8 @@ def _scaled_values(owner, n_loc, row0, rowptr, col, t64, deg, r, alpha, return_f
                                              ptr(o_v64) if o_v64 is not None else None, current_stream_ptr()), "sgl_norm_block_scale")
             if keep:
                 owner._hat64 = (key, o_v64)
+                if return_fp64:
+                    o_v64 = o_v64.clone()            # the caller may edit what it gets; the cache entry stays private
             return (o_val, o_v64) if return_fp64 else (o_val,)
         # PPR with the cache empty: the Laplacian in fp64 first (o_val is scratch for its fp32 rounding), then the mix below
         hat64 = torch.empty(m, dtype=torch.float64, device=dev)
@@ -790,6 +831,7 @@ def hop_lincomb(feats, weights, outs=None):
     with torch.cuda.device(feats[0].device):
         check(lib().sgl_hop_lincomb_f32(len(feats), ptrs, lds, n_out, optrs, olds, ptr(w), int(w.stride(0)), n, dw, current_stream_ptr()),
               "sgl_hop_lincomb_f32")
+    _wrote(*outs)
     return outs
 
 
@@ -1309,6 +1351,7 @@ def nafs_prefix(feats, emit_hops, outs=None, combine=NAFS_STORE, divisor=1.0, ou
     with torch.cuda.device(feats[0].device):
         check(lib().sgl_nafs_prefix_f32(len(feats), ptrs, lds, mask, optrs, olds, pad, int(combine), float(divisor), n, d,
                                         current_stream_ptr()), "sgl_nafs_prefix_f32")
+    _wrote(*outs)
     return outs
 
 
@@ -1329,6 +1372,7 @@ def scatter_rows(x, src, dst, out):
     with torch.cuda.device(x.device):
         check(lib().sgl_scatter_rows_f32(ptr(x), _ld(x), x.shape[0], ptr(src), ptr(dst), src.numel(), ptr(out), _ld(out),
                                          out.shape[0], x.shape[1], current_stream_ptr()), "sgl_scatter_rows_f32")
+    _wrote(out)
     return out
 
 
@@ -1402,4 +1446,5 @@ def gather_rows(x, idx, out=None):
     with torch.cuda.device(x.device):
         check(lib().sgl_gather_rows_padded_f32(ptr(x), _ld(x), n_rows, ptr(idx), idx.numel(), ptr(out), _ld(out), d, pad,
                                                current_stream_ptr()), "sgl_gather_rows_padded_f32")
+    _wrote(out)
     return out

@@ -168,9 +168,12 @@ class SharedHops:
                 del self._memo[q]
         return key
 
-    def data_key(self, adj, feature):
+    def data_key(self, adj, feature, device=None):
+        """key of (adjacency content, feature content, target device): hop lists live on ONE device and are handed out as they are,
+        so an operator on cuda:1 must not be served a chain that lives on cuda:0"""
         import hashlib
-        return hashlib.blake2b(repr((_lib.lib().sgl_version(), self._content(adj), self._content(feature))).encode(), digest_size=16).hexdigest()
+        return hashlib.blake2b(repr((_lib.lib().sgl_version(), self._content(adj), self._content(feature), str(device))).encode(),
+                               digest_size=16).hexdigest()
 
     def _touch(self, k):
         self.clock += 1

@@ -64,15 +64,36 @@ class BaseSGAPModel(nn.Module):
     # sgl/tasks/node_classification_dist.py:69, sgl/search/auto_search_dist.py:80).  When preprocess() folded the aggregation into
     # the SpMM epilogue no hop list was kept; it is then produced ON DEMAND, the first time somebody asks for it.
     # A read must not silently trigger K SpMMs over matrices that were folded precisely because the K+1 hop matrices would not fit:
-    # the lazy path only runs when they take at most half of the free device memory.  Otherwise the read RAISES, deterministically
-    # and with the way out in the message (materialize_hops(force=True)) -- never None: the reference-compatible readers would fail
-    # later with an opaque TypeError, and the same model would read as a list or as None depending on the allocator's state.
+    # the lazy path only runs when they take at most half of the free device memory.  Otherwise the read gives None -- what the
+    # reference's plain attribute holds before preprocess(), so hasattr(), inspect.getmembers() and `is None` probes behave -- and
+    # says so ONCE in a warning that names the way out; materialize_hops() is the explicit request and raises instead, and
+    # hops_available() is the query that never computes anything.
     @property
     def _processed_feat_list(self):
         hops = self.__dict__.get("_hop_list")
         if hops is None and self.__dict__.get("_hop_source") is not None:
-            hops = self.materialize_hops()          # raises RuntimeError when the hop matrices would not fit
+            if not self._hops_fit():
+                if not self.__dict__.get("_hop_warned"):
+                    import warnings
+                    self.__dict__["_hop_warned"] = True
+                    warnings.warn("_processed_feat_list: the aggregation of the last preprocess() was folded into the propagation and the "
+                                  "K+1 hop matrices would take more than half of the free device memory (or the device could not report "
+                                  "it), so none were produced and the attribute reads as None; call model.materialize_hops(force=True) "
+                                  "to propagate them anyway, or set sgl_amd.config.fuse_aggregate = False before preprocess()",
+                                  RuntimeWarning, stacklevel=2)
+                return None
+            hops = self.materialize_hops()
         return hops
+
+    def hops_available(self):
+        """'kept' (the hop list exists), 'lazy' (folded preprocess: a read of _processed_feat_list would propagate them now and
+        they fit), 'too_large' (folded, and they would not fit: the attribute reads as None, materialize_hops(force=True)
+        overrides) or 'none' (preprocess() has not run / no graph operator).  Never computes anything."""
+        if self.__dict__.get("_hop_list") is not None:
+            return "kept"
+        if self.__dict__.get("_hop_source") is None:
+            return "none"
+        return "lazy" if self._hops_fit() else "too_large"
 
     def materialize_hops(self, force=False):
         """The hop list [X, A_hat X, ..., A_hat^K X] of the last preprocess() when its aggregation was folded into the SpMM

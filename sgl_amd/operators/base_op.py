@@ -20,10 +20,10 @@ class AdjIdentity:
     threads, about a gigabyte in a few tens of milliseconds, no optional dependency), buffer addresses -- so any in-place edit
     of a cached matrix is noticed."""
 
-    def __init__(self, adj):
+    def __init__(self, adj, on_death=None):
         import weakref
         try:
-            self._ref = weakref.ref(adj)
+            self._ref = weakref.ref(adj, on_death) if on_death is not None else weakref.ref(adj)
         except TypeError:
             self._ref = None
         self._strong = adj if self._ref is None else None
@@ -43,19 +43,48 @@ class AdjIdentity:
         return ("device", tuple(adj.shape), int(adj.nnz), adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr(),
                 adj.rowptr._version, adj.col._version, adj.val._version)
 
+    def holds(self, adj):
+        return (self._ref() if self._ref is not None else self._strong) is adj
+
     def matches(self, adj):
         held = self._ref() if self._ref is not None else self._strong
         return held is adj and self._print == self.fingerprint(adj)
 
 
-_GRAPHS = []            # at most two entries: (AdjIdentity, device string, PreparedAdjacency)
+_GRAPHS = []            # (AdjIdentity, device string, PreparedAdjacency), least recently used first
+
+
+def _prune_dead(_ref=None):
+    """weak-reference callback of a cached matrix: its preparation goes the moment the matrix does"""
+    _GRAPHS[:] = [e for e in _GRAPHS if e[0]._ref is None or e[0]._ref() is not None]
+
+
+def _cache_bytes():
+    return sum(e[2].nbytes() for e in _GRAPHS)
+
+
+def _enforce_budget(keep=None):
+    """stay under config.cache_prepared_gb: cached fp64 Laplacians go first, then whole entries, least recently used first"""
+    budget = config.cache_prepared_gb * 2 ** 30
+    if _cache_bytes() <= budget:
+        return
+    for e in _GRAPHS:
+        e[2].drop_values()
+    while len(_GRAPHS) > 0 and _cache_bytes() > budget:
+        victim = next((i for i, e in enumerate(_GRAPHS) if e[2] is not keep), None)
+        if victim is None:
+            break
+        del _GRAPHS[victim]
 
 
 def prepared_graph(adj, device=None):
     """device.PreparedAdjacency of `adj` (scipy sparse matrix or sgl_amd.io.DeviceAdjacency), shared process-wide between all
     operators over the same matrix object with unchanged contents (AdjIdentity: object identity + full content hashes / device
-    buffer versions).  Holds the device copy of A and A + I in fp64 (24 bytes per non-zero) for the two most recently used
-    graphs while they are alive; clear_graph_cache() releases them, sgl_amd.config.cache_prepared = False turns the sharing off."""
+    buffer versions).  A cached entry holds A + I in fp64 and the degrees (12 bytes per non-zero).  The cache is bounded by
+    config.cache_prepared_gb: a preparation that alone would exceed it is returned WITHOUT being kept (`prep.cached` False: the
+    caller's reference is the only one, so it is freed before the hop matrices are allocated), older entries are evicted to make
+    room, and an entry dies with its matrix.  clear_graph_cache() releases everything, config.cache_prepared = False turns the
+    sharing off."""
     from .. import _lib
     from ..io import DeviceAdjacency
     from .utils import canonical_csr
@@ -64,7 +93,7 @@ def prepared_graph(adj, device=None):
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())     # "cuda" and "cuda:0" are the same place
     key = str(device)
-    _GRAPHS[:] = [e for e in _GRAPHS if e[0]._ref is None or e[0]._ref() is not None]      # matrices that are gone
+    _prune_dead()
     for i, (ident, dkey, prep) in enumerate(_GRAPHS):
         if dkey == key and ident.matches(adj):
             _GRAPHS.append(_GRAPHS.pop(i))
@@ -79,9 +108,13 @@ def prepared_graph(adj, device=None):
         rowptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(device)
         col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
         val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+    # the same object with other contents (edited in place since it was prepared): its old preparation can never be served again
+    _GRAPHS[:] = [e for e in _GRAPHS if not (e[1] == key and e[0].holds(adj))]
     prep = dev.PreparedAdjacency(rowptr, col, val, n)
-    _GRAPHS.append((AdjIdentity(adj), key, prep))
-    del _GRAPHS[:-2]
+    prep.cached = prep.nbytes() <= config.cache_prepared_gb * 2 ** 30
+    if prep.cached:
+        _GRAPHS.append((AdjIdentity(adj, on_death=_prune_dead), key, prep))
+        _enforce_budget(keep=prep)
     return prep
 
 
@@ -152,7 +185,13 @@ class GraphOp:
             # the (r, alpha)-independent part of the normalisation -- the device copy of A, A + I in fp64, the degrees, the symmetry
             # check -- is shared by EVERY operator over the same matrix (prepared_graph below): a PaSca-style search builds a fresh
             # GraphOp per trial (sgl/search/search_models.py:19-46) and pays one scaling pass per trial instead of upload + preparation
-            rowptr, col, val = prepared_graph(adj, self._opt("device")).normalize(r, alpha)
+            prep = prepared_graph(adj, self._opt("device"))
+            rowptr, col, val = prep.normalize(r, alpha)
+            if not config.keep_sweep_values:
+                prep.drop_values()                 # the fp64 Laplacian a PPR request leaves behind (8 bytes per non-zero)
+            elif prep.cached:
+                _enforce_budget(keep=prep)
+            del prep
         elif isinstance(adj, DeviceAdjacency):   # already on the device (sgl_amd.io ingest): nothing touches the host
             rowptr, col, val = dev.normalize_adj(adj.rowptr, adj.col, adj.val, adj.shape[0], r, alpha)
         else:
@@ -287,7 +326,7 @@ class GraphOp:
             self._checked(adj, feature)
             from ..hopcache import SHARED
             r, alpha = self._norm_params()
-            dkey = SHARED.data_key(adj, feature)
+            dkey = SHARED.data_key(adj, feature, self._adj.device)
             strict = bool(self._opt("strict_order"))
             hops = SHARED.lookup(dkey, type(self).__name__, r, alpha, self._prop_steps, strict)
             if hops is None and alpha is not None and not strict:

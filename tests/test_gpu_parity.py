@@ -485,6 +485,48 @@ def test_operators_over_one_matrix_share_its_preparation(goldens, cuda):
     gc.collect()
     base_op.prepared_graph(g, cuda)
     assert len(base_op._GRAPHS) == 1                                    # the entry of the matrix that is gone was dropped
+    # an entry dies WITH its matrix (weak-reference callback), not at the next lookup
+    g3 = g.copy()
+    LaplacianGraphOp(1).propagate(g3, x)
+    assert len(base_op._GRAPHS) == 2
+    del g3
+    gc.collect()
+    assert len(base_op._GRAPHS) == 1
+    # what stays resident: A + I in fp64 + degrees (12 bytes per non-zero + 16 per row), the raw copy of a symmetric matrix is
+    # released, and the fp64 Laplacian a PPR request leaves behind is dropped unless a sweep is asked for (config.keep_sweep_values)
+    prep = base_op._GRAPHS[0][2]
+    m = prep.nnz_out
+    base_bytes = m * 12 + (2000 + 1) * 8 + 2000 * 8
+    assert prep.src is None and prep.cached and prep.nbytes() in (base_bytes, base_bytes + 2000 * 8)   # (+ the diagonal positions a PPR request leaves)
+    PprGraphOp(1, r=0.5, alpha=0.2).propagate(g, x)
+    assert prep.__dict__.get("_hat64") is None
+    config.keep_sweep_values = True
+    try:
+        PprGraphOp(1, r=0.5, alpha=0.2).propagate(g, x)
+        assert prep.__dict__["_hat64"] is not None and prep.nbytes() >= m * 20
+        v64 = prep.normalize(0.5, None, return_fp64=True)[3]
+        v64.zero_()                                                      # a caller's edit of what it was handed ...
+        y_ppr = PprGraphOp(1, r=0.5, alpha=0.2, strict_order=True).propagate(g, x)[1]
+        ref = oracle.propagate((g1["pl2000|indptr"], g1["pl2000|indices"], g1["pl2000|ppr|0.5|0.2"].astype(np.float32)), x, 1)[1]
+        assert np.array_equal(y_ppr.cpu().numpy(), ref)                  # ... never reaches the cached Laplacian
+    finally:
+        config.keep_sweep_values = False
+    # the byte budget: a preparation that alone exceeds it is handed out but NOT kept (transient, as before the cache existed);
+    # under a budget that fits one entry the least recently used one is evicted
+    base_op.clear_graph_cache()
+    old = config.cache_prepared_gb
+    try:
+        config.cache_prepared_gb = 1e-6
+        big = LaplacianGraphOp(2, r=0.5, strict_order=True).propagate(g, x)
+        assert not base_op._GRAPHS and all(torch.equal(a_, b_) for a_, b_ in zip(big, hops[0]))
+        assert base_op.prepared_graph(g, cuda).cached is False
+        config.cache_prepared_gb = base_bytes * 1.5 / 2 ** 30
+        g4_, g5_ = g.copy(), g.copy()
+        p4 = base_op.prepared_graph(g4_, cuda)
+        p5 = base_op.prepared_graph(g5_, cuda)
+        assert p4.cached and p5.cached and len(base_op._GRAPHS) == 1 and base_op._GRAPHS[0][2] is p5
+    finally:
+        config.cache_prepared_gb = old
     base_op.clear_graph_cache()
     assert not base_op._GRAPHS
     config.cache_prepared = False
@@ -836,7 +878,8 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     mb.preprocess(a, x)
     assert len(mb._processed_feat_list) == 4 and torch.equal(mb._processed_feature, mu._processed_feature)
     # the inputs kept for the lazy list do not travel with a pickled / copied model, and a list that would not fit is never produced
-    # by an incidental read: the read raises (never None), materialize_hops() refuses unless forced
+    # by an incidental read: the read gives None like the reference's attribute before preprocess() (hasattr / getmembers / `is None`
+    # probes must not raise) and warns ONCE with the way out; materialize_hops() is the explicit request and refuses unless forced
     import copy
     import pickle
     mc = SGC(3, d, 5)
@@ -845,13 +888,20 @@ def test_fused_aggregation_in_the_spmm_epilogue(goldens, cuda, d):
     for clone in (copy.deepcopy(mc), pickle.loads(pickle.dumps(mc))):
         assert clone.__dict__["_hop_source"] is None and clone._processed_feat_list is None
         assert torch.equal(clone._processed_feature.cpu(), mc._processed_feature.cpu())
+    assert mc.hops_available() == "lazy"
     mc._hops_fit = lambda: False
-    with pytest.raises(RuntimeError, match="materialize_hops"):          # never None: a deterministic error that names the way out
-        mc._processed_feat_list
+    assert mc.hops_available() == "too_large"
+    with pytest.warns(RuntimeWarning, match="materialize_hops"):         # said once, with the way out
+        assert mc._processed_feat_list is None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # ... and only once
+        assert mc._processed_feat_list is None and hasattr(mc, "_processed_feat_list")
     assert mc.__dict__["_hop_list"] is None
     with pytest.raises(RuntimeError):
         mc.materialize_hops()
-    assert len(mc.materialize_hops(force=True)) == 4 and mc._processed_feat_list is not None
+    assert len(mc.materialize_hops(force=True)) == 4 and mc._processed_feat_list is not None and mc.hops_available() == "kept"
+    assert SGC(3, d, 5).hops_available() == "none"
 
 
 def test_host_output_from_the_pinned_pool_keeps_the_contract(goldens, cuda):
@@ -2591,6 +2641,100 @@ def test_bench_single_gpu_line_validates_itself(cuda, monkeypatch):
     bench.run(args, engine_cls=Corrupting, workloads=tiny, emit=lines.append)
     j = json.loads(lines[0])
     assert j["config"]["validated"] is False and j["config"]["validation"]["sampled_rows_fp64_ok"] is False and j["value"] > 0
+
+
+def test_library_writes_bump_tensor_versions(goldens, cuda):
+    """the library writes into caller tensors through raw pointers; every wrapper then bumps the tensor's torch version counter
+    (device._wrote), so that (data_ptr, _version)-keyed memos -- hopcache.SharedHops' content key, degree_powers' cache -- and
+    autograd's saved-tensor checks see the write: a feature buffer refilled by a kernel between two propagate() calls maps to a NEW
+    key under share_hops, and the hop store keys on the device the chain lives on"""
+    from sgl_amd import config
+    from sgl_amd.hopcache import SHARED
+    from sgl_amd.operators.graph_op import LaplacianGraphOp
+    g = goldens.graph("pl2000")
+    n, d = 2000, 16
+    ptr_, col_, val_ = oracle.laplacian_adj(g.indptr, g.indices, g.data, n, 0.5)
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(cuda)  # noqa: E731
+    csr = dev.DeviceCSR(to(ptr_, np.int64), to(col_, np.int32), to(val_, np.float32), (n, n))
+    x = torch.from_numpy(hash_matrix(n, d, seed=1)).to(cuda)
+    out, acc = torch.zeros_like(x), torch.zeros_like(x)
+
+    def bumped(t, fn):
+        v = t._version
+        fn()
+        return t._version > v
+    assert bumped(out, lambda: csr.spmm(x, out=out))
+    assert bumped(acc, lambda: csr.spmm_acc(x, out, acc))
+    outs = [torch.zeros_like(x) for _ in range(2)]
+    assert bumped(outs[1], lambda: csr.spmm_chain(x, 2, outs=outs))
+    assert bumped(out, lambda: csr.spmm_axpb_clamp(x, 0.5, out=out))
+    idx = torch.arange(0, n, 7, device=cuda)
+    sub = torch.zeros((idx.numel(), d), device=cuda)
+    assert bumped(sub, lambda: dev.gather_rows(x, idx, out=sub))
+    big = torch.zeros_like(x)
+    assert bumped(big, lambda: dev.scatter_rows(x, idx, idx, big))
+    mixed = [torch.zeros_like(x)]
+    assert bumped(mixed[0], lambda: dev.hop_lincomb([x, out], np.array([[0.25, 0.75]]), outs=mixed))
+    graph = csr.capture_chain(x, outs)
+    assert bumped(outs[0], graph.replay)
+    # the hop store: a kernel-refilled feature buffer is another key; the device is part of the key
+    old = config.share_hops
+    config.share_hops = True
+    try:
+        SHARED.entries.clear()
+        feat = x.clone()
+        op = LaplacianGraphOp(2)
+        h1 = op.propagate(g, feat)
+        k1 = SHARED.data_key(g, feat, cuda)
+        dev.gather_rows(x, torch.arange(n - 1, -1, -1, device=cuda), out=feat)        # refilled in place by a library kernel
+        assert SHARED.data_key(g, feat, cuda) != k1
+        h2 = LaplacianGraphOp(2).propagate(g, feat)
+        ref = oracle.propagate((ptr_, col_, val_), feat.cpu().numpy(), 2)
+        assert oracle.parity_ok(h2[2].cpu().numpy(), ref[2], TOL) and not torch.equal(h1[2], h2[2])
+        assert SHARED.data_key(g, feat, "cuda:1") != SHARED.data_key(g, feat, "cuda:0")
+    finally:
+        config.share_hops = old
+        SHARED.entries.clear()
+
+
+def test_model_written_against_the_reference_names_runs_on_the_alias(goldens, cuda):
+    """sgl_amd.compat.install(): a model whose source uses only the REFERENCE's module names (the body of sgl/models/homo/gamlp.py:1-13
+    and sgc.py:1-13, typed here -- the reference's files themselves do not exist on this box; tests/test_host_cpu.py loads them
+    where they do) preprocesses and predicts on the GPU and reproduces the logits recorded from the reference (G4)."""
+    from sgl_amd import compat
+    try:
+        compat.install()
+        from sgl.models.base_model import BaseSGAPModel
+        from sgl.models.simple_models import LogisticRegression, MultiLayerPerceptron
+        from sgl.operators.graph_op import LaplacianGraphOp
+        from sgl.operators.message_op import LastMessageOp, LearnableWeightedMessageOp
+
+        class SGC(BaseSGAPModel):
+            def __init__(self, prop_steps, feat_dim, output_dim):
+                super(SGC, self).__init__(prop_steps, feat_dim, output_dim)
+                self._pre_graph_op = LaplacianGraphOp(prop_steps, r=0.5)
+                self._pre_msg_op = LastMessageOp()
+                self._base_model = LogisticRegression(feat_dim, output_dim)
+
+        class GAMLP(BaseSGAPModel):
+            def __init__(self, prop_steps, feat_dim, output_dim, hidden_dim, num_layers):
+                super(GAMLP, self).__init__(prop_steps, feat_dim, output_dim)
+                self._pre_graph_op = LaplacianGraphOp(prop_steps, r=0.5)
+                self._pre_msg_op = LearnableWeightedMessageOp(0, prop_steps + 1, "jk", prop_steps, feat_dim)
+                self._base_model = MultiLayerPerceptron(feat_dim, hidden_dim, num_layers, output_dim)
+        g4 = goldens.npz("g4_models")
+        g = goldens.graph("pl2000")
+        x = hash_matrix(2000, 16, seed=4242)
+        for name, model in (("SGC", SGC(3, 16, 5)), ("GAMLP", GAMLP(3, 16, 5, 32, 2))):
+            model.load_state_dict({k.split("|param|")[1]: torch.from_numpy(v) for k, v in g4.items() if k.startswith(name + "|param|")})
+            model = model.to(cuda).eval()
+            model.preprocess(g, x)
+            with torch.no_grad():
+                y = model.model_forward(g4["idx"], cuda)
+            rep = oracle.parity_report(y.cpu().numpy(), g4[f"{name}|out"], TOL, rowwise=False)
+            assert rep["ok"], (name, rep)
+    finally:
+        compat.uninstall()
 
 
 def test_bench_secondary_sections_cover_every_baseline_config(cuda, monkeypatch, tmp_path):

@@ -632,3 +632,114 @@ def test_shared_slope_prelu_is_nn_prelu_with_another_backward():
     with torch.no_grad():
         assert torch.equal(ours(x), ref(x))
     assert "_MultiLayerPerceptron__prelu.weight" in MultiLayerPerceptron(4, 8, 2, 3).state_dict()
+
+
+# ---- `sgl` namespace alias (sgl_amd/compat.py): the reference's model files consume the path unchanged --------------------------
+REFERENCE_ROOT = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE_ROOT, "sgl", "models", "homo")),
+                    reason="needs the reference checkout (build container only; nothing of it is copied or shipped)")
+def test_reference_model_files_run_unchanged_on_the_sgl_alias(goldens, monkeypatch):
+    """sgl_amd.compat.install(reference_root) registers sgl.operators[.graph_op / .message_op / .base_op / .utils],
+    sgl.models.base_model and sgl.models.simple_models as aliases of the sgl_amd modules; the ten files of the reference's
+    sgl/models/homo/ are then imported AS THEY ARE (their four import lines, e.g. sgc.py:1-4, resolve to sgl_amd) and the classes
+    they define -- the reference's own code objects -- are built on sgl_amd operators: same state_dict keys as the golden record G4
+    (recorded from the reference's own classes), G4's parameters load, and with the oracle's pre-propagation result in place of the
+    GPU's the logits equal G4's (models whose aggregator is not learnable; the learnable ones aggregate per batch with the HIP
+    kernels and fail loudly here, where there is no GPU)."""
+    import inspect
+    import sys
+    import oracle
+    from inputs import hash_matrix
+    from sgl_amd import compat
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)            # the reference tree is read-only
+    assert not any(k == "sgl" or k.startswith("sgl.") for k in sys.modules)
+    try:
+        names = compat.install(REFERENCE_ROOT)
+        assert set(names) == {"sgl.operators", "sgl.operators.base_op", "sgl.operators.utils", "sgl.operators.graph_op",
+                              "sgl.operators.message_op", "sgl.models.base_model", "sgl.models.simple_models"}
+        import sgl.operators.graph_op as ref_named
+        import sgl_amd.operators.graph_op as ours
+        assert ref_named is ours
+        from sgl.operators.message_op import LearnableWeightedMessageOp as L1
+        from sgl_amd.operators.message_op import LearnableWeightedMessageOp as L2
+        assert L1 is L2
+        g4 = goldens.npz("g4_models")
+        g = goldens.graph("pl2000")
+        n, d, C, K = 2000, 16, 5, 3
+        x = hash_matrix(n, d, seed=4242)
+        hops = oracle.propagate(oracle.laplacian_adj(g.indptr, g.indices, g.data, n, 0.5), x, K)
+        folded = {"SGC": oracle.agg_last(hops), "SSGC": oracle.agg_mean(hops, 0, K + 1), "SIGN": oracle.agg_concat(hops, 0, K + 1),
+                  "GBP": oracle.agg_simple_weighted(hops, 0, K + 1, "alpha", 0.85), "NAFS": oracle.agg_over_smooth_distance(hops)}
+        ctor = {"SGC": (K, d, C), "SSGC": (K, d, C), "SIGN": (K, d, C, 32, 2), "GBP": (K, d, C, 32, 2),
+                "GAMLP": (K, d, C, 32, 2), "GAMLPRecursive": (K, d, C, 32, 2), "NAFS": (K, d, C),
+                "PASCA_V1": (K, d, C, 32, 3), "PASCA_V2": (K, d, C, 32, 3), "PASCA_V3": (K, 2, d, C, 32, 3)}
+        idx = g4["idx"]
+        for name, args in ctor.items():
+            cls = compat.load_reference_model(name, REFERENCE_ROOT)
+            assert inspect.getsourcefile(cls).startswith(REFERENCE_ROOT + "/sgl/models/homo/"), name      # the reference's file, unchanged
+            assert cls.__mro__[1].__module__ == "sgl_amd.models.base_model", name
+            model = cls(*args)
+            assert type(model._pre_graph_op).__module__.startswith("sgl_amd.operators.graph_op"), name
+            assert type(model._pre_msg_op).__module__.startswith("sgl_amd.operators.message_op"), name
+            keys = sorted(k.split("|param|")[1] for k in g4 if k.startswith(name + "|param|"))
+            assert sorted(model.state_dict().keys()) == keys, name
+            model.load_state_dict({k.split("|param|")[1]: torch.from_numpy(v) for k, v in g4.items() if k.startswith(name + "|param|")})
+            model.eval()
+            if name in folded:
+                model._pre_msg_learnable = False
+                model._processed_feature = torch.from_numpy(np.ascontiguousarray(folded[name]))
+                with torch.no_grad():
+                    y = model.model_forward(idx, torch.device("cpu"))
+                assert oracle.parity_ok(y.numpy(), g4[f"{name}|out"], 1e-5, rowwise=False), name
+            elif not has_gpu():
+                model._pre_msg_learnable = True
+                model._processed_feat_list = [torch.from_numpy(h) for h in hops]
+                with pytest.raises(_lib.SglHipError):
+                    model.model_forward(idx, torch.device("cpu"))
+        with pytest.raises(FileNotFoundError):
+            compat.install("/nonexistent/checkout")
+    finally:
+        compat.uninstall()
+    assert not any(k == "sgl" or k.startswith("sgl.") for k in sys.modules)
+
+
+def test_sgl_alias_without_a_reference_checkout():
+    """install() with no reference_root: the operator / base-model modules under their reference names, nothing else; a model written
+    against the reference's API (the body of sgl/models/homo/sgc.py:7-13, typed here) builds on them; a real `sgl` that is already
+    imported is not silently shadowed"""
+    import sys
+    import types
+    from sgl_amd import compat
+    try:
+        compat.install()
+        from sgl.models.base_model import BaseSGAPModel
+        from sgl.models.simple_models import LogisticRegression
+        from sgl.operators.graph_op import LaplacianGraphOp
+        from sgl.operators.message_op import LastMessageOp
+
+        class MySGC(BaseSGAPModel):
+            def __init__(self, prop_steps, feat_dim, output_dim):
+                super(MySGC, self).__init__(prop_steps, feat_dim, output_dim)
+                self._pre_graph_op = LaplacianGraphOp(prop_steps, r=0.5)
+                self._pre_msg_op = LastMessageOp()
+                self._base_model = LogisticRegression(feat_dim, output_dim)
+        m = MySGC(2, 8, 3)
+        assert type(m._pre_graph_op).__module__.startswith("sgl_amd.") and sys.modules["sgl"].__sgl_amd_shell__
+        with pytest.raises(ModuleNotFoundError):
+            import sgl.models.homo.sgc  # noqa: F401  (no checkout was named: the shells have an empty path)
+    finally:
+        compat.uninstall()
+    fake = types.ModuleType("sgl")
+    sys.modules["sgl"] = fake
+    try:
+        with pytest.raises(RuntimeError):
+            compat.install()
+        compat.install(force=True)
+        assert sys.modules["sgl.operators.graph_op"].__name__ == "sgl_amd.operators.graph_op" and sys.modules["sgl"] is fake
+    finally:
+        compat.uninstall()
+        sys.modules.pop("sgl", None)
+        for k in [k for k in sys.modules if k.startswith("sgl.")]:
+            del sys.modules[k]
