@@ -1172,6 +1172,60 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     }
 }
 
+// out_h[i,:] = X_h[idx[i],:] for EVERY hop matrix h in one launch (the training feed of the learnable aggregators,
+// models/base_model.py:58-60: the same rows of all K + 1 hop matrices).  A thread owns one 16-byte vector of U rows: it loads the
+// U indices ONCE and then, per batch of HB hops, issues HB x U independent row loads before the HB x U stores -- the memory-level
+// parallelism of U x HB rows per thread for U index loads and U x HB vector registers, in one launch whose grid does not shrink with H.
+template <int LPR, int U, int HB>
+__global__ __launch_bounds__(256) void gather_hops_kernel(const Hops hx, const HopsOut ho, const int n_hops, const int64_t n_rows,
+                                                          const int64_t *__restrict__ idx, const int64_t n_idx, const int d,
+                                                          const int dz) {
+    constexpr int RPB = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int64_t i0 = (int64_t)blockIdx.x * (RPB * U) + threadIdx.x / LPR;
+    int64_t src[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * RPB;
+        int64_t s = i < n_idx ? idx[i] : 0;
+        if (s < 0) s += n_rows;
+        if (s < 0 || s >= n_rows) __builtin_trap();
+        src[u] = s;
+    }
+    for (int c = l * 4; c < d; c += LPR * 4) {
+        for (int hb = 0; hb < n_hops; hb += HB) {
+            f4 v[HB][U];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int h = hb + k < n_hops ? hb + k : n_hops - 1;      // (clamped: the surplus loads of the last batch are dropped below)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c < dz) {
+                        v[k][u] = *reinterpret_cast<const f4 *>(hx.p[h] + src[u] * hx.ld[h] + c);
+                        if (c + 4 > dz) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e >= dz) v[k][u][e] = 0.f;
+                        }
+                    } else {
+                        v[k][u] = (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                if (hb + k < n_hops) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int64_t i = i0 + (int64_t)u * RPB;
+                        if (i < n_idx) __builtin_nontemporal_store(v[k][u], reinterpret_cast<f4 *>(ho.p[hb + k] + i * ho.ld[hb + k] + c));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // out[:, h*d + k] = X_h[:, k]
 template <int VEC>
 __global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
@@ -2260,6 +2314,71 @@ SGL_EXPORT int sgl_gather_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows
 SGL_EXPORT int sgl_gather_rows_padded_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_idx, int64_t n_idx,
                                           float *d_out, int64_t ldo, int64_t d, int64_t pad_cols, void *stream) {
     return copy_rows("sgl_gather_rows_padded_f32", d_x, ldx, n_rows, d_idx, nullptr, n_idx, n_idx, d_out, ldo, d, pad_cols, stream);
+}
+
+// The same rows of EVERY hop matrix in one launch (gather_hops_kernel): out_h = X_h[idx] for h < n_hops, all X_h with n_rows rows,
+// all outputs with n_idx rows; columns [d, d + pad_cols) of the output rows are written as zeros (the destination's own padding).
+// Needs 16-byte aligned rows and pitches that are multiples of 4 floats on both sides (else SGL_ERR_UNSUPPORTED: gather hop by hop).
+SGL_EXPORT int sgl_gather_hops_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, int64_t n_rows, const int64_t *d_idx,
+                                          int64_t n_idx, float *const *h_out, const int64_t *h_ldo, int64_t d, int64_t pad_cols, void *stream) {
+    SGL_REQUIRE(n_idx >= 0 && d >= 0 && pad_cols >= 0 && d + pad_cols < INT32_MAX && n_rows >= 0, "sgl_gather_hops_padded_f32: bad sizes");
+    if (n_idx == 0 || d == 0) return SGL_OK;
+    SGL_REQUIRE(d_idx && h_out && h_ldo, "sgl_gather_hops_padded_f32: NULL arguments");
+    Hops hx;
+    bool vec4 = true;
+    int rc = fill_hops(hx, n_hops, h_x, h_ldx, d, vec4);
+    if (rc != SGL_OK) return rc;
+    const int64_t dw = d + pad_cols;
+    HopsOut ho;
+    for (int h = 0; h < SGL_MAX_HOPS; ++h) {
+        ho.p[h] = h < n_hops ? h_out[h] : nullptr;
+        ho.ld[h] = h < n_hops ? h_ldo[h] : 0;
+        if (h < n_hops) {
+            SGL_REQUIRE(ho.p[h] && ho.ld[h] >= dw, "sgl_gather_hops_padded_f32: output %d: NULL or pitch < d + pad_cols", h);
+            if (ho.ld[h] % 4 != 0 || !aligned_to(ho.p[h], 16)) vec4 = false;
+        }
+    }
+    if (!vec4 || dw % 4 != 0) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_gather_hops_padded_f32: rows are not 16-byte vectors (gather hop by hop)");
+    hipStream_t st = sgl::as_stream(stream);
+    const int64_t nv = dw / 4;
+    int lpr = 64;
+    {
+        int64_t best = -1;
+        for (int cand : {64, 32, 16, 8}) {
+            const int64_t waste = (nv + cand - 1) / cand * cand - nv;
+            if (best < 0 || waste < best) {
+                best = waste;
+                lpr = cand;
+            }
+        }
+        if (sgl::tuning("gather_lpr", 0) > 0) lpr = (int)sgl::tuning("gather_lpr", 0);
+    }
+    const int rpb = 256 / lpr;
+    // one row per thread: with HB = 4 hops per batch a thread already keeps 4 independent row loads in flight, and the grid stays
+    // n_idx / rows-per-block workgroups whatever H is (measured, profiles/r06_gather_hops.log: 1 row 0.153 ms, 2 rows 0.158, 4 rows
+    // 0.164 for 200 000 rows of 4 hops at d = 100; hop by hop 0.162)
+    int u = (int)sgl::tuning("gather_rows_per_thread", 0);
+    if (u != 1 && u != 2 && u != 4) u = 1;
+    const int64_t blocks = (n_idx + (int64_t)rpb * u - 1) / ((int64_t)rpb * u);
+    if (!sgl::launch_fits(blocks, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_gather_hops_padded_f32: too many indices for one launch");
+#define SGL_GH(L, UU) hipLaunchKernelGGL((gather_hops_kernel<L, UU, 4>), dim3((unsigned)blocks), dim3(256), 0, st, hx, ho, n_hops, n_rows, d_idx, n_idx, (int)dw, (int)d)
+#define SGL_GHU(L)                   \
+    do {                             \
+        if (u == 1) SGL_GH(L, 1);    \
+        else if (u == 4) SGL_GH(L, 4); \
+        else SGL_GH(L, 2);           \
+    } while (0)
+    switch (lpr) {
+        case 8: SGL_GHU(8); break;
+        case 16: SGL_GHU(16); break;
+        case 32: SGL_GHU(32); break;
+        default: SGL_GHU(64); break;
+    }
+#undef SGL_GHU
+#undef SGL_GH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sgl::fail((int)e, "sgl_gather_hops_padded_f32: kernel launch failed: %s", hipGetErrorString(e));
+    return SGL_OK;
 }
 
 // out[dst[i], :] = X[src[i], :], i < n_idx (dst entries distinct; every index is range-checked in the kernel, which traps on a

@@ -1,7 +1,7 @@
 // Plan-time locality ordering (sgl_reorder_community): semi-synchronous label propagation on the device, then a stable
 // sort of the nodes by label.  Real co-purchase / citation graphs have communities; when their members are processed
 // close together, a gathered row of X fetched for one member is still in L2 / the Infinity Cache for the next
-// (tools/bench_reorder.py).  Not part of the per-hop path: runs once per adjacency.
+// (DESIGN.md K1 "Locality ordering", tools/bench_reorder.py).  Not part of the per-hop path: runs once per adjacency.
 //
 // One round: every node looks at (a strided sample of at most 256 of) its neighbours' labels and adopts the most
 // frequent one, ties to the smaller label.  One wavefront per node: the sampled labels sit in LDS, every lane counts

@@ -2,7 +2,7 @@
 // (reference: sgl/operators/base_op.py:29-35 -> csrc/matmul.c:23-40; successor of the dead cuSPARSE twin
 // csrc/cudamatmul.c:104-119).
 //
-// Design (see DESIGN.md "Kernel 1"):
+// Design:
 //   * the path is sparse x dense, ~0.5 flop/byte: HBM/cache bound, no MFMA;
 //   * one 64-lane wavefront owns one work item = a run of <= 63 whole rows holding ~item_nnz non-zeros
 //     (host-built plan, sgl_core.cpp); very long rows are cut into pieces whose partial sums are combined by a

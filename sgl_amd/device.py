@@ -1393,7 +1393,7 @@ def _device_index(idx, n_rows, device):
     return idx.to(device=device, dtype=torch.int64).contiguous().view(-1)
 
 
-def gather_hops(feats, idx):
+def gather_hops(feats, idx, one_launch=None):
     """[x[idx] for x in feats]: the training feed of the learnable aggregators, `[feat[idx].to(device) for feat in
     self._processed_feat_list]` (sgl/models/base_model.py:58-60), with the indices validated and uploaded ONCE for all hop
     matrices.  Host indices (what the reference's tasks pass) are where the time of the hop-by-hop form goes: 200 000 rows of 4 /
@@ -1407,7 +1407,37 @@ def gather_hops(feats, idx):
                     for f in feats)
     if same_rows:
         idx = _device_index(idx, feats[0].shape[0], feats[0].device)
+    one = _gather_hops_one_launch(feats, idx) if (same_rows and one_launch is not False and len(feats) > 1) else None
+    if one is not None:
+        return one
     return [gather_rows(x, idx) for x in feats]
+
+
+def _gather_hops_one_launch(feats, idx):
+    """sgl_gather_hops_padded_f32 when every hop matrix is a float32 [n, d] matrix of 16-byte rows (what propagate() returns), else None"""
+    n_rows, d = feats[0].shape
+    m = int(idx.numel())
+    dp = round_up(d, 4)
+    if m < 2 or n_rows < 2 or len(feats) > 16:
+        return None
+    for x in feats:
+        if not (x.dtype == torch.float32 and x.shape == (n_rows, d) and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) >= dp
+                and x.data_ptr() % 16 == 0 and x.untyped_storage().nbytes() // 4 - x.storage_offset() >= (n_rows - 1) * x.stride(0) + dp):
+            return None
+    outs = [alloc_rows(m, d, feats[0].device, zero_pad=False) for _ in feats]
+    ldo = outs[0].stride(0)
+    if ldo % 4 or ldo < dp or any(o.data_ptr() % 16 for o in outs):
+        return None
+    pad = (ldo - d) if ldo - d < 32 else (dp - d)
+    if pad != ldo - d:
+        for o in outs:
+            padded_parent(o)[:, d + pad:].zero_()
+    ptrs, lds = _lib.hop_arrays(feats)
+    optrs, olds = _lib.hop_arrays(outs)
+    with torch.cuda.device(feats[0].device):
+        check(lib().sgl_gather_hops_padded_f32(len(feats), ptrs, lds, n_rows, ptr(idx), m, optrs, olds, d, pad, current_stream_ptr()),
+              "sgl_gather_hops_padded_f32")
+    return outs
 
 
 def gather_rows(x, idx, out=None):

@@ -1,4 +1,4 @@
-"""Plan-time node ordering for locality: real co-purchase / citation graphs have communities, and a
+"""Plan-time node ordering for locality ("Locality ordering"): real co-purchase / citation graphs have communities, and a
 gathered row of X that was fetched for one member of a community is fetched again for the next -- if the members are processed
 close together it is still in L2 / the Infinity Cache.  A processing order that keeps communities together turns that into
 hits; ids as they come out of a dump carry no such order.

@@ -3208,6 +3208,18 @@ def test_gather_hops_uploads_the_indices_once(cuda, monkeypatch):
                 want = torch.from_numpy(host[h])[ref_idx]
                 assert got[h].shape == want.shape and torch.equal(got[h].cpu(), want), (n, d, H, type(idx), h)
                 assert not bool(dev.padded_parent(got[h])[:, d:].abs().sum())            # the outputs' own padding is zeros
+        # hop matrices of 16-byte rows (what propagate() returns) go through ONE launch for all hops (sgl_gather_hops_padded_f32: the
+        # indices are read once per row); bit-identical to the hop-by-hop form; packed odd widths and single matrices fall back
+        dv_idx = torch.from_numpy(np.where(picks < 0, picks + n, picks)).to(cuda)
+        one = dev._gather_hops_one_launch(feats, dv_idx) if H > 1 else None
+        assert (one is not None) == (H > 1), (n, d, H)                  # every multi-hop shape of this list is eligible
+        if one is not None:
+            per_hop = dev.gather_hops(feats, dv_idx, one_launch=False)
+            assert all(torch.equal(a_, b_) and torch.equal(dev.padded_parent(a_), dev.padded_parent(b_)) for a_, b_ in zip(one, per_hop))
+            for u_ in (2, 4):
+                _lib.set_tuning("gather_rows_per_thread", u_)
+                assert all(torch.equal(a_, b_) for a_, b_ in zip(dev._gather_hops_one_launch(feats, dv_idx), per_hop))
+            _lib.set_tuning("gather_rows_per_thread", 0)
     with pytest.raises(IndexError):
         dev.gather_hops(feats, [0, n])
     assert [tuple(t.shape) for t in dev.gather_hops(feats, [])] == [(0, 37)] and dev.gather_hops([], [1]) == []

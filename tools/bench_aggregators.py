@@ -95,6 +95,14 @@ def main():
         idx_host = idx.cpu().numpy()
         rep(f"gather 200k rows of {H} hops, hop by hop", timeit(lambda: [dev.gather_rows(f_, idx) for f_ in feats]), 2 * H * 200_000 * d * 4)
         rep(f"gather 200k rows of {H} hops, gather_hops", timeit(lambda: dev.gather_hops(feats, idx)), 2 * H * 200_000 * d * 4)
+        rep(f"gather 200k rows of {H} hops, gather_hops per hop", timeit(lambda: dev.gather_hops(feats, idx, one_launch=False)), 2 * H * 200_000 * d * 4)
+        for u_ in (1, 4):
+            _lib.set_tuning("gather_rows_per_thread", u_)
+            rep(f"gather 200k rows of {H} hops, gather_hops rows/thread={u_}", timeit(lambda: dev.gather_hops(feats, idx)), 2 * H * 200_000 * d * 4)
+        _lib.set_tuning("gather_rows_per_thread", 0)
+        g_one = dev.gather_hops(feats, idx)
+        g_ref = [dev.gather_rows(f_, idx) for f_ in feats]
+        print(f"AGG   one-launch gather bit-identical to hop by hop: {all(torch.equal(a_, b_) for a_, b_ in zip(g_one, g_ref))}", flush=True)
         rep(f"  ... host indices, hop by hop", timeit(lambda: [dev.gather_rows(f_, idx_host) for f_ in feats]), 2 * H * 200_000 * d * 4)
         rep(f"  ... host indices, gather_hops", timeit(lambda: dev.gather_hops(feats, idx_host)), 2 * H * 200_000 * d * 4)
         # the kernel alone: ten launches queued back to back into a preallocated output (the host's ~20 us per call -- allocation,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What a community-aware PARTITION would buy the need-aware exchange (a "what comes next" measurement, DESIGN.md section 8).
+"""What a community-aware PARTITION would buy the need-aware exchange (a "what comes next" measurement, DESIGN.md section 9).
 
 The row-sharded job cuts the node ids into G contiguous blocks.  With the need-aware exchange a rank receives only the rows its
 block references -- on a graph without structure (the benchmark graph) that is still 84 % of all foreign rows at G = 8.  Real
