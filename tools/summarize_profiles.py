@@ -57,7 +57,7 @@ if means:
     with open(os.path.join(dst, f"{tag}_{workload}_pmc_spmm_kernel.md"), "w") as f:
         f.write(f"# rocprofv3 PMC counters, {kname}, workload {workload}\n\n")
         f.write("Command per pass: `rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python bench.py "
-                f"--workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-papers` (one pass per counter group; means over "
+                f"--workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-papers --no-extras` (one pass per counter group; means over "
                 "the launches)\n\n")
         f.write(f"VGPR {regs[0]}, SGPR {regs[1]}, grid {regs[2]} threads, workgroup {regs[3]}\n\n")
         f.write("| counter | mean per launch | launches |\n|---|---|---|\n")
