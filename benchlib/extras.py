@@ -422,7 +422,10 @@ def section_s4_papers_shard(args, engine, parts=8):
         ok = _sampled_spmm_ok(engine, rowptr, col, val, n, x, hops[K], lo=lo, d=d)
         ok_all = ok_all and ok
         alg = nnz * d * 4 + nnz * 8 + (n_loc + 1) * 4 + n_loc * d * 4
+        ceiling = engine.gather_ceiling(col, x, d) if alpha is None else None       # the bare pattern of THIS block on THIS table, measured now
         row = {"graph_op": name, "normalise_block_ms": t_norm, "propagate_ms": t_prop, "ms_per_hop": t_prop / K,
+               "gather_ceiling_Ggathers_per_s": ceiling, "kernel_Ggathers_per_s": nnz / (t_prop / K * 1e-3) / 1e9,
+               "frac_of_gather_ceiling": (nnz / (t_prop / K * 1e-3) / 1e9 / ceiling) if ceiling else None,
                "value": nnz * d * K / (t_prop * 1e-3), "unit": "edge·featdim/s per GPU", "nnz_block": nnz,
                "roofline": _roof(alg, t_prop / K), "validated": ok}
         if alpha is None:
@@ -558,6 +561,7 @@ def compact_sections(sections):
                                              "gpu_rows_per_s": {k: _r(v) for k, v in cb["gpu_rows_per_s"].items()}}
             if name == "S4_papers_shard":
                 c["rows_block"] = s["rows_block"]
+                c["frac_of_gather_ceiling"] = _r(s["graph_ops"][0].get("frac_of_gather_ceiling"))
         elif name == "S1_community":
             ra = s["reorder_auto"]
             c.update({"reorder_none": {"ms_per_hop": _r(s["reorder_none"]["ms_per_hop"]), "frac": _r(s["reorder_none"]["roofline"]["frac"])},
