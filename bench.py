@@ -352,14 +352,35 @@ def run(args, engine_cls=None, workloads=None, emit=print):
         gc.collect()
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
-        extras_fn = None
+        # Nothing below may cost the headline: every step is fenced, a failure is recorded in the line instead of raised.
+        extras_fn, detail, t_x = None, {}, 0.0
+
+        def publish_sections():
+            if not (want_extras and rank == 0 and detail.get("sections")):
+                return
+            try:
+                # LAST key of the line and short on purpose (4 significant digits, tables as rows): whoever keeps only the tail of a
+                # long line still reads every section.  The complete dictionaries go to --detail-out.
+                out.pop("sections", None)
+                out["sections"] = compact_sections(detail["sections"])
+                if getattr(args, "detail_out", None):
+                    with open(args.detail_out, "w") as f:
+                        json.dump({"head": {k: out[k] for k in ("metric", "value", "ms_per_step", "n_gpus", "steps", "warmup")},
+                                   "sections": detail["sections"]}, f, indent=1)
+            except Exception as e:  # noqa: BLE001
+                out["sections"] = {"failed": f"could not render the sections: {e!r}"[:300]}
+
         if want_extras:
-            from benchlib.extras import compact_sections, run_extras as extras_fn
-            detail = {}
-            _phase("extras: S0 / S2 / S4_products / S1_community")
-            t_x = time.perf_counter()
-            extras_fn(args, engine, detail, budget_s=args.extras_budget, which=("S0_pubmed", "S2_gamlp", "S4_products", "S1_community"))
-            t_x = time.perf_counter() - t_x
+            try:
+                from benchlib.extras import compact_sections, run_extras as extras_fn
+                _phase("extras: S0 / S2 / S4_products / S1_community")
+                t_x = time.perf_counter()
+                extras_fn(args, engine, detail, budget_s=args.extras_budget, which=("S0_pubmed", "S2_gamlp", "S4_products", "S1_community"))
+                t_x = time.perf_counter() - t_x
+            except Exception as e:  # noqa: BLE001
+                out["secondary_sections_error"] = repr(e)[:300]
+                extras_fn = None
+            publish_sections()               # (the watchdog prints whatever is published if the papers100M section overruns)
         if want_papers:
             _phase("papers100M section")
             try:
@@ -369,18 +390,15 @@ def run(args, engine_cls=None, workloads=None, emit=print):
                 papers = {"failed": repr(e)[:200], "where": traceback.format_exc()[-700:]}
             if rank == 0:
                 out["papers100M"] = papers
-        if want_extras:
-            _phase("extras: S4_papers_shard")
-            gc.collect()
-            torch.cuda.empty_cache()
-            extras_fn(args, engine, detail, budget_s=args.extras_budget - t_x, which=("S4_papers_shard",))
-        if want_extras and rank == 0:
-            # LAST key of the line and short on purpose (4 significant digits, tables as rows): whoever keeps only the tail of a long
-            # line still reads every section.  The complete dictionaries go to --detail-out.
-            out["sections"] = compact_sections(detail["sections"])
-            if getattr(args, "detail_out", None):
-                with open(args.detail_out, "w") as f:
-                    json.dump({"head": {k: out[k] for k in ("metric", "value", "ms_per_step", "n_gpus", "steps", "warmup")}, "sections": detail["sections"]}, f, indent=1)
+        if want_extras and extras_fn is not None:
+            try:
+                _phase("extras: S4_papers_shard")
+                gc.collect()
+                torch.cuda.empty_cache()
+                extras_fn(args, engine, detail, budget_s=args.extras_budget - t_x, which=("S4_papers_shard",))
+            except Exception as e:  # noqa: BLE001
+                out["secondary_sections_error"] = repr(e)[:300]
+        publish_sections()                   # again: `sections` stays the LAST key whatever was added since
         done.set()
         timer.cancel()
     emit_line()

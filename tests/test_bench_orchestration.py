@@ -661,3 +661,47 @@ def test_planted_partition_generator_properties():
     rp2, col2, _, truth2 = sy.planted_partition_torch(n, m, 600, blk, 0.8, seed=3, device="cpu")
     assert torch.equal(rp, rp2) and torch.equal(col, col2) and torch.equal(truth, truth2)        # seeded
     assert int(truth.max()) == (n - 1) // blk and sy.WORKLOADS["S1_community"]["n"] == sy.WORKLOADS["S1_products"]["n"]
+
+
+def test_a_crash_in_the_secondary_sections_cannot_cost_the_headline(monkeypatch):
+    """bench.run: whatever happens after the timed region -- the section runner raising outright, a section failing, the renderer
+    choking on a malformed section -- the ONE line is printed with the measured value, and says what went wrong"""
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    import bench
+    from benchlib import extras
+
+    class WithSections(_make_engine()):
+        hashed_block = staticmethod(lambda *a, **k: None)        # (what marks an engine that can run the secondary sections)
+    workloads = {"S1_products": TINY["T_tiny"]}
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--workload", "S1_products", "--no-cpu-baseline", "--no-papers"])
+
+    def run(fn):
+        monkeypatch.setattr(extras, "run_extras", fn)
+        lines = []
+        bench.run(args, engine_cls=WithSections, workloads=workloads, emit=lines.append)
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    def boom(*a, **k):
+        raise RuntimeError("boom in the runner")
+    j = run(boom)
+    assert j["value"] > 0 and "boom in the runner" in j["secondary_sections_error"] and "sections" not in j
+
+    def one_bad_section(args_, engine, detail, budget_s=0, which=None):
+        sec = detail.setdefault("sections", {})
+        for name in which:
+            sec[name] = {"failed": "RuntimeError('section died')", "where": "traceback tail", "wall_s": 0.1}
+    j = run(one_bad_section)
+    assert j["value"] > 0 and list(j)[-1] == "sections" and "section died" in j["sections"]["S0_pubmed"]["failed"]
+    assert set(j["sections"]) == {"S0_pubmed", "S2_gamlp", "S4_products", "S1_community", "S4_papers_shard"}
+
+    def malformed(args_, engine, detail, budget_s=0, which=None):
+        detail.setdefault("sections", {})["S0_pubmed"] = {"workload": "S0_pubmed: x"}          # no ms / roofline: the renderer raises
+    j = run(malformed)
+    assert j["value"] > 0 and "could not render" in j["sections"]["failed"]
+    j = run(lambda *a, **k: None)                                                             # nothing produced: no key at all
+    assert j["value"] > 0 and "sections" not in j
+    args.no_extras = True
+    assert "sections" not in run(boom) and "secondary_sections_error" not in run(boom)        # --no-extras: the runner is never called
