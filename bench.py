@@ -110,6 +110,9 @@ def parse_args(argv=None):
                     help="file that receives the secondary sections in full (the line carries their short form)")
     ap.add_argument("--extras-scale", choices=("full", "small"), default=os.environ.get("SGL_BENCH_EXTRAS_SCALE", "full"),
                     help="small = the same sections on graphs that finish in seconds (tests)")
+    ap.add_argument("--reorder", choices=("community", "auto"), default=None,
+                    help="N = 1: process the rows of A_hat in a plan-time locality order (GraphOp(reorder=...): bit-identical results); "
+                         "auto keeps the order only when it makes the graph measurably more local (workload S1_community: yes; S1_products: no)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dup2", action="store_true",
                     help="edge weight 2.0 instead of 1.0: the reference's Ogbn loader symmetrises an already "

@@ -53,6 +53,8 @@ class _QuietStdout:
 WORKLOAD_TEXT = {
     "S0": "SGC prop_steps={K} pre-propagation on a Pubmed-sized Chung-Lu graph (BASELINE config 1), LaplacianGraphOp r=0.5",
     "S1": "SGC prop_steps={K} pre-propagation on an ogbn-products-shaped Chung-Lu graph (BASELINE config 2), LaplacianGraphOp r=0.5",
+    "S1_community": "SGC prop_steps={K} pre-propagation on the ogbn-products degree law WITH planted communities (4 096 nodes, p_in = 0.8) and "
+                    "shuffled node ids (secondary workload: what a locality ordering can find), LaplacianGraphOp r=0.5",
     "S2": "GAMLP label-reuse sized propagation (d=147, prop_steps={K}) on the ogbn-products-shaped graph (BASELINE config 3), "
           "LaplacianGraphOp r=0.5",
     "S3_papers_shard": "one rank's 1/8 row block of an ogbn-papers100M-shaped hashed graph against the full 111 M x 128 feature "

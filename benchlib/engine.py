@@ -130,6 +130,10 @@ class GpuEngine:
     def build_raw(self, args, wl):
         """the raw (un-normalised) symmetric adjacency A of a Chung-Lu workload on this device: (rowptr, col, val)"""
         from sgl_amd import synthetic
+        if wl.get("community"):          # the same degree law with planted communities and shuffled ids (S1_community)
+            cm = wl["community"]
+            return synthetic.planted_partition_torch(wl["n"], wl["m"], wl["d_max"], cm["block"], cm["p_in"], seed=args.seed, device=self.device,
+                                                     weight=2.0 if getattr(args, "dup2", False) else 1.0)[:3]
         return synthetic.chung_lu_torch(wl["n"], wl["m"], wl["d_max"], seed=args.seed, device=self.device,
                                         weight=2.0 if getattr(args, "dup2", False) else 1.0)
 
@@ -300,7 +304,19 @@ class GpuEngine:
 
     def single_step(self, args, rowptr, col, val, x0, n, d, K):
         from sgl_amd import device as dev
-        csr = dev.DeviceCSR(rowptr, col, val, (rowptr.numel() - 1, n), strict=args.strict)
+        reorder_info = None
+        if getattr(args, "reorder", None) and rowptr.numel() - 1 == n:
+            # plan-time locality ordering (GraphOp(reorder=...)): rows stored and processed community by community behind a row map;
+            # ids, X, Y and every row's term order untouched -- the validation below still recomputes rows of the ORIGINAL matrix
+            from sgl_amd.reorder import plan_rowmap
+            rowmap, reorder_info = plan_rowmap(rowptr, col, n, args.reorder)
+            if rowmap is not None:
+                rp2, c2, v2 = dev.permute_rows(rowptr, col, val, rowmap)
+                csr = dev.DeviceCSR(rp2, c2, v2, (n, n), strict=args.strict).set_rowmap(rowmap)
+            else:
+                csr = dev.DeviceCSR(rowptr, col, val, (n, n), strict=args.strict)
+        else:
+            csr = dev.DeviceCSR(rowptr, col, val, (rowptr.numel() - 1, n), strict=args.strict)
         n_out = rowptr.numel() - 1
         free, _ = torch.cuda.mem_get_info()
         pingpong = n_out == n and K > 2 and K * n_out * dev.row_pitch(d) * 4 > free // 2
@@ -314,6 +330,8 @@ class GpuEngine:
         outs = [dev.padded_parent(b) for b in bufs]
 
         info = csr.info()
+        if reorder_info is not None:
+            info["reorder"] = reorder_info
         if pingpong:
             info["hops_retained"] = "last two only (K hop matrices of this size do not fit one GPU)"
         # what validate_single() looks at after the timed region: the operand and the result of the LAST launch of a step

@@ -501,6 +501,14 @@ def section_s1_community(args, engine):
         ok = ok and same
     out["validated"] = bool(ok)
     out["roofline"] = out["reorder_auto"].get("roofline", out["reorder_none"]["roofline"])
+    # fabric-side bytes per launch from the builder's separate rocprofv3 --pmc passes over `bench.py --workload S1_community
+    # [--reorder auto]` (profiles/traffic.json): REPLAYED, not measured in this run -- against the algorithmic bytes of the no-reuse model
+    from .common import _replayed_profile
+    for key, tag in (("reorder_none", "none"), ("reorder_auto", "auto")):
+        prof = _replayed_profile(f"{name}_{tag}", 1)
+        if prof and prof.get("hbm_bytes_per_launch"):
+            out[key]["traffic_replayed"] = {"bytes_per_launch": prof["hbm_bytes_per_launch"], "over_algorithmic": prof["hbm_bytes_per_launch"] / alg,
+                                            "source": prof.get("source")}
     return out
 
 
@@ -568,7 +576,9 @@ def compact_sections(sections):
                       "reorder_auto": {"ms_per_hop": _r(ra.get("ms_per_hop")), "frac": _r(ra["roofline"]["frac"]) if "roofline" in ra else None,
                                        "applied": ra["plan"].get("applied"), "edge_locality": [ra["plan"].get("edge_locality_before"), ra["plan"].get("edge_locality_after")],
                                        "plan_ms": _r(ra["plan_ms"]), "bit_identical": ra.get("bit_identical_to_reorder_none")},
-                      "frac_model": "no-reuse bytes: may exceed 1 when gathers hit in cache"})
+                      "frac_model": "no-reuse bytes: may exceed 1 when gathers hit in cache",
+                      "traffic_over_algorithmic_replayed": [_r((s["reorder_none"].get("traffic_replayed") or {}).get("over_algorithmic")),
+                                                            _r((ra.get("traffic_replayed") or {}).get("over_algorithmic"))]})
         out[name] = {k: v for k, v in c.items() if v is not None}
     return out
 

@@ -215,19 +215,28 @@ class GraphOp:
     def _checked(self, adj, feature):
         """_construct_adj BEFORE validation (reference order, base_op.py:20-27), then the reference's exceptions"""
         self._adj = self._construct_adj(adj)
+        self._validate_inputs(adj, feature, self._adj.shape[1])
 
+    def _validate_inputs(self, adj, feature, n_cols):
+        """the reference's type / shape exceptions (base_op.py:22-27) -- needs no normalised adjacency, only its column count"""
         from ..io import DeviceAdjacency
         if not isinstance(adj, (sp.csr_matrix, DeviceAdjacency)):
             raise TypeError("The adjacency matrix must be a scipy csr sparse matrix!")
         elif not isinstance(feature, np.ndarray) and not (isinstance(feature, Tensor) and not self._opt("strict_types")):
             raise TypeError("The feature matrix must be a numpy.ndarray!")
-        elif self._adj.shape[1] != feature.shape[0]:
+        elif n_cols != feature.shape[0]:
             raise ValueError("Dimension mismatch detected for the adjacency and the feature matrix!")
         if self._opt("strict_types") and feature.dtype != np.float32:
             # the reference's ctypes ndpointer(float32) rejects anything else (operators/utils.py:22-26)
             raise TypeError("The feature matrix must be a float32 numpy.ndarray!")
         if feature.ndim != 2:
             raise ValueError("The feature matrix must be two-dimensional!")
+
+    def _target_device(self):
+        dv = torch.device(self._opt("device") or "cuda")
+        if dv.type == "cuda" and dv.index is None:
+            dv = torch.device("cuda", torch.cuda.current_device())
+        return dv
 
     def _device_features(self, feature):
         """the input features as a [n, d] view of a 16-byte aligned, line-aware-pitch device buffer"""
@@ -322,11 +331,18 @@ class GraphOp:
     def _propagate_or_cache(self, adj, feature):
         cache_dir = self._opt("hop_cache_dir")
         if config.share_hops and not cache_dir and not self._opt("host_output") and not self._opt("slab_hops"):
-            # process-wide store of device-resident hop lists (hopcache.SharedHops): the reference's exceptions first, then the lookup
-            self._checked(adj, feature)
+            # process-wide store of device-resident hop lists (hopcache.SharedHops): the reference's exceptions first, then the lookup.
+            # The normalised adjacency and its SpMM plan are NOT built here: a hit (or a PPR chain mixed from the Laplacian's) never
+            # needs them; the real-miss branch below builds them through _propagate
+            from .. import _lib
+            _lib.require_gpu()
+            if not (sp.issparse(adj) or hasattr(adj, "rowptr")):
+                self._checked(adj, feature)                         # not a matrix at all: let the reference's own order of errors apply
+            else:
+                self._validate_inputs(adj, feature, adj.shape[1])
             from ..hopcache import SHARED
             r, alpha = self._norm_params()
-            dkey = SHARED.data_key(adj, feature, self._adj.device)
+            dkey = SHARED.data_key(adj, feature, self._target_device())
             strict = bool(self._opt("strict_order"))
             hops = SHARED.lookup(dkey, type(self).__name__, r, alpha, self._prop_steps, strict)
             if hops is None and alpha is not None and not strict:
@@ -337,7 +353,7 @@ class GraphOp:
                                  cache_adj=self._cache_adj, reorder=self._reorder).propagate(adj, feature)
                 hops = SHARED.lookup(dkey, type(self).__name__, r, alpha, self._prop_steps, strict)
             if hops is None:
-                hops = self._propagate(adj, feature, checked=True)
+                hops = self._propagate(adj, feature)                # the real miss: normalise, plan, k SpMMs
                 if torch.is_tensor(feature) and hops[0].data_ptr() == feature.data_ptr():
                     hops[0] = hops[0].clone()                  # the caller may edit its tensor later; the stored hop 0 must not follow
                 SHARED.store(dkey, type(self).__name__, r, alpha, strict, hops)

@@ -3112,9 +3112,16 @@ def test_shared_hop_store_serves_fresh_operators(goldens, cuda):
                 assert rep["ok"], (key, h, rep)
                 n_checked += 1
             h0 = store.stats["hits"]
-            assert all(a_ is b_ for a_, b_ in zip(hops, PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"]).propagate(g, x)))
+            fresh = PprGraphOp(m["K"], r=m["r"], alpha=m["alpha"])
+            assert all(a_ is b_ for a_, b_ in zip(hops, fresh.propagate(g, x)))
             assert store.stats["hits"] == h0 + 1
+            assert fresh._adj is None             # a hit builds neither the normalised adjacency nor an SpMM plan
         assert n_checked >= 15
+        # the reference's exceptions still come first, hit or miss
+        with pytest.raises(TypeError, match="scipy csr sparse matrix"):
+            LaplacianGraphOp(2).propagate(g.tocoo(), x)
+        with pytest.raises(ValueError, match="Dimension mismatch"):
+            LaplacianGraphOp(2).propagate(g, x[:-1])
         # strict order: propagates itself (bit-identical to the strict chain without the store), and then answers relaxed requests
         g = goldens.graph("pl256")
         x = hash_matrix(256, 24, seed=5)
