@@ -429,8 +429,8 @@ int sgl_gather_rows_padded_f32(const float *d_x, int64_t ldx, int64_t n_rows, co
                                int64_t ldo, int64_t d, int64_t pad_cols, void *stream);
 /* The same rows of EVERY hop matrix in ONE launch: out_h[i, :] = X_h[idx[i], :] for h < n_hops (host arrays of n_hops device pointers
  * and pitches; every X_h has n_rows rows, every out_h n_idx rows; pad_cols as above).  The training feed of the learnable aggregators,
- * `[feat[idx].to(device) for feat in self._processed_feat_list]` (sgl/models/base_model.py:58-60): the indices are read once per row
- * for all hops.  16-byte aligned rows and pitches that are multiples of 4 floats on both sides, else SGL_ERR_UNSUPPORTED. */
+ * `[feat[idx].to(device) for feat in self._processed_feat_list]` (sgl/models/base_model.py:58-60): one grid over (hop, block of rows),
+ * no launch gaps between the hops.  16-byte aligned rows and pitches that are multiples of 4 floats on both sides, else SGL_ERR_UNSUPPORTED. */
 int sgl_gather_hops_padded_f32(int n_hops, const float *const *h_x, const int64_t *h_ldx, int64_t n_rows, const int64_t *d_idx,
                                int64_t n_idx, float *const *h_out, const int64_t *h_ldo, int64_t d, int64_t pad_cols, void *stream);
 /* out[dst[i], :] = X[src[i], :] for i < n_idx   (src, dst: int64 on device, dst entries distinct and < n_out_rows; a bad index

@@ -1226,6 +1226,53 @@ __global__ __launch_bounds__(256) void gather_hops_kernel(const Hops hx, const H
     }
 }
 
+// The same copy with the hop in blockIdx.y: every (hop, block of rows) is a workgroup of gather_rows_kernel's shape -- U index loads,
+// U row loads, U stores per thread -- in ONE grid, so the launch is H times larger than a hop's own (no launch gaps, one ramp) and
+// every thread is the short three-round-trip program of the per-hop kernel.  The indices are re-read per hop (n_idx x 8 bytes: L2).
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void gather_hops_y_kernel(const Hops hx, const HopsOut ho, const int64_t n_rows,
+                                                            const int64_t *__restrict__ idx, const int64_t n_idx, const int d,
+                                                            const int dz) {
+    constexpr int RPB = 256 / LPR;
+    const int h = blockIdx.y;
+    const float *__restrict__ x = hx.p[h];
+    const int64_t ldx = hx.ld[h];
+    float *__restrict__ out = ho.p[h];
+    const int64_t ldo = ho.ld[h];
+    const int l = threadIdx.x % LPR;
+    const int64_t i0 = (int64_t)blockIdx.x * (RPB * U) + threadIdx.x / LPR;
+    int64_t src[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * RPB;
+        int64_t s = i < n_idx ? idx[i] : 0;
+        if (s < 0) s += n_rows;
+        if (s < 0 || s >= n_rows) __builtin_trap();
+        src[u] = s;
+    }
+    for (int c = l * 4; c < d; c += LPR * 4) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c < dz) {
+                v[u] = *reinterpret_cast<const f4 *>(x + src[u] * ldx + c);
+                if (c + 4 > dz) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e >= dz) v[u][e] = 0.f;
+                }
+            } else {
+                v[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * RPB;
+            if (i < n_idx) __builtin_nontemporal_store(v[u], reinterpret_cast<f4 *>(out + i * ldo + c));
+        }
+    }
+}
+
 // out[:, h*d + k] = X_h[:, k]
 template <int VEC>
 __global__ __launch_bounds__(256) void hop_concat_kernel(const Hops hx, const int n_hops, float *__restrict__ out,
@@ -2354,6 +2401,36 @@ SGL_EXPORT int sgl_gather_hops_padded_f32(int n_hops, const float *const *h_x, c
         if (sgl::tuning("gather_lpr", 0) > 0) lpr = (int)sgl::tuning("gather_lpr", 0);
     }
     const int rpb = 256 / lpr;
+    if (sgl::tuning("gather_hops_grid", 1) != 0 && n_hops <= 65535) {
+        // hop in blockIdx.y (gather_hops_y_kernel), the default.  Per launch with ten launches queued, 200 000 rows (profiles/
+        // r06_gather_hops.log): d = 100, H = 4: 0.122 ms (0.65 of 8 TB/s; hop loop 0.124), d = 147, H = 6: 0.281 (0.63; 0.303),
+        // d = 128, H = 11: 0.384 (0.73; 0.403) -- one row per thread, two for rows shorter than four lines (d = 100: 0.129 -> 0.122)
+        int uy = (dw * 4 < 512) ? 2 : 1;
+        if (sgl::tuning("gather_rows_per_thread", 0) > 0) uy = (int)sgl::tuning("gather_rows_per_thread", 0);
+        if (uy != 1 && uy != 2 && uy != 4 && uy != 8) uy = 4;
+        const int64_t by = (n_idx + (int64_t)rpb * uy - 1) / ((int64_t)rpb * uy);
+        if (!sgl::launch_fits(by * n_hops, 256)) return sgl::fail(SGL_ERR_UNSUPPORTED, "sgl_gather_hops_padded_f32: too many indices for one launch");
+#define SGL_GY(L, UU) hipLaunchKernelGGL((gather_hops_y_kernel<L, UU>), dim3((unsigned)by, (unsigned)n_hops), dim3(256), 0, st, hx, ho, n_rows, d_idx, n_idx, (int)dw, (int)d)
+#define SGL_GYU(L)                     \
+    do {                               \
+        if (uy == 1) SGL_GY(L, 1);     \
+        else if (uy == 2) SGL_GY(L, 2); \
+        else if (uy == 8) SGL_GY(L, 8); \
+        else SGL_GY(L, 4);             \
+    } while (0)
+        switch (lpr) {
+            case 8: SGL_GYU(8); break;
+            case 16: SGL_GYU(16); break;
+            case 32: SGL_GYU(32); break;
+            default: SGL_GYU(64); break;
+        }
+#undef SGL_GYU
+#undef SGL_GY
+        hipError_t ey = hipGetLastError();
+        if (ey != hipSuccess) return sgl::fail((int)ey, "sgl_gather_hops_padded_f32: kernel launch failed: %s", hipGetErrorString(ey));
+        return SGL_OK;
+    }
+    // gather_hops_grid = 0: the first form, a hop loop inside the thread (3-8 % slower than the grid form above, kept for comparison).
     // one row per thread: with HB = 4 hops per batch a thread already keeps 4 independent row loads in flight, and the grid stays
     // n_idx / rows-per-block workgroups whatever H is (measured, profiles/r06_gather_hops.log: 1 row 0.153 ms, 2 rows 0.158, 4 rows
     // 0.164 for 200 000 rows of 4 hops at d = 100; hop by hop 0.162)

@@ -39,6 +39,7 @@ static std::map<std::string, int64_t> &tune_map() {
         {"row_narrow_groups", 1},  // row-wise kernels: 16 lanes x 3 / 8 lanes x 5 chunks when that at least halves the idle lane slots
                                    // (0 = off, 1 = both, 2 = 16 x 3 only, 3 = 8 x 5 only)
         {"gather_lpr", 0},       // row gather / scatter: 0 = the lane group that idles the fewest slots; 8 / 16 / 32 / 64 force one
+        {"gather_hops_grid", 1},         // sgl_gather_hops_padded_f32: 1 = hop in blockIdx.y (default), 0 = hop loop inside the thread
         {"gather_rows_per_thread", 0},   // 0 = sized so that the grid is about one round of the chip (1 ... 16); else 1 / 2 / 4 / 8 / 16
         {"concat_flat_read", 1}, // whole-rows concat: read whole pitches contiguously across the block's rows (0 = row by row, hop by hop)
         {"concat_lds", 1},       // any-width concat of rows >= 256 floats: assemble the output row in LDS (1 = auto: whole rows per block

@@ -110,6 +110,18 @@ def main():
         gout_ = dev.alloc_rows(200_000, d, device)
         rep("  gather_rows 200k (10 queued, per launch)", timeit(lambda: [dev.gather_rows(feats[0], idx, out=gout_) for _ in range(10)]) / 10,
             2 * 200_000 * d * 4)
+        rep(f"  gather_hops 200k x {H} hops (10 queued, per launch)", timeit(lambda: [dev.gather_hops(feats, idx) for _ in range(10)]) / 10,
+            2 * H * 200_000 * d * 4)
+        for g_, u_ in ((0, 0), (1, 1), (1, 2), (1, 4)):                  # 0: hop loop inside the thread (round 6, first form); 1: hop in blockIdx.y
+            _lib.set_tuning("gather_hops_grid", g_)
+            _lib.set_tuning("gather_rows_per_thread", u_)
+            ok_ = all(torch.equal(a_, b_) for a_, b_ in zip(dev.gather_hops(feats, idx), g_ref))
+            what_ = "hop loop in the thread" if g_ == 0 else f"hop in the grid, rows/thread={u_}"
+            rep(f"  gather_hops {what_}, single call (bit-identical {ok_})", timeit(lambda: dev.gather_hops(feats, idx)), 2 * H * 200_000 * d * 4)
+            rep(f"  gather_hops {what_} (10 queued, per launch)",
+                timeit(lambda: [dev.gather_hops(feats, idx) for _ in range(10)]) / 10, 2 * H * 200_000 * d * 4)
+        _lib.set_tuning("gather_hops_grid", 1)
+        _lib.set_tuning("gather_rows_per_thread", 0)
         rep("  contiguous copy 200k (10 queued, per launch)",
             timeit(lambda: [dev.padded_parent(gout_).copy_(dev.padded_parent(feats[0][:200_000])) for _ in range(10)]) / 10, 2 * 200_000 * d * 4)
         # what a launch of THIS size can reach at all: the same bytes as one contiguous copy, and a sorted (nearly sequential) gather
