@@ -439,6 +439,13 @@ int sgl_gather_hops_padded_f32(int n_hops, const float *const *h_x, const int64_
 int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_rows, const int64_t *d_src, const int64_t *d_dst,
                          int64_t n_idx, float *d_out, int64_t ldo, int64_t n_out_rows, int64_t d, void *stream);
 
+/* Per-column content signature of a DEVICE matrix: d_sig[c] = wrapping 64-bit sum over the rows r of mix(bits(X[r, c]), r), for
+ * c < round_up(d, 4) (uint64 on device; rows 16-byte aligned, pitch a multiple of 4 floats covering round_up(d, 4)).  One streaming
+ * read.  GraphOp.propagate (sgl/operators/base_op.py:29-35) is separable by columns: between two calls over one adjacency only the
+ * columns whose signature moved need new hops -- the label-reuse loop (sgl/tasks/node_classification_with_label_use.py:88-104)
+ * rewrites the last C of its d + C columns between preprocess() calls. */
+int sgl_col_signature_f32(const float *d_x, int64_t ldx, int64_t n, int64_t d, uint64_t *d_sig, void *stream);
+
 /* order-sensitive 64-bit hash of a HOST buffer, multi-threaded (what the reference-signature shims key their cached adjacency
  * on; the operator layer fingerprints scipy index / value arrays with it).  Host-only: works without a GPU. */
 int sgl_content_hash(const void *h_ptr, int64_t bytes, uint64_t *out);

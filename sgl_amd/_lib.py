@@ -122,6 +122,7 @@ PROTOTYPES = {
                                            c_void_p]),
     "sgl_scatter_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                      c_int64, c_void_p]),
+    "sgl_col_signature_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "sgl_content_hash": (c_int, [c_void_p, c_int64, POINTER(c_uint64)]),
 }
 

@@ -41,6 +41,16 @@ trace         True (SGL_AMD_TRACE=1) -> every GraphOp.propagate() records the wa
               upload / normalise / plan; features: upload; hops: the k SpMMs; output: download or cache), synchronising at the phase
               ends, in `op.last_trace` and prints them on stderr -- the reference times its whole preprocess() with time.time() and a
               print (tasks/node_classification.py:34-38)
+delta_propagate  True (default) -> GraphOp.propagate remembers a 64-bit content signature per feature COLUMN (sgl_col_signature_f32: one
+              streaming read) and, weakly, the hop matrices it returned.  The product is separable by columns, so when the next call
+              comes with the same adjacency, the same shape, the previous hop matrices still alive and untouched, and only some
+              columns of X changed -- the label-reuse loop rewrites the last C of d + C columns between its preprocess() calls
+              (sgl/tasks/node_classification_with_label_use.py:88-104) -- only the 4-aligned column range that covers the changed
+              columns is propagated again; the other columns of the NEW hop matrices are copied from the old ones.  Fresh tensors
+              are returned either way.  Bit-identical to a full propagation under strict_order; otherwise the narrower slice may
+              run in another lane layout (same result within 1e-5).  Only for feature matrices of at least delta_propagate_min_mb
+              (default 64) and when the range is at most delta_propagate_max_fraction (default 0.7) of the columns; `op.delta_info`
+              says what the last call did
 hop_cache_dir None -> every propagate() computes; a directory -> the hop matrices of propagate() are kept on disk under a key of
               the CONTENT of adjacency + features + operator parameters and loaded on a hit (sgl_amd/hopcache.py; the reference
               recomputes them in every run of every task)
@@ -63,6 +73,9 @@ cache_adj = _env_bool("SGL_AMD_CACHE_ADJ", True)
 cache_prepared = _env_bool("SGL_AMD_CACHE_PREPARED", True)
 cache_prepared_gb = float(os.environ.get("SGL_AMD_CACHE_PREPARED_GB", "8"))
 keep_sweep_values = _env_bool("SGL_AMD_KEEP_SWEEP_VALUES", False)
+delta_propagate = _env_bool("SGL_AMD_DELTA_PROPAGATE", True)
+delta_propagate_min_mb = float(os.environ.get("SGL_AMD_DELTA_PROPAGATE_MIN_MB", "64"))
+delta_propagate_max_fraction = float(os.environ.get("SGL_AMD_DELTA_PROPAGATE_MAX_FRACTION", "0.7"))
 share_hops = _env_bool("SGL_AMD_SHARE_HOPS", False)
 share_hops_gb = float(os.environ.get("SGL_AMD_SHARE_HOPS_GB", "64"))
 _fa = os.environ.get("SGL_AMD_FUSE_AGGREGATE", "auto").strip().lower()

@@ -2466,6 +2466,65 @@ SGL_EXPORT int sgl_scatter_rows_f32(const float *d_x, int64_t ldx, int64_t n_row
     return copy_rows("sgl_scatter_rows_f32", d_x, ldx, n_rows, d_src, d_dst, n_out_rows, n_idx, d_out, ldo, d, 0, stream);
 }
 
+// ---- per-column content signature ----------------------------------------------------------------------------------------------
+// sig[c] = sum over rows r of mix(bits(X[r, c]), r)  (64-bit wrapping sum: order-free, so any parallel schedule gives the same value).
+// What GraphOp.propagate compares between two calls over one adjacency: the product is separable by columns, so only the columns
+// whose signature moved need new hops (the label-reuse loop of node_classification_with_label_use.py:88-104 rewrites the last C of
+// d + C columns between its preprocess() calls).  One streaming read of X.
+__device__ __forceinline__ unsigned long long sig_mix(unsigned int bits, unsigned long long r) {
+    unsigned long long h = ((unsigned long long)bits ^ (r * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+    h *= 0x94D049BB133111EBull;
+    return h ^ (h >> 29);
+}
+
+__global__ __launch_bounds__(256) void col_signature_kernel(const float *__restrict__ x, const int64_t ld, const int64_t n, const int nv,
+                                                            const int nvp_log2, const int64_t rows_per_block,
+                                                            unsigned long long *__restrict__ out) {
+    const int v = threadIdx.x & ((1 << nvp_log2) - 1);
+    const int rsub = threadIdx.x >> nvp_log2, rstep = 256 >> nvp_log2;
+    if (v >= nv) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t r = r0 + rsub; r < r1; r += rstep) {
+        const f4 q = *reinterpret_cast<const f4 *>(x + r * ld + v * 4);
+        s0 += sig_mix(__float_as_uint(q[0]), (unsigned long long)r);
+        s1 += sig_mix(__float_as_uint(q[1]), (unsigned long long)r);
+        s2 += sig_mix(__float_as_uint(q[2]), (unsigned long long)r);
+        s3 += sig_mix(__float_as_uint(q[3]), (unsigned long long)r);
+    }
+    atomicAdd(out + v * 4 + 0, s0);   // integer adds: the result does not depend on their order
+    atomicAdd(out + v * 4 + 1, s1);
+    atomicAdd(out + v * 4 + 2, s2);
+    atomicAdd(out + v * 4 + 3, s3);
+}
+
+// d_sig[0 .. round_up(d, 4)) <- signatures of the columns of X [n, >= round_up(d, 4)] (16-byte aligned rows, ld % 4 == 0: the pitch
+// alloc_rows gives; the up-to-3 pad columns behind d are signed with the rest)
+SGL_EXPORT int sgl_col_signature_f32(const float *d_x, int64_t ldx, int64_t n, int64_t d, uint64_t *d_sig, void *stream) {
+    SGL_REQUIRE(n >= 0 && d >= 0 && d < INT32_MAX, "sgl_col_signature_f32: bad sizes");
+    const int64_t dw = (d + 3) / 4 * 4;
+    if (dw == 0) return SGL_OK;
+    SGL_REQUIRE(d_sig != nullptr, "sgl_col_signature_f32: NULL output");
+    hipStream_t st = sgl::as_stream(stream);
+    SGL_HIP_CHECK(hipMemsetAsync(d_sig, 0, (size_t)dw * sizeof(uint64_t), st));
+    if (n == 0) return SGL_OK;
+    SGL_REQUIRE(d_x && ldx >= dw && ldx % 4 == 0 && aligned_to(d_x, 16),
+                "sgl_col_signature_f32: rows must be 16-byte aligned with a pitch that is a multiple of 4 floats and covers round_up(d, 4)");
+    for (int64_t c0 = 0; c0 < dw; c0 += 1024) {                       // 256 vector columns per launch
+        const int nv = (int)(std::min<int64_t>(1024, dw - c0) / 4);
+        int lg = 0;
+        while ((1 << lg) < nv) ++lg;
+        const int rstep = 256 >> lg;
+        const int64_t rows_per_block = std::max<int64_t>((int64_t)rstep * 8, (n + 8191) / 8192);
+        const int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(col_signature_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_x + c0, ldx, n, nv, lg, rows_per_block,
+                           reinterpret_cast<unsigned long long *>(d_sig) + c0);
+    }
+    SGL_LAUNCH_CHECK("sgl_col_signature_f32");
+    return SGL_OK;
+}
+
 // ---- learnable gates -------------------------------------------------------------------------------------------------------
 // register-resident row kernels: H <= 16, d <= 512, 16-byte aligned rows.  Anything else -> SGL_ERR_UNSUPPORTED and the caller
 // takes the two-pass route (sgl_hop_rowdot_f32 + sgl_hop_wsum2d_f32).

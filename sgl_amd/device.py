@@ -1393,6 +1393,27 @@ def _device_index(idx, n_rows, device):
     return idx.to(device=device, dtype=torch.int64).contiguous().view(-1)
 
 
+def column_signature(x):
+    """per-column content signatures of a [n, d] float32 device matrix with 16-byte rows (sgl_col_signature_f32): an int64 device
+    tensor of round_up(d, 4) entries (the bits of the 64-bit sums), or None when the rows are not 16-byte vectors of a pitch that
+    covers round_up(d, 4) columns.  Two matrices of one shape differ in column c (almost surely) iff their signatures differ at c."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return None
+    n, d = x.shape
+    dw = round_up(d, 4)
+    if n == 0 or d == 0:
+        return None
+    ld = x.stride(0) if n > 1 else dw
+    if x.stride(1) != 1 or ld % 4 or ld < dw or x.data_ptr() % 16:
+        return None
+    if x.untyped_storage().nbytes() // 4 - x.storage_offset() < (n - 1) * ld + dw:
+        return None
+    sig = torch.empty(dw, dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().sgl_col_signature_f32(ptr(x), ld, n, d, ptr(sig), current_stream_ptr()), "sgl_col_signature_f32")
+    return sig
+
+
 def gather_hops(feats, idx, one_launch=None):
     """[x[idx] for x in feats]: the training feed of the learnable aggregators, `[feat[idx].to(device) for feat in
     self._processed_feat_list]` (sgl/models/base_model.py:58-60), with the indices validated and uploaded ONCE for all hop

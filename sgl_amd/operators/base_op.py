@@ -151,7 +151,7 @@ class GraphOp:
     # settings only and rebuilds them on its next propagate().
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_adj", "_adj_key", "_hop_cache", "_download_stream", "_prepared", "last_trace"):
+        for k in ("_adj", "_adj_key", "_hop_cache", "_download_stream", "_prepared", "last_trace", "_delta", "delta_info"):
             if k in state:
                 state[k] = None
         return state
@@ -397,7 +397,11 @@ class GraphOp:
             pooled = self._propagate_to_pooled_host(feature, cur, src, d, K)
             if pooled is not None:
                 return pooled
-        prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
+        prop_feat_list, sig = (None, None) if self._opt("host_output") else self._delta_propagate(cur, src, d, K)
+        if prop_feat_list is None:
+            prop_feat_list = [cur] + [y[:, :d] if y.shape[1] != d else y for y in self._adj.spmm_chain(src, self._prop_steps)]
+        if sig is not None:
+            self._delta_remember(sig, prop_feat_list, src.shape[1])
         self._phase_done("hops")
 
         if self._opt("host_output"):
@@ -413,6 +417,57 @@ class GraphOp:
             return out
         return prop_feat_list
 
+
+    # ---- only what changed (config.delta_propagate) -----------------------------------------------------------------------------
+    # A_hat . X is separable by columns.  The label-reuse loop (sgl/tasks/node_classification_with_label_use.py:88-104) calls
+    # preprocess() again and again on a matrix of which only the last C columns were rewritten; the reference propagates all d + C
+    # columns every time.  Here a call leaves behind the per-column content signature of its X and weak references to the hop
+    # matrices it returned; the next call re-propagates only the 4-aligned column range covering the columns whose signature moved
+    # and copies the others from the previous hop matrices into FRESH ones (nothing the caller holds is ever written).
+    delta_info = None
+
+    def _delta_propagate(self, cur, src, d, K):
+        """(hop list or None, signature of X or None)"""
+        self.delta_info = None
+        st, self._delta = self.__dict__.get("_delta"), None
+        n, ld = cur.shape[0], src.shape[1]
+        if not config.delta_propagate or K < 1 or n * ld * 4 < config.delta_propagate_min_mb * 2 ** 20:
+            return None, None
+        sig = dev.column_signature(cur)
+        if sig is None or st is None:
+            return None, sig
+        if st["adj"]() is not self._adj or st["shape"] != (n, d, K, ld) or st["sig"].device != sig.device:
+            return None, sig
+        old = [w() for w in st["hops"]]
+        if any(o is None for o in old) or any(o._version != v for o, v in zip(old, st["versions"])):
+            return None, sig                      # the previous hop matrices are gone, or somebody wrote into them
+        dw = sig.numel()
+        ch = torch.nonzero(sig != st["sig"]).flatten().cpu().numpy()
+        c0, c1 = (0, 0) if ch.size == 0 else (int(ch.min()) // 4 * 4, min(dw, (int(ch.max()) // 4 + 1) * 4))
+        if c1 - c0 > config.delta_propagate_max_fraction * dw:
+            return None, sig
+        outs, prev = [], src
+        for k in range(K):
+            y = dev.padded_parent(dev.alloc_rows(n, d, cur.device))
+            oldp = dev.padded_parent(old[k])
+            if c0 > 0:
+                y[:, :c0].copy_(oldp[:, :c0])
+            if c1 < dw:
+                y[:, c1:dw].copy_(oldp[:, c1:dw])
+            if c1 > c0:
+                self._adj.spmm(prev[:, c0:c1], out=y[:, c0:c1])
+            outs.append(y)
+            prev = y
+        self.delta_info = {"columns_propagated": (c0, c1), "columns_changed": int(ch.size), "of": d}
+        return [cur] + [y[:, :d] if y.shape[1] != d else y for y in outs], sig
+
+    def _delta_remember(self, sig, hops, ld):
+        import weakref
+        try:
+            self._delta = {"adj": weakref.ref(self._adj), "shape": (hops[0].shape[0], hops[0].shape[1], len(hops) - 1, ld), "sig": sig,
+                           "hops": [weakref.ref(h) for h in hops[1:]], "versions": [h._version for h in hops[1:]]}
+        except TypeError:
+            self._delta = None
 
     def _propagate_to_pooled_host(self, feature, cur, src, d, K):
         """host_output=True with destinations from the pinned pool (sgl_amd/hostpool.py): the hops are launched one by one and

@@ -2148,14 +2148,21 @@ def test_forward_over_a_contiguous_row_range_reads_the_hops_in_place(goldens, cu
         assert take_rows(feats[0], range(0, 10, 2), cuda).data_ptr() != feats[0].data_ptr()      # a strided range is gathered
 
 
-def test_label_reuse_loop_matches_reference_task(goldens, cuda):
+@pytest.mark.parametrize("delta", [False, True])
+def test_label_reuse_loop_matches_reference_task(goldens, cuda, delta, monkeypatch):
     """BASELINE config 3's loop (tasks/node_classification_with_label_use.py:58-137: label use every epoch, label reuse from epoch 1
     on, `preprocess` re-run after every write-back) on the device -- sgl_amd.tricks.add_labels / label_reuse, GAMLP with the
     reference's saved parameters, d + C = 147 columns, K = 5 -- against G10, which the reference's own task code recorded: after
     EVERY preprocess call the label columns (sampled rows), the column sums of the feature matrix and the fp64 sums of all six hop
     matrices; at the end hop 1 / 3 / 5 rows and the logits.  Nothing leaves the GPU inside the loop."""
+    from sgl_amd import config
     from sgl_amd.models.homo import GAMLP
     from sgl_amd.tricks import add_labels, label_reuse
+    # delta: every preprocess call after the first re-propagates only the label columns (config.delta_propagate, forced on for this
+    # small graph) -- the same goldens must hold; without it every call propagates all d + C columns
+    monkeypatch.setattr(config, "delta_propagate", delta)
+    monkeypatch.setattr(config, "delta_propagate_min_mb", 0.0)
+    deltas = []
     g10 = goldens.npz("g10_label_reuse")
     g12 = goldens.npz("g12_fp64_truth")
     n, d, C, K = (int(g10[k]) for k in ("n", "d", "C", "K"))
@@ -2180,6 +2187,7 @@ def test_label_reuse_loop_matches_reference_task(goldens, cuda):
         cs = features.double().sum(0).cpu().numpy()
         assert np.allclose(cs, g10[f"call{i}|feature_colsum"], rtol=1e-4, atol=1e-2), i
         real_pre(adj, features)
+        deltas.append(model._pre_graph_op.delta_info)
         sums = np.array([h.double().sum().item() for h in model._processed_feat_list])
         assert len(sums) == K + 1 and np.allclose(sums, g10[f"call{i}|hop_sums"], rtol=1e-4, atol=1e-2), (i, sums, g10[f"call{i}|hop_sums"])
         calls.append(i)
@@ -2197,6 +2205,10 @@ def test_label_reuse_loop_matches_reference_task(goldens, cuda):
             assert set(unlabeled[: (~mask).sum()].tolist()) == set(train_pred.tolist())
             label_reuse(model, g, feats, unlabeled, C, 2, device=cuda, batch_size=700)
     assert len(calls) == 7
+    if delta:      # every call but the first found the previous hop matrices and re-propagated the label columns only
+        assert deltas[0] is None and all(di is not None and di["columns_propagated"] == (d // 4 * 4, (d + C + 3) // 4 * 4) for di in deltas[1:]), deltas
+    else:
+        assert all(di is None for di in deltas)
     hops = model._processed_feat_list
     for h in (1, 3, 5):
         rep = oracle.truth_report(hops[h][sub].cpu().numpy(), g10[f"final|hop{h}_sub"], g12[f"g10|final|hop{h}_sub"])
@@ -2208,6 +2220,109 @@ def test_label_reuse_loop_matches_reference_task(goldens, cuda):
     assert rep["ok"], rep
     assert oracle.parity_ok(logits[sub].cpu().numpy(), g10["final|logits_sub"], TOL, rowwise=False)
     assert np.allclose(logits.double().sum(0).cpu().numpy(), g10["final|logits_colsum"], rtol=1e-3, atol=1e-2)
+
+
+def test_column_signature_matches_its_definition(cuda):
+    """sgl_col_signature_f32 against a numpy statement of its definition: sig[c] = sum_r mix(bits(X[r, c]), r) mod 2^64"""
+    def mix(bits, r):
+        with np.errstate(over="ignore"):
+            h = (bits.astype(np.uint64) ^ (r.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0xBF58476D1CE4E5B9)
+            h ^= h >> np.uint64(31)
+            h *= np.uint64(0x94D049BB133111EB)
+            return h ^ (h >> np.uint64(29))
+    for n, d in ((1, 4), (7, 3), (1000, 147), (4097, 100), (300, 1030), (513, 64)):
+        xp = dev.alloc_rows(n, d, cuda)
+        xp.copy_(torch.from_numpy(hash_matrix(n, d, seed=n + d)).to(cuda))
+        sig = dev.column_signature(xp)
+        dw = (d + 3) // 4 * 4
+        assert sig is not None and sig.numel() == dw
+        full = dev.padded_parent(xp)[:, :dw].cpu().numpy()
+        with np.errstate(over="ignore"):
+            want = mix(full.view(np.uint32), np.arange(n, dtype=np.uint64)[:, None]).sum(axis=0, dtype=np.uint64)
+        assert np.array_equal(sig.cpu().numpy().view(np.uint64), want), (n, d)
+        # one element moved -> exactly its column's signature moves; two rows swapped -> every column that differs between them
+        if n > 1:
+            xp[n // 2, d - 1] += 1.0
+            sig2 = dev.column_signature(xp)
+            assert torch.nonzero(sig2 != sig).flatten().tolist() == [d - 1]
+    assert dev.column_signature(torch.zeros((5, 3), device=cuda)) is None          # 12-byte rows: not 16-byte vectors
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_delta_propagate_recomputes_only_the_changed_columns(goldens, cuda, strict, monkeypatch):
+    """config.delta_propagate: the second propagate() over one adjacency re-propagates the column range whose content changed and
+    copies the rest from the hop matrices of the first call -- into fresh tensors, bit-identical to a full propagation in strict
+    order, within the tolerance otherwise; every reason not to trust the previous hop matrices leads to a full propagation."""
+    from sgl_amd import config
+    from sgl_amd.operators.graph_op import LaplacianGraphOp, PprGraphOp
+    monkeypatch.setattr(config, "delta_propagate", True)
+    monkeypatch.setattr(config, "delta_propagate_min_mb", 0.0)
+    g = goldens.graph("pl2000")
+    n, d, C, K = g.shape[0], 147, 47, 5
+    x = dev.alloc_rows(n, d, cuda)
+    x.copy_(torch.from_numpy(hash_matrix(n, d, seed=77)).to(cuda))
+
+    def full(xx, cls=LaplacianGraphOp, **kw):
+        monkeypatch.setattr(config, "delta_propagate", False)
+        try:
+            return cls(K, strict_order=strict, **kw).propagate(g, xx.clone())
+        finally:
+            monkeypatch.setattr(config, "delta_propagate", True)
+
+    for cls, kw in ((LaplacianGraphOp, {}), (PprGraphOp, {"alpha": 0.2})):
+        x.copy_(torch.from_numpy(hash_matrix(n, d, seed=77)).to(cuda))
+        op = cls(K, strict_order=strict, **kw)
+        h1 = op.propagate(g, x)
+        assert op.delta_info is None
+        keep1 = [h.clone() for h in h1]
+        x[:, d - C:] = torch.from_numpy(hash_matrix(n, C, seed=78)).to(cuda)          # in place, like features[unlabeled, -C:] = ...
+        h2 = op.propagate(g, x)
+        assert op.delta_info == {"columns_propagated": (100, 148), "columns_changed": C, "of": d}
+        want = full(x, cls, **kw)
+        for k in range(K + 1):
+            assert h2[k].data_ptr() not in [t.data_ptr() for t in h1[1:]]              # fresh tensors
+            if strict:
+                assert torch.equal(h2[k], want[k]), (cls.__name__, k)
+            else:
+                assert torch.equal(h2[k][:, :d - C], want[k][:, :d - C]), (cls.__name__, k)    # copied columns: the same bits
+                assert oracle.parity_ok(h2[k].cpu().numpy(), want[k].cpu().numpy(), TOL), (cls.__name__, k)
+            if k:
+                assert torch.equal(h1[k], keep1[k])                                     # nothing the caller holds was written
+                assert float(dev.padded_parent(h2[k])[:, d:].abs().max()) == 0.0        # pad columns stay zero
+        # unchanged X: a copy of the previous hops
+        h3 = op.propagate(g, x)
+        assert op.delta_info["columns_propagated"] == (0, 0) and all(torch.equal(a, b) for a, b in zip(h3, h2))
+        # one column in the middle
+        x[:, 50] += 1.0
+        h4 = op.propagate(g, x)
+        assert op.delta_info["columns_propagated"] == (48, 52)
+        want = full(x, cls, **kw)
+        assert all(oracle.parity_ok(a.cpu().numpy(), b.cpu().numpy(), TOL) for a, b in zip(h4, want))
+        assert (not strict) or all(torch.equal(a, b) for a, b in zip(h4, want))
+        # reasons for a full propagation: the caller wrote into a previous hop matrix; the previous list is gone; too many columns
+        h4[2].mul_(1.0)
+        x[:, 50] += 1.0
+        h5 = op.propagate(g, x)
+        assert op.delta_info is None
+        del h1, h2, h3, h4, h5
+        x[:, 50] += 1.0
+        h6 = op.propagate(g, x)
+        assert op.delta_info is None
+        x[:, ::8] += 1.0                                                                # columns 0, 8, ..., 144: the range is everything
+        h7 = op.propagate(g, x)
+        assert op.delta_info is None
+        want = full(x, cls, **kw)
+        assert all(oracle.parity_ok(a.cpu().numpy(), b.cpu().numpy(), TOL) for a, b in zip(h7, want))
+        # another adjacency object with the same operator: nothing of the old chain may be reused
+        g2 = (g + sp.identity(n, dtype=g.dtype, format="csr")).tocsr()
+        x[:, d - 1] += 1.0
+        h8 = op.propagate(g2, x)
+        assert op.delta_info is None
+        monkeypatch.setattr(config, "delta_propagate", False)
+        want = cls(K, strict_order=strict, **kw).propagate(g2, x.clone())
+        monkeypatch.setattr(config, "delta_propagate", True)
+        assert all(oracle.parity_ok(a.cpu().numpy(), b.cpu().numpy(), TOL) for a, b in zip(h8, want))
+        del h6, h7, h8
 
 
 def test_spmm_axpb_clamp_epilogue(cuda):
@@ -2766,6 +2881,8 @@ def test_bench_secondary_sections_cover_every_baseline_config(cuda, monkeypatch,
     assert sec["S0_pubmed"]["strict_order_bit_equal_to_cpu_oracle"] is True and sec["S0_pubmed"]["fast_order_row_l2_rel"] <= TOL
     assert sec["S0_pubmed"]["cpu_baseline"]["propagate_ms"] > 0
     assert len(sec["S2_gamlp"]["preprocess_calls_ms"]) == 3 and sec["S2_gamlp"]["train_feed_ms"] > 0
+    cpc = sec["S2_gamlp"]["columns_propagated_per_call"]              # calls 2 and 3 re-propagate the label columns only
+    assert cpc[0] > cpc[1] == cpc[2] == 48 and sec["S2_gamlp"]["full_recompute_call_ms"] > 0, cpc
     for name in ("S4_products", "S4_papers_shard"):
         assert len(sec[name]["message_ops"]) == 10 and all(r[3] is True for r in sec[name]["message_ops"]), sec[name]["message_ops"]
         assert all(g[4] is True for g in sec[name]["graph_ops"])
