@@ -82,10 +82,12 @@ def main():
     print("preprocess() calls, ms: " + " ".join(f"{c:.1f}" for c in calls))
     print("label use + reuse per epoch (add_labels, (1 + label_iters) x preprocess, label_iters x full prediction + write-back), ms: "
           + " ".join(f"{c:.1f}" for c in epoch_ms))
-    nnz_hat = adj.nnz + n
-    rate = nnz_hat * (d + C + 1) * a.prop_steps * n_prep / t_prep    # padded width d + C rounded up to 148
-    print(f"{n_prep} preprocess() calls, {a.prop_steps} hops each over [N={n}, {d + C}]: {t_prep / n_prep * 1e3:.1f} ms per call "
-          f"({rate / 1e12:.3f}e12 edge*feat/s incl. first-call normalisation); mini-batch training {t_train:.2f}s")
+    di = getattr(model._pre_graph_op, "delta_info", None)
+    what = "every column propagated in every call" if di is None else \
+        (f"calls after the first re-propagate columns {di['columns_propagated'][0]}..{di['columns_propagated'][1]} only "
+         f"(config.delta_propagate: the others are copied from the previous hop matrices)")
+    print(f"{n_prep} preprocess() calls, {a.prop_steps} hops each over [N={n}, {d + C}]: {t_prep / n_prep * 1e3:.1f} ms per call incl. first-call "
+          f"normalisation; {what}; mini-batch training {t_train:.2f}s")
 
 
 if __name__ == "__main__":
