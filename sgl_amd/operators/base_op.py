@@ -448,12 +448,8 @@ class GraphOp:
             return None, sig
         outs, prev = [], src
         for k in range(K):
-            y = dev.padded_parent(dev.alloc_rows(n, d, cur.device))
-            oldp = dev.padded_parent(old[k])
-            if c0 > 0:
-                y[:, :c0].copy_(oldp[:, :c0])
-            if c1 < dw:
-                y[:, c1:dw].copy_(oldp[:, c1:dw])
+            # one contiguous copy of the whole pitched matrix (whole lines, pad columns included), then the slice is overwritten
+            y = dev.padded_parent(old[k]).clone(memory_format=torch.contiguous_format)
             if c1 > c0:
                 self._adj.spmm(prev[:, c0:c1], out=y[:, c0:c1])
             outs.append(y)
