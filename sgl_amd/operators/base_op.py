@@ -436,8 +436,8 @@ class GraphOp:
         sig = dev.column_signature(cur)
         if sig is None or st is None:
             return None, sig
-        if st["adj"]() is not self._adj or st["shape"] != (n, d, K, ld) or st["sig"].device != sig.device:
-            return None, sig
+        if st["adj"]() is not self._adj or st["shape"] != (n, d, K, ld) or st["sig"].device != sig.device or st["val"] != self._val_token():
+            return None, sig                      # another matrix (or the same handle re-weighted), another shape
         old = [w() for w in st["hops"]]
         if any(o is None for o in old) or any(o._version != v for o, v in zip(old, st["versions"])):
             return None, sig                      # the previous hop matrices are gone, or somebody wrote into them
@@ -457,10 +457,15 @@ class GraphOp:
         self.delta_info = {"columns_propagated": (c0, c1), "columns_changed": int(ch.size), "of": d}
         return [cur] + [y[:, :d] if y.shape[1] != d else y for y in outs], sig
 
+    def _val_token(self):
+        v = getattr(self._adj, "val", None)
+        return (v.data_ptr(), v._version) if torch.is_tensor(v) else None
+
     def _delta_remember(self, sig, hops, ld):
         import weakref
         try:
-            self._delta = {"adj": weakref.ref(self._adj), "shape": (hops[0].shape[0], hops[0].shape[1], len(hops) - 1, ld), "sig": sig,
+            self._delta = {"adj": weakref.ref(self._adj), "val": self._val_token(),
+                           "shape": (hops[0].shape[0], hops[0].shape[1], len(hops) - 1, ld), "sig": sig,
                            "hops": [weakref.ref(h) for h in hops[1:]], "versions": [h._version for h in hops[1:]]}
         except TypeError:
             self._delta = None
