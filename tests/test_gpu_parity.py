@@ -3346,10 +3346,14 @@ def test_gather_hops_uploads_the_indices_once(cuda, monkeypatch):
         if one is not None:
             per_hop = dev.gather_hops(feats, dv_idx, one_launch=False)
             assert all(torch.equal(a_, b_) and torch.equal(dev.padded_parent(a_), dev.padded_parent(b_)) for a_, b_ in zip(one, per_hop))
-            for u_ in (2, 4):
-                _lib.set_tuning("gather_rows_per_thread", u_)
-                assert all(torch.equal(a_, b_) for a_, b_ in zip(dev._gather_hops_one_launch(feats, dv_idx), per_hop))
+            for grid_ in (1, 0):            # 1: the hop in blockIdx.y (default); 0: the hop loop inside the thread
+                _lib.set_tuning("gather_hops_grid", grid_)
+                for u_ in (0, 1, 2, 4):
+                    _lib.set_tuning("gather_rows_per_thread", u_)
+                    assert all(torch.equal(a_, b_) and torch.equal(dev.padded_parent(a_), dev.padded_parent(b_))
+                               for a_, b_ in zip(dev._gather_hops_one_launch(feats, dv_idx), per_hop)), (n, d, H, grid_, u_)
             _lib.set_tuning("gather_rows_per_thread", 0)
+            _lib.set_tuning("gather_hops_grid", 1)
     with pytest.raises(IndexError):
         dev.gather_hops(feats, [0, n])
     assert [tuple(t.shape) for t in dev.gather_hops(feats, [])] == [(0, 37)] and dev.gather_hops([], [1]) == []
